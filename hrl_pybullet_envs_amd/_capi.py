@@ -1,0 +1,53 @@
+"""ctypes mirror of include/hrl_envs.h (structs + constants only; no library loading here)."""
+import ctypes as C
+
+HRL_ABI_VERSION = 1
+HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER = 0, 1, 2, 3
+HRL_STATE_STRIDE = 32
+HRL_QPOS_OFF, HRL_QVEL_OFF, HRL_EPRET_OFF, HRL_INITZ_OFF, HRL_POTENTIAL_OFF = 0, 15, 29, 30, 31
+HRL_ITEMS_STRIDE = 32
+HRL_MAX_ITEMS = 16
+HRL_MAX_BINS = 16
+HRL_AUX_STRIDE = 4
+HRL_INFO_STRIDE = 4
+HRL_MAX_TARGETS = 8
+HRL_OK, HRL_ERR_BAD_ARG, HRL_ERR_HIP, HRL_ERR_NO_DEVICE = 0, 1, 2, 3
+
+
+class hrl_model(C.Structure):
+    _fields_ = [('gravity', C.c_float), ('timestep', C.c_float), ('frame_skip', C.c_int32),
+                ('solver_iters', C.c_int32), ('density', C.c_float), ('torque_scale', C.c_float),
+                ('contact_erp', C.c_float), ('limit_erp', C.c_float), ('friction_ground', C.c_float),
+                ('friction_robot', C.c_float), ('contact_dist', C.c_float), ('limit_margin', C.c_float),
+                ('max_joint_vel', C.c_float), ('limit_max_impulse', C.c_float), ('ground_z', C.c_float),
+                ('point_force', C.c_float)]
+
+
+class hrl_config(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('env_kind', C.c_int32), ('num_envs', C.c_int32),
+                ('max_episode_steps', C.c_int32), ('env_id_offset', C.c_int64), ('seed', C.c_uint64),
+                ('auto_reset', C.c_int32),
+                ('n_food', C.c_int32), ('n_poison', C.c_int32), ('n_bins', C.c_int32),
+                ('use_sensor', C.c_int32), ('respawn', C.c_int32),
+                ('world_size', C.c_float * 2),
+                ('sensor_range', C.c_float), ('sensor_span', C.c_float), ('robot_coll_dist', C.c_float),
+                ('robot_object_spacing', C.c_float), ('dying_cost', C.c_float),
+                ('target_encoding', C.c_int32), ('sense_target', C.c_int32), ('sense_walls', C.c_int32),
+                ('done_at_target', C.c_int32), ('max_steps', C.c_int32), ('targ_dist_rew', C.c_int32),
+                ('n_targets', C.c_int32),
+                ('tol', C.c_float), ('inner_rew_weight', C.c_float),
+                ('targets', (C.c_float * 2) * HRL_MAX_TARGETS),
+                ('start_pos', C.c_float * 3),
+                ('centroid_n_static', C.c_int32), ('centroid_static_sum', C.c_float * 2),
+                ('walk_target', C.c_float * 2),
+                ('model', hrl_model)]
+
+    def copy(self):
+        c = hrl_config()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(hrl_config))
+        return c
+
+
+class hrl_buffers(C.Structure):
+    _fields_ = [('state', C.c_void_p), ('items', C.c_void_p), ('aux', C.c_void_p), ('actions', C.c_void_p),
+                ('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('info', C.c_void_p)]

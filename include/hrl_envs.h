@@ -1,0 +1,158 @@
+/*
+ * hrl_envs.h -- C-ABI of the MI355X-native batched Ant/Point environment step
+ * (hot path of sash-a/hrl_pybullet_envs).
+ *
+ * The reference has NO FFI/plugin ABI: its boundary is the old-gym `gym.Env` class API
+ * (reset() -> obs ; step(a) -> (obs, rew, done, info) ; seed(s)), see
+ *   hrl_pybullet_envs/__init__.py:11-16, README.md:24-34,
+ *   envs/gather/ant_gather_env.py:68-119, envs/ant_maze/ant_maze_bullet_env.py:77-121,
+ *   envs/gather/gather_base.py:67-109, envs/MjAnt.py:36-97.
+ * Beneath that class API the reference calls pybullet's C-API client (stepSimulation & getters).
+ * This header is the ABI a maintainer would bind in place of those pybullet calls: plain
+ * pointers + sizes, caller-owned buffers, int status returns, no C++/torch types.
+ *
+ * Every entry point documents the reference call site it replaces.
+ * All `float*`/`uint8_t*`/`int32_t*` buffer arguments of the hip library are DEVICE pointers;
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on
+ * that stream.  The library owns nothing but the immutable config copied at hrl_create().
+ */
+#ifndef HRL_ENVS_H
+#define HRL_ENVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HRL_ABI_VERSION 1
+
+/* env kinds */
+#define HRL_ANT_FLAT 0     /* AntMjEnv: flat ground, obs 29 (envs/MjAnt.py:31-97)                        */
+#define HRL_ANT_GATHER 1   /* AntGatherBulletEnv: obs 26 + 2*n_bins (envs/gather/ant_gather_env.py:12-200) */
+#define HRL_ANT_MAZE 2     /* AntMazeBulletEnv: obs 26 + 2 + n_bins (envs/ant_maze/ant_maze_bullet_env.py) */
+#define HRL_POINT_GATHER 3 /* PointGatherBulletEnv: obs 8 + 2*n_bins (envs/gather/point_gather_env.py)     */
+
+/* buffer geometry (floats / ints per env) */
+#define HRL_STATE_STRIDE 32 /* state record: qpos[15] | qvel[14] | ep_return | initial_z | potential */
+#define HRL_QPOS_OFF 0      /* x,y,z, qx,qy,qz,qw, hip_1,ankle_1,...,hip_4,ankle_4 (MjAnt.py:19-20)  */
+#define HRL_QVEL_OFF 15     /* vx,vy,vz, wx,wy,wz (world), joint rates (MjAnt.py:22-23)              */
+#define HRL_EPRET_OFF 29
+#define HRL_INITZ_OFF 30
+#define HRL_POTENTIAL_OFF 31
+#define HRL_ITEMS_STRIDE 32 /* 16 items x (x,y): food slots first, then poison slots */
+#define HRL_MAX_ITEMS 16
+#define HRL_MAX_BINS 16
+#define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index */
+#define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
+#define HRL_MAX_TARGETS 8
+
+/* status codes */
+#define HRL_OK 0
+#define HRL_ERR_BAD_ARG 1
+#define HRL_ERR_HIP 2
+#define HRL_ERR_NO_DEVICE 3
+
+/* Rigid-body model + solver parameters.  Defaults: hrl_default_config().  Physics constants the
+ * reference fixes in-tree: gravity 9.8, timestep 0.0165/4, frame_skip 4 (ant_gather_env.py:58,
+ * ant_maze_bullet_env.py:60); ground/wall friction 0.8, restitution 0.5
+ * (sizeable_enclosed_scene.py:60); Ant geometry/friction 1.5 (assets/ant.xml:9-58).  Everything
+ * else restates upstream pybullet behaviour from memory (unverified). */
+typedef struct hrl_model {
+    float gravity;           /* 9.8 */
+    float timestep;          /* 0.0165/4 (one physics substep) */
+    int32_t frame_skip;      /* 4 substeps per env step */
+    int32_t solver_iters;    /* 5 PGS iterations per substep */
+    float density;           /* 1000 kg/m^3 */
+    float torque_scale;      /* 2.5 * 100 N*m per unit action */
+    float contact_erp;       /* 0.9 */
+    float limit_erp;         /* 0.2 */
+    float friction_ground;   /* 0.8 */
+    float friction_robot;    /* 1.5 ant, 0.1 point */
+    float contact_dist;      /* 0.02: contacts closer than this become solver rows */
+    float limit_margin;      /* 0.25 rad: joint limits closer than this become solver rows */
+    float max_joint_vel;     /* 100 rad/s */
+    float limit_max_impulse; /* 100 */
+    float ground_z;          /* 0.005 = top of the 50x50x0.01 plane box (assets/plane.xml:19) */
+    float point_force;       /* 500 N (point_bot.py:29) */
+} hrl_model;
+
+typedef struct hrl_config {
+    int32_t abi_version;       /* HRL_ABI_VERSION */
+    int32_t env_kind;          /* HRL_ANT_* / HRL_POINT_GATHER */
+    int32_t num_envs;          /* envs owned by this handle (this GPU's shard) */
+    int32_t max_episode_steps; /* 2000 (hrl_pybullet_envs/__init__.py:15); <= 0 disables */
+    int64_t env_id_offset;     /* global id of local env 0: RNG streams are keyed by global id */
+    uint64_t seed;
+    int32_t auto_reset;        /* 1: envs that finish are reset inside hrl_step */
+    /* gather task (ant_gather_env.py:16-29, point_gather_env.py:8-21) */
+    int32_t n_food, n_poison, n_bins;
+    int32_t use_sensor, respawn;
+    float world_size[2];
+    float sensor_range, sensor_span, robot_coll_dist, robot_object_spacing, dying_cost;
+    /* maze task (ant_maze_bullet_env.py:23-25) */
+    int32_t target_encoding, sense_target, sense_walls, done_at_target, max_steps, targ_dist_rew;
+    int32_t n_targets;
+    float tol, inner_rew_weight;
+    float targets[HRL_MAX_TARGETS][2];
+    float start_pos[3];        /* maze: (-2,-5,0.25) (ant_maze_bullet_env.py:27) */
+    /* upstream WalkerBase.calc_state averages x,y over robot.parts, which after the first reset also
+     * holds the scene's static bodies: count and summed xy of those statics. */
+    int32_t centroid_n_static;
+    float centroid_static_sum[2];
+    float walk_target[2];      /* flat: (1e3, 0) upstream default; maze: overwritten by the episode's target */
+    hrl_model model;
+} hrl_config;
+
+/* Caller-owned buffers of one shard.  Unused pointers may be NULL (items for non-gather kinds). */
+typedef struct hrl_buffers {
+    float *state;         /* [N][HRL_STATE_STRIDE]  in/out */
+    float *items;         /* [N][HRL_ITEMS_STRIDE]  in/out (gather kinds) */
+    int32_t *aux;         /* [N][HRL_AUX_STRIDE]    in/out */
+    const float *actions; /* [N][act_dim]           in  (step only) */
+    float *obs;           /* [N][obs_dim]           out */
+    float *reward;        /* [N]                    out (step only) */
+    uint8_t *done;        /* [N]                    out (step only) */
+    float *info;          /* [N][HRL_INFO_STRIDE]   out (step only) */
+} hrl_buffers;
+
+typedef struct hrl_handle hrl_handle;
+
+/* Fill `cfg` with the reference's constructor defaults for `env_kind`
+ * (ant_gather_env.py:16-29, point_gather_env.py:8-21, ant_maze_bullet_env.py:23-27, MjAnt.py:31-34). */
+int hrl_default_config(int32_t env_kind, hrl_config *cfg);
+
+/* obs/action widths implied by a config (ant_gather_env.py:53-55, gather_base.py:54-55,
+ * ant_maze_bullet_env.py:54-57, MjAnt.py:15, point_bot.py:15-16). */
+int hrl_obs_dim(const hrl_config *cfg);
+int hrl_act_dim(const hrl_config *cfg);
+
+/* Replaces env construction (gym.make / Env.__init__ + first BulletClient): validates and copies cfg. */
+int hrl_create(const hrl_config *cfg, hrl_handle **out);
+int hrl_destroy(hrl_handle *h);
+
+/* Replaces Env.reset() (ant_gather_env.py:68-74, gather_base.py:67-72, ant_maze_bullet_env.py:104-121,
+ * upstream WalkerBaseBulletEnv.reset): envs with mask[i] != 0 (all when mask == NULL) are put in the
+ * reset distribution and their first observation is written to bufs->obs. */
+int hrl_reset(hrl_handle *h, const hrl_buffers *bufs, const uint8_t *mask, void *stream);
+
+/* Replaces Env.step(a): robot.apply_action + scene.global_step (pybullet stepSimulation) +
+ * robot.calc_state + task logic (ant_gather_env.py:76-119, gather_base.py:74-109,
+ * ant_maze_bullet_env.py:77-97, MjAnt.py:36-97).  One call steps all N envs once. */
+int hrl_step(hrl_handle *h, const hrl_buffers *bufs, void *stream);
+
+/* State access for identical-state parity tests (replaces pybullet get/resetBasePositionAndOrientation,
+ * get/resetJointState): copies between the packed state record and split qpos[N][15] / qvel[N][14]. */
+int hrl_get_state(hrl_handle *h, const hrl_buffers *bufs, float *qpos, float *qvel, void *stream);
+int hrl_set_state(hrl_handle *h, const hrl_buffers *bufs, const float *qpos, const float *qvel, void *stream);
+
+/* Last error text of the calling thread ("" if none). */
+const char *hrl_last_error(void);
+
+/* Name of the backend that implements this library: "hip-gfx950" for the product. */
+const char *hrl_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRL_ENVS_H */

@@ -1,0 +1,1192 @@
+/*
+ * orc_impl.h -- CPU ORACLE (test infrastructure, NOT product code) for the hrl_pybullet_envs hot path.
+ *
+ * Included twice by hrl_oracle.c: REAL=double/SUF=_f64 and REAL=float/SUF=_f32.
+ *
+ * Two halves:
+ *   (1) TASK LOGIC -- a line-by-line restatement of the reference's in-tree Python; each function cites the
+ *       reference file:line it follows.  Pinned by tests/golden/NAME.json (generated from the reference itself).
+ *   (2) RIGID-BODY STEP -- the reference delegates this to the third-party `pybullet` wheel (requirements.txt:1,
+ *       `pybullet>=3.0.0`, unpinned; call sites ant_gather_env.py:77-80), whose source is NOT under
+ *       /root/reference and which is not installed.  "PARITY UNPINNED": this half restates the published
+ *       algorithm family Bullet uses (Featherstone articulated-body algorithm + sequential-impulse / projected
+ *       Gauss-Seidel contact and joint-limit rows + semi-implicit Euler) as the build's own
+ *       specification.  It is the spec the HIP kernels are checked against, and it is
+ *       checked itself by self-consistency known-answer tests (tests/test_oracle_physics.py).
+ */
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SUF)
+
+#define R_(x) ((REAL)(x))
+
+/* ---------------------------------------------------------------------------------------------- small vector helpers */
+static inline void FN(v3set)(REAL *o, REAL x, REAL y, REAL z) { o[0] = x; o[1] = y; o[2] = z; }
+static inline void FN(v3cross)(REAL *o, const REAL *a, const REAL *b) {
+    REAL x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline REAL FN(v3dot)(const REAL *a, const REAL *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline REAL FN(dot6)(const REAL *a, const REAL *b) {
+    return ((((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]) + a[4] * b[4]) + a[5] * b[5];
+}
+/* balanced butterfly over 16 slots: pairs (i,i+8), then +4, +2, +1 -- the order a 16-lane rotate-add tree produces */
+static inline REAL FN(sum16_tree)(const REAL *x) {
+    REAL a[8], b[4], c[2];
+    for (int i = 0; i < 8; ++i) a[i] = x[i] + x[i + 8];
+    for (int i = 0; i < 4; ++i) b[i] = a[i] + a[i + 4];
+    for (int i = 0; i < 2; ++i) c[i] = b[i] + b[i + 2];
+    return c[0] + c[1];
+}
+#if REAL_IS_FLOAT
+#define RSQRT(x) sqrtf(x)
+#define RSIN(x) sinf(x)
+#define RCOS(x) cosf(x)
+#define RATAN2(y, x) atan2f(y, x)
+#define RASIN(x) asinf(x)
+#define RFABS(x) fabsf(x)
+#define RFMOD(x, y) fmodf(x, y)
+#else
+#define RSQRT(x) sqrt(x)
+#define RSIN(x) sin(x)
+#define RCOS(x) cos(x)
+#define RATAN2(y, x) atan2(y, x)
+#define RASIN(x) asin(x)
+#define RFABS(x) fabs(x)
+#define RFMOD(x, y) fmod(x, y)
+#endif
+static inline REAL FN(clampr)(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* hrl_config stores angles as float; the reference kwargs are python floats (np.pi, 2*np.pi): promote exact matches */
+static inline REAL FN(cfg_angle)(float v) {
+    if (v == (float)3.14159265358979323846) return R_(3.14159265358979323846);
+    if (v == (float)6.28318530717958647692) return R_(6.28318530717958647692);
+    return R_(v);
+}
+
+/* =================================================================================================================
+ * PART 1 -- TASK LOGIC (restates in-tree reference Python)
+ * ================================================================================================================= */
+
+/* envs/intersection_utils.py:84-90 `_find_intersection`: infinite line p1p2 x infinite line p3p4; d == 0 -> none. */
+int FN(orc_inf_intersection)(const REAL *p, REAL *out) {
+    REAL x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3], x3 = p[4], y3 = p[5], x4 = p[6], y4 = p[7];
+    REAL d = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+    if (d == 0) return 0;
+    out[0] = ((x1 * y2 - y1 * x2) * (x3 - x4) - (x1 - x2) * (x3 * y4 - y3 * x4)) / d;
+    out[1] = ((x1 * y2 - y1 * x2) * (y3 - y4) - (y1 - y2) * (x3 * y4 - y3 * x4)) / d;
+    return 1;
+}
+
+/* envs/intersection_utils.py:93-104 `quadrant`: first match in the order 1,4,2,3 with >=/<= tests. */
+int FN(orc_quadrant)(REAL x, REAL y) {
+    if (x >= 0 && y >= 0) return 1;
+    if (x >= 0 && y <= 0) return 4;
+    if (x <= 0 && y >= 0) return 2;
+    if (x <= 0 && y <= 0) return 3;
+    return -1; /* NaN input: the reference raises (intersection_utils.py:104) */
+}
+
+/* envs/intersection_utils.py:14-36 `_on_segment`, `_orientation` */
+static int FN(on_segment)(const REAL *p, const REAL *q, const REAL *r) {
+    REAL mxx = p[0] > r[0] ? p[0] : r[0], mnx = p[0] < r[0] ? p[0] : r[0];
+    REAL mxy = p[1] > r[1] ? p[1] : r[1], mny = p[1] < r[1] ? p[1] : r[1];
+    return (q[0] <= mxx) && (q[0] >= mnx) && (q[1] <= mxy) && (q[1] >= mny);
+}
+static int FN(orientation)(const REAL *p, const REAL *q, const REAL *r) {
+    REAL val = ((q[1] - p[1]) * (r[0] - q[0])) - ((q[0] - p[0]) * (r[1] - q[1]));
+    return val > 0 ? 1 : (val < 0 ? 2 : 0);
+}
+/* envs/intersection_utils.py:39-71 `segment_intersection` */
+int FN(orc_segment_intersection)(const REAL *p) {
+    const REAL *p1 = p, *q1 = p + 2, *p2 = p + 4, *q2 = p + 6;
+    int o1 = FN(orientation)(p1, q1, p2), o2 = FN(orientation)(p1, q1, q2);
+    int o3 = FN(orientation)(p2, q2, p1), o4 = FN(orientation)(p2, q2, q1);
+    if (o1 != o2 && o3 != o4) return 1;
+    if (o1 == 0 && FN(on_segment)(p1, p2, q1)) return 1;
+    if (o2 == 0 && FN(on_segment)(p1, q2, q1)) return 1;
+    if (o3 == 0 && FN(on_segment)(p2, p1, q2)) return 1;
+    if (o4 == 0 && FN(on_segment)(p2, q1, q2)) return 1;
+    return 0;
+}
+
+/* envs/sizeable_enclosed_scene.py:63-97 `sense_walls` (+ intersection_utils.py:113-116 pol2cart).
+ * lines: [n_lines][4] = (ax,ay,bx,by) in the order of Scene.bounds (world_bounds then box_bounds). */
+void FN(orc_sense_walls)(int bins, REAL span, REAL range, const REAL *pos, REAL yaw, const REAL *lines, int n_lines,
+                         int span_is_2pi, REAL *out) {
+    const REAL half_pi = R_(1.5707963267948966);
+    for (int i = 0; i < bins; ++i) {
+        REAL phi; /* :68-71 -- the == 2*pi special case is decided by the caller on the exact kwarg value */
+        if (span_is_2pi) phi = half_pi + yaw + (R_(i + 1) / R_(bins)) * span;
+        else phi = half_pi + yaw + (R_(i) / R_(bins - 1)) * span;
+        REAL sv[2] = {pos[0] + range * RCOS(phi), pos[1] + range * RSIN(phi)}; /* :72 */
+        int sq = FN(orc_quadrant)(sv[0] - pos[0], sv[1] - pos[1]);              /* :74 */
+        REAL best = 0;
+        for (int l = 0; l < n_lines; ++l) { /* :79 */
+            REAL p[8] = {pos[0], pos[1], sv[0], sv[1], lines[4 * l], lines[4 * l + 1], lines[4 * l + 2], lines[4 * l + 3]};
+            REAL in[2];
+            if (!FN(orc_inf_intersection)(p, in)) continue; /* :81-83 */
+            REAL dx = pos[0] - in[0], dy = pos[1] - in[1];
+            REAL dist = RSQRT(dx * dx + dy * dy);                                 /* :85 */
+            if (dist > range) continue;                                           /* :86 */
+            if (sq != FN(orc_quadrant)(in[0] - pos[0], in[1] - pos[1])) continue; /* :89 */
+            REAL v = R_(1.) - dist / range;                                       /* :95 */
+            if (v > best) best = v;
+        }
+        out[i] = best;
+    }
+}
+
+/* ant_gather_env.py:148-155 angle wrap: python `%` (result in [0, 2pi)) then fold to (-pi, pi]. */
+static REAL FN(wrap_angle)(REAL a) {
+    const REAL two_pi = R_(6.283185307179586), pi = R_(3.141592653589793);
+    a = RFMOD(a, two_pi);
+    if (a < 0) a += two_pi;
+    if (a >= two_pi) a -= two_pi; /* python: (-tiny) % 2pi rounds to 2pi in floating point only if fmod+2pi rounds up */
+    if (a > pi) a = a - two_pi;
+    if (a < -pi) a = a + two_pi;
+    return a;
+}
+
+/* ant_gather_env.py:198-200 / gather_base.py:189-191 `sq_dist_robot`: SQUARED planar distance. */
+REAL FN(orc_sq_dist)(const REAL *item_xy, const REAL *robot_xy) {
+    REAL dx = item_xy[0] - robot_xy[0], dy = item_xy[1] - robot_xy[1];
+    return dx * dx + dy * dy;
+}
+
+/* ant_gather_env.py:128-177 / gather_base.py:118-168 `get_sensor_readings`.
+ * The reference sorts all items by d2 descending and lets nearer items overwrite farther ones per bin; since
+ * intensity = 1 - d2/range is monotone in d2 that is "per bin and type, the nearest in-range in-span item wins",
+ * implemented here literally (stable sort, reverse=True keeps input order among equal keys). */
+void FN(orc_food_sensor)(int n_bins, REAL span, REAL range, const REAL *robot_xy, REAL yaw, const REAL *items_xy,
+                         int n_food, int n_poison, const REAL *d2, REAL *food_out, REAL *poison_out) {
+    int n = n_food + n_poison, order[HRL_MAX_ITEMS];
+    for (int i = 0; i < n_bins; ++i) food_out[i] = poison_out[i] = 0;
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i) { /* stable insertion sort, descending d2 (:141) */
+        int k = order[i], j = i - 1;
+        while (j >= 0 && d2[order[j]] < d2[k]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = k;
+    }
+    REAL bin_res = span / R_(n_bins); /* :142 */
+    REAL half_span = span * R_(0.5);  /* :158 */
+    for (int s = 0; s < n; ++s) {
+        int k = order[s];
+        if (d2[k] > range) continue;                                                               /* :145 */
+        REAL angle = RATAN2(items_xy[2 * k + 1] - robot_xy[1], items_xy[2 * k] - robot_xy[0]) - yaw; /* :148 */
+        angle = FN(wrap_angle)(angle);                                                             /* :151-155 */
+        if (!(RFABS(angle) <= half_span)) continue; /* :159; NaN-safe (the reference raises ValueError at int(nan), :161) */
+        int bin = (int)((angle + half_span) / bin_res);                                            /* :161 */
+        if (bin >= n_bins) bin = n_bins - 1; /* reference would raise IndexError at angle == +half_span (measure zero) */
+        REAL intensity = R_(1.0) - d2[k] / range; /* :162 */
+        if (k < n_food) food_out[bin] = intensity; else poison_out[bin] = intensity;
+    }
+}
+
+/* ant_gather_env.py:179-196 `get_abs_pos`: nearest-first xy of min(n, n_bins) food then poison items. */
+void FN(orc_abs_pos)(int n_bins, const REAL *items_xy, int n_food, int n_poison, const REAL *d2, REAL *food_out,
+                     REAL *poison_out) {
+    for (int t = 0; t < 2; ++t) {
+        int base = t ? n_food : 0, n = t ? n_poison : n_food, order[HRL_MAX_ITEMS];
+        REAL *out = t ? poison_out : food_out;
+        for (int i = 0; i < n; ++i) order[i] = base + i;
+        for (int i = 1; i < n; ++i) { /* stable ascending (:183-184) */
+            int k = order[i], j = i - 1;
+            while (j >= 0 && d2[order[j]] > d2[k]) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = k;
+        }
+        int m = n < n_bins ? n : n_bins;
+        for (int i = 0; i < m; ++i) { out[2 * i] = items_xy[2 * order[i]]; out[2 * i + 1] = items_xy[2 * order[i] + 1]; }
+    }
+}
+
+/* gather_scene.py:52-62 `_random_on_plane`: pos = rand(2)*(size-1) - (size-1)/2, redrawn while |avoid-pos| < spacing.
+ * Uniform pairs come from `draws` (consumed in order; returns the number consumed, or -1 if it ran out). */
+int FN(orc_random_on_plane)(const REAL *world_size, const REAL *avoid_xy, REAL spacing, const REAL *draws, int n_draws,
+                            REAL *pos_out) {
+    REAL sx = world_size[0] - 1, sy = world_size[1] - 1;
+    for (int k = 0; k < n_draws; ++k) {
+        REAL px = draws[2 * k] * sx - sx / 2, py = draws[2 * k + 1] * sy - sy / 2;
+        REAL dx = avoid_xy[0] - px, dy = avoid_xy[1] - py;
+        if (!(RSQRT(dx * dx + dy * dy) < spacing)) { pos_out[0] = px; pos_out[1] = py; return k + 1; }
+    }
+    return -1;
+}
+
+/* ant_maze_bullet_env.py:123-133 `get_target_vec_obs` (encoding 0 normed vector, 1 sin/cos of relative angle). */
+void FN(orc_target_vec_obs)(int encoding, const REAL *target, const REAL *robot_xy, REAL yaw, REAL *out) {
+    REAL vx = target[0] - robot_xy[0], vy = target[1] - robot_xy[1];
+    if (encoding == 0) {
+        REAL n = RSQRT(vx * vx + vy * vy);
+        out[0] = vx / n; out[1] = vy / n;
+    } else {
+        REAL a = RATAN2(vy, vx) - yaw;
+        out[0] = RSIN(a); out[1] = RCOS(a);
+    }
+}
+
+/* ant_maze_bullet_env.py:135-178 `get_target_sensor_obs`: box occlusion via segment_intersection, then one bin. */
+void FN(orc_target_sensor_obs)(int n_bins, REAL span, REAL range, const REAL *target, const REAL *robot_xy, REAL yaw,
+                               REAL walk_target_dist, const REAL *box_lines, int n_box_lines, REAL *out) {
+    for (int i = 0; i < n_bins; ++i) out[i] = 0;
+    if (n_bins <= 0) return;
+    if (walk_target_dist > range) return; /* :145 */
+    for (int l = 0; l < n_box_lines; ++l) { /* :148-150 */
+        REAL p[8] = {robot_xy[0], robot_xy[1], target[0], target[1], box_lines[4 * l], box_lines[4 * l + 1],
+                     box_lines[4 * l + 2], box_lines[4 * l + 3]};
+        if (FN(orc_segment_intersection)(p)) return;
+    }
+    REAL angle = FN(wrap_angle)(RATAN2(target[1] - robot_xy[1], target[0] - robot_xy[0]) - yaw); /* :153-160 */
+    REAL half_span = span * R_(0.5), bin_res = span / R_(n_bins);
+    if (!(RFABS(angle) <= half_span)) return; /* :164, NaN-safe */
+    int bin = (int)((angle + half_span) / bin_res);
+    if (bin >= n_bins) bin = n_bins - 1;
+    out[bin] = R_(1.0) - walk_target_dist / range; /* :167-168 */
+}
+
+/* point_bot.py:48-67 `PointBot.calc_state` (float32 array in the reference). */
+void FN(orc_pointbot_state)(const REAL *xyz, const REAL *rpy, const REAL *speed, const REAL *target, REAL initial_z,
+                            REAL *out) {
+    REAL yaw = rpy[2];
+    REAL theta = RATAN2(target[1] - xyz[1], target[0] - xyz[0]);
+    REAL a = theta - yaw;
+    REAL c = RCOS(-yaw), s = RSIN(-yaw);
+    REAL vx = c * speed[0] - s * speed[1], vy = s * speed[0] + c * speed[1], vz = speed[2];
+    out[0] = xyz[2] - initial_z; out[1] = RSIN(a); out[2] = RCOS(a);
+    out[3] = R_(0.3) * vx; out[4] = R_(0.3) * vy; out[5] = R_(0.3) * vz; out[6] = rpy[0]; out[7] = rpy[1];
+}
+
+/* The task half of AntGatherBulletEnv.step / GatherBulletEnv.step given the post-physics robot state
+ * (ant_gather_env.py:81-119, gather_base.py:80-109).
+ *   base_state : robot.calc_state() (28 for the ant, 8 for the point bot), ant=1 drops elements 1:3 (:81)
+ *   items_xy   : [n_food+n_poison][2] in/out (respawned in place); draws: uniform pairs for respawns
+ *   alive_z    : > 0 enables `alive = +1 if z > alive_z else -1` (ant); <= 0 means "can't die" (point_bot.py:73-74)
+ * Returns number of uniform pairs consumed. */
+int FN(orc_gather_task)(const hrl_config *cfg, int ant, const REAL *base_state, int n_base, const REAL *torso_xyz,
+                        REAL yaw, REAL initial_z, REAL alive_z, REAL *items_xy, const REAL *draws, int n_draws,
+                        REAL *obs, REAL *rew, int *done, REAL *food_rew_out, REAL *dead_rew_out) {
+    int nf = cfg->n_food, np_ = cfg->n_poison, n = nf + np_, no = 0, used = 0;
+    REAL d2[HRL_MAX_ITEMS];
+    if (ant) { obs[no++] = base_state[0]; for (int i = 3; i < n_base; ++i) obs[no++] = base_state[i]; } /* :81 */
+    else for (int i = 0; i < n_base; ++i) obs[no++] = base_state[i];
+    for (int i = 0; i < n; ++i) d2[i] = FN(orc_sq_dist)(items_xy + 2 * i, torso_xyz); /* :84 */
+    REAL food_reward = 0;
+    REAL ws[2] = {R_(cfg->world_size[0]), R_(cfg->world_size[1])};
+    if (cfg->robot_coll_dist > 0) { /* :88 */
+        for (int i = 0; i < n; ++i) {
+            if (d2[i] < R_(cfg->robot_coll_dist)) { /* :90 -- squared distance vs linear threshold (SURVEY C-1) */
+                food_reward += (i < nf) ? 1 : -1;   /* gather_scene.py:95-112 */
+                if (cfg->respawn) {
+                    int k = FN(orc_random_on_plane)(ws, torso_xyz, R_(cfg->robot_object_spacing), draws + 2 * used,
+                                                    n_draws - used, items_xy + 2 * i);
+                    if (k < 0) return -1;
+                    used += k;
+                } else { items_xy[2 * i] = 100; items_xy[2 * i + 1] = 0; } /* gather_scene.py:13,100-102 */
+                d2[i] = FN(orc_sq_dist)(items_xy + 2 * i, torso_xyz); /* :92 */
+            }
+        }
+    }
+    REAL fr[HRL_MAX_ITEMS * 2], pr[HRL_MAX_ITEMS * 2];
+    int nfo, npo;
+    if (cfg->use_sensor) { /* :121-125 */
+        FN(orc_food_sensor)(cfg->n_bins, FN(cfg_angle)(cfg->sensor_span), R_(cfg->sensor_range), torso_xyz, yaw, items_xy, nf, np_,
+                            d2, fr, pr);
+        nfo = npo = cfg->n_bins;
+    } else {
+        FN(orc_abs_pos)(cfg->n_bins, items_xy, nf, np_, d2, fr, pr);
+        nfo = 2 * (nf < cfg->n_bins ? nf : cfg->n_bins);
+        npo = 2 * (np_ < cfg->n_bins ? np_ : cfg->n_bins);
+    }
+    for (int i = 0; i < nfo; ++i) obs[no++] = fr[i];
+    for (int i = 0; i < npo; ++i) obs[no++] = pr[i]; /* :96 */
+    REAL alive = 1;
+    if (alive_z > 0) alive = (obs[0] + initial_z > alive_z) ? R_(1) : R_(-1); /* :99 + upstream Ant.alive_bonus */
+    int d = alive < 0;                                                         /* :100 */
+    for (int i = 0; i < no; ++i) if (!isfinite(obs[i])) d = 1;                 /* :101-103 */
+    REAL dead_rew = alive < 0 ? R_(cfg->dying_cost) : 0;                       /* :118 */
+    *rew = food_reward + dead_rew; *done = d; *food_rew_out = food_reward; *dead_rew_out = dead_rew; /* :119 */
+    return used;
+}
+
+/* The task half of AntMazeBulletEnv.step given the upstream WalkerBaseBulletEnv.step result
+ * (ant_maze_bullet_env.py:63-97).  lines = Scene.bounds (7 for the maze), box lines = last 3. */
+void FN(orc_maze_task)(const hrl_config *cfg, const REAL *ant_obs28, REAL inner_rew, int inner_done, const REAL *torso_xy,
+                       REAL yaw, const REAL *target, REAL walk_target_dist, int t_after_increment, const REAL *lines,
+                       int n_lines, int n_box_lines, REAL *obs, REAL *rew, int *done) {
+    int no = 0;
+    obs[no++] = ant_obs28[0];
+    for (int i = 3; i < 28; ++i) obs[no++] = ant_obs28[i]; /* :75 */
+    if (cfg->sense_target) {
+        FN(orc_target_sensor_obs)(cfg->n_bins, FN(cfg_angle)(cfg->sensor_span), R_(cfg->sensor_range), target, torso_xy, yaw,
+                                  walk_target_dist, lines + 4 * (n_lines - n_box_lines), n_box_lines, obs + no);
+        no += cfg->n_bins;
+    } else {
+        FN(orc_target_vec_obs)(cfg->target_encoding, target, torso_xy, yaw, obs + no);
+        no += 2;
+    }
+    if (cfg->sense_walls) {
+        const double two_pi = 6.283185307179586;
+        FN(orc_sense_walls)(cfg->n_bins, FN(cfg_angle)(cfg->sensor_span), R_(cfg->sensor_range), torso_xy, yaw, lines, n_lines,
+                            (double)cfg->sensor_span == (double)(float)two_pi, obs + no);
+        no += cfg->n_bins;
+    }
+    REAL r = inner_rew * R_(cfg->inner_rew_weight); /* :84 */
+    int d = inner_done;
+    if (walk_target_dist < R_(cfg->tol)) { /* :86-89 */
+        if (cfg->done_at_target || (!cfg->done_at_target && t_after_increment == cfg->max_steps - 1)) { r += 1; d = 1; }
+    }
+    if (t_after_increment == cfg->max_steps - 1) d = 1; /* :91-92 */
+    if (cfg->targ_dist_rew && d) r -= walk_target_dist; /* :94-95 */
+    *rew = r; *done = d;
+}
+
+/* MjAnt.py:36-97 `AntMjEnv.step` reward assembly: alive + progress + joints_at_limit_cost * n + 0. */
+void FN(orc_antmj_reward)(const REAL *state29, REAL potential_old, REAL potential_new, int joints_at_limit,
+                          REAL joints_at_limit_cost, REAL *rew, int *done) {
+    REAL alive = state29[2] > R_(0.26) ? R_(1) : R_(-1); /* :27-28,44 (initial_z cancels) */
+    int d = alive < 0;
+    for (int i = 0; i < 29; ++i) if (!isfinite(state29[i])) d = 1; /* :46-48 */
+    REAL progress = potential_new - potential_old;                   /* :50-52 */
+    *rew = ((alive + progress) + joints_at_limit_cost * R_(joints_at_limit)) + 0; /* :68,82-88,97 */
+    *done = d;
+}
+
+/* =================================================================================================================
+ * PART 2 -- RIGID-BODY STEP (build's own specification; PARITY UNPINNED against pybullet, see header)
+ * Replaces robot.apply_action + scene.global_step at ant_gather_env.py:77-78 (upstream: setJointMotorControl2 +
+ * stepSimulation with fixedTimeStep 0.0165, numSubSteps 4, 5 solver iterations -- SURVEY Appendix A.1/A.3).
+ * ================================================================================================================= */
+
+#define NJ 8
+#define NBODY 9
+#define NDOF 14
+#define MAXC 13
+#define MAXR 48
+
+typedef struct FN(orc_consts) {
+    REAL h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z;
+    REAL r_torso, r_caps, L1, L2;
+    REAL m0, a0, b0;      /* composite torso: mass, inertia alpha*1 + beta*Z Z^T                         */
+    REAL m1, a1, b1;      /* aux (short) capsule about its own COM: alpha*1 + beta*e e^T, e = capsule axis */
+    REAL m2, a2, b2;      /* foot capsule                                                                */
+    REAL lo[NJ], hi[NJ];  /* joint ranges, assets/ant.xml:18-54                                          */
+    int iters, nsub;
+} FN(orc_consts);
+
+/* static collision world: ground plane + lateral half-spaces + axis-aligned boxes
+ * (sizeable_enclosed_scene.py:39-61, maze_scene.py:33-38, assets/plane.xml, wall.xml, box.xml) */
+typedef struct FN(orc_world) {
+    int n_planes; REAL plane_n[4][3], plane_d[4]; /* inside: n.p - d > 0 */
+    int n_boxes;  REAL box_lo[1][3], box_hi[1][3];
+} FN(orc_world);
+
+/* ant leg signs / ankle axes: assets/ant.xml:15-58 */
+#ifndef ORC_LEG_TABLES
+#define ORC_LEG_TABLES
+static const int LEG_SX[4] = {1, -1, -1, 1}, LEG_SY[4] = {1, 1, -1, -1};
+static const int ANK_AX[4] = {-1, 1, -1, 1}, ANK_AY[4] = {1, 1, 1, 1};
+static const int LEG_SIGMA[4] = {-1, 1, 1, -1}; /* (ankle axis) x (leg direction) = sigma * z */
+#endif
+
+void FN(orc_consts_init)(const hrl_model *M, FN(orc_consts) * K) {
+    const double pi = 3.14159265358979323846, s2 = 1.41421356237309504880;
+    double rho = M->density, rt = 0.25, rc = 0.08, L1 = 0.2 * s2, L2 = 0.4 * s2; /* ant.xml:13,16,19,22 */
+    double msph = rho * 4.0 / 3.0 * pi * rt * rt * rt, Isph = 0.4 * msph * rt * rt;
+    double m[2], Ia[2], It[2], L[2] = {L1, L2};
+    for (int k = 0; k < 2; ++k) { /* solid capsule = cylinder + two hemispheres */
+        double mc = rho * pi * rc * rc * L[k], ms = rho * 4.0 / 3.0 * pi * rc * rc * rc;
+        m[k] = mc + ms;
+        Ia[k] = mc * rc * rc / 2 + ms * 0.4 * rc * rc;
+        It[k] = mc * (L[k] * L[k] / 12 + rc * rc / 4) + ms * (0.4 * rc * rc + L[k] * L[k] / 4 + 3 * L[k] * rc / 8);
+    }
+    /* torso body = sphere + the four jointless "leg" capsules (ant.xml:15-16,26-27,37-38,48-49) merged rigidly */
+    double c = L1 / 2, common = Isph + 4 * (It[0] + m[0] * c * c), dz = Ia[0] - It[0] - m[0] * c * c;
+    K->m0 = R_(msph + 4 * m[0]); K->a0 = R_(common + 2 * dz); K->b0 = R_(common - (common + 2 * dz));
+    K->m1 = R_(m[0]); K->a1 = R_(It[0]); K->b1 = R_(Ia[0] - It[0]);
+    K->m2 = R_(m[1]); K->a2 = R_(It[1]); K->b2 = R_(Ia[1] - It[1]);
+    K->r_torso = R_(rt); K->r_caps = R_(rc); K->L1 = R_(L1); K->L2 = R_(L2);
+    K->h = R_(M->timestep); K->g = R_(M->gravity); K->erp_c = R_(M->contact_erp); K->erp_l = R_(M->limit_erp);
+    K->mu = R_(M->friction_ground * M->friction_robot); K->cdist = R_(M->contact_dist); K->lmargin = R_(M->limit_margin);
+    K->vmax = R_(M->max_joint_vel); K->limp_max = R_(M->limit_max_impulse); K->ground_z = R_(M->ground_z);
+    K->iters = M->solver_iters; K->nsub = M->frame_skip;
+    const double d2r = pi / 180.0;
+    const double lo[NJ] = {-40, 30, -40, -100, -40, -100, -40, 30}, hi[NJ] = {40, 100, 40, -30, 40, -30, 40, 100};
+    for (int j = 0; j < NJ; ++j) { K->lo[j] = R_(lo[j] * d2r); K->hi[j] = R_(hi[j] * d2r); }
+}
+
+void FN(orc_world_init)(const hrl_config *cfg, FN(orc_world) * W) {
+    memset(W, 0, sizeof(*W));
+    REAL hx = 0, hy = 0;
+    if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) { hx = R_(cfg->world_size[0]) / 2; hy = R_(cfg->world_size[1]) / 2; }
+    if (cfg->env_kind == HRL_ANT_MAZE) { hx = 5; hy = 9; } /* maze_scene.py:10 */
+    if (hx > 0) { /* walls 0.1 thick centred on +-size/2 (sizeable_enclosed_scene.py:46-57, wall.xml:19) */
+        REAL t = R_(0.05);
+        REAL n[4][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}};
+        REAL d[4] = {-(hx - t), -(hx - t), -(hy - t), -(hy - t)};
+        W->n_planes = 4;
+        for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) W->plane_n[i][k] = n[i][k]; W->plane_d[i] = d[i]; }
+    }
+    if (cfg->env_kind == HRL_ANT_MAZE) { /* box.xml:19 6x4x2 at (-2,0,1) (maze_scene.py:12-13,35) */
+        W->n_boxes = 1;
+        FN(v3set)(W->box_lo[0], -5, -2, 0); FN(v3set)(W->box_hi[0], 1, 2, 2);
+    }
+}
+
+/* per-substep kinematic + articulated-body data */
+typedef struct FN(orc_dyn) {
+    REAL X[3], Y[3], Z[3];
+    REAL ph[4][3], pa[4][3], tip[4][3]; /* hip anchor, ankle anchor, foot tip, relative to O = torso COM, world axes */
+    REAL S[NJ][6], U[NJ][6], invD[NJ], uterm[NJ], cb[NJ][6];
+    REAL I0inv[6][6];
+    REAL a0[6], qdd[NJ];
+} FN(orc_dyn);
+
+static void FN(spatial_inertia)(REAL I[6][6], REAL m, REAL alpha, REAL beta, const REAL *e, const REAL *c) {
+    REAL cc = FN(v3dot)(c, c);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            REAL d = (i == j) ? R_(1) : R_(0);
+            I[i][j] = (alpha * d + beta * e[i] * e[j]) + m * (cc * d - c[i] * c[j]);
+            I[3 + i][3 + j] = m * d;
+        }
+    /* top-right = m [c]x ; bottom-left = its transpose */
+    REAL cx[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { I[i][3 + j] = m * cx[i][j]; I[3 + j][i] = m * cx[i][j]; }
+}
+static void FN(matvec6)(REAL *o, REAL A[6][6], const REAL *x) {
+    for (int i = 0; i < 6; ++i) o[i] = FN(dot6)(A[i], x);
+}
+static void FN(crm)(REAL *o, const REAL *v, const REAL *m) { /* spatial motion cross product v x m */
+    REAL a[3], b[3], c[3];
+    FN(v3cross)(a, v, m); FN(v3cross)(b, v, m + 3); FN(v3cross)(c, v + 3, m);
+    for (int i = 0; i < 3; ++i) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+static void FN(crf)(REAL *o, const REAL *v, const REAL *f) { /* spatial force cross product v x* f */
+    REAL a[3], b[3], c[3];
+    FN(v3cross)(a, v, f); FN(v3cross)(b, v + 3, f + 3); FN(v3cross)(c, v, f + 3);
+    for (int i = 0; i < 3; ++i) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+
+/* explicit inverse of a symmetric positive-definite 6x6 via Cholesky: A = L L^T, Ainv = Linv^T Linv */
+static void FN(spd6_inverse)(REAL Ainv[6][6], REAL A[6][6]) {
+    REAL L[6][6], Li[6][6];
+    memset(L, 0, sizeof(L)); memset(Li, 0, sizeof(Li));
+    for (int j = 0; j < 6; ++j) {
+        REAL s = A[j][j];
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        REAL d = RSQRT(s), id = R_(1) / d;
+        L[j][j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            REAL t = A[i][j];
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            L[i][j] = t * id;
+        }
+    }
+    for (int j = 0; j < 6; ++j) { /* Li = L^-1 (lower), column by column */
+        Li[j][j] = R_(1) / L[j][j];
+        for (int i = j + 1; i < 6; ++i) {
+            REAL t = 0;
+            for (int k = j; k < i; ++k) t -= L[i][k] * Li[k][j];
+            Li[i][j] = t / L[i][i];
+        }
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            REAL t = 0;
+            for (int k = i; k < 6; ++k) t += Li[k][i] * Li[k][j];
+            Ainv[i][j] = t; Ainv[j][i] = t;
+        }
+}
+
+/* Kinematics at q, articulated inertias, and (if u/tau given) forward dynamics qdd, a0.
+ * All spatial quantities are in world axes about the point O = current torso COM (an inertial frame that
+ * instantaneously coincides with the torso), so parent<->child transforms are the identity. */
+static void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, const REAL *tau, FN(orc_dyn) * D) {
+    const REAL is2 = R_(0.70710678118654752440);
+    REAL x = q[3], y = q[4], z = q[5], w = q[6];
+    FN(v3set)(D->X, 1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y));
+    FN(v3set)(D->Y, 2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x));
+    FN(v3set)(D->Z, 2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y));
+    REAL IA[NBODY][6][6], pA[NBODY][6], v[NBODY][6];
+    REAL zero3[3] = {0, 0, 0};
+    FN(spatial_inertia)(IA[0], K->m0, K->a0, K->b0, D->Z, zero3);
+    for (int i = 0; i < 6; ++i) v[0][i] = u[i];
+    REAL com[NBODY][3], mass[NBODY];
+    FN(v3set)(com[0], 0, 0, 0); mass[0] = K->m0;
+    for (int l = 0; l < 4; ++l) {
+        REAL qh = q[7 + 2 * l], qa = q[8 + 2 * l];
+        REAL ch = RCOS(qh), sh = RSIN(qh), ca = RCOS(qa), sa = RSIN(qa);
+        REAL sx = R_(LEG_SX[l]), sy = R_(LEG_SY[l]), ax = R_(ANK_AX[l]), ay = R_(ANK_AY[l]), sg = R_(LEG_SIGMA[l]);
+        REAL e1x = (sx * ch - sy * sh) * is2, e1y = (sx * sh + sy * ch) * is2; /* Rz(qh) * leg direction, torso frame */
+        REAL axx = (ax * ch - ay * sh) * is2, axy = (ax * sh + ay * ch) * is2; /* Rz(qh) * ankle axis            */
+        REAL e1[3], axw[3], e2[3], caux[3], cfoot[3];
+        for (int k = 0; k < 3; ++k) {
+            e1[k] = e1x * D->X[k] + e1y * D->Y[k];
+            axw[k] = axx * D->X[k] + axy * D->Y[k];
+            e2[k] = ca * e1[k] + (sg * sa) * D->Z[k];
+            D->ph[l][k] = R_(0.2) * (sx * D->X[k] + sy * D->Y[k]);
+            D->pa[l][k] = D->ph[l][k] + K->L1 * e1[k];
+            D->tip[l][k] = D->pa[l][k] + K->L2 * e2[k];
+            caux[k] = D->ph[l][k] + (K->L1 * R_(0.5)) * e1[k];
+            cfoot[k] = D->pa[l][k] + (K->L2 * R_(0.5)) * e2[k];
+        }
+        int jh = 2 * l, ja = 2 * l + 1, bx = 1 + 2 * l, bf = 2 + 2 * l;
+        for (int k = 0; k < 3; ++k) { D->S[jh][k] = D->Z[k]; D->S[ja][k] = axw[k]; }
+        FN(v3cross)(D->S[jh] + 3, D->ph[l], D->Z);
+        FN(v3cross)(D->S[ja] + 3, D->pa[l], axw);
+        FN(spatial_inertia)(IA[bx], K->m1, K->a1, K->b1, e1, caux);
+        FN(spatial_inertia)(IA[bf], K->m2, K->a2, K->b2, e2, cfoot);
+        for (int k = 0; k < 3; ++k) { com[bx][k] = caux[k]; com[bf][k] = cfoot[k]; }
+        mass[bx] = K->m1; mass[bf] = K->m2;
+        REAL qdh = u[6 + 2 * l], qda = u[7 + 2 * l], vjh[6], vja[6];
+        for (int k = 0; k < 6; ++k) { vjh[k] = D->S[jh][k] * qdh; v[bx][k] = v[0][k] + vjh[k]; }
+        for (int k = 0; k < 6; ++k) { vja[k] = D->S[ja][k] * qda; v[bf][k] = v[bx][k] + vja[k]; }
+        FN(crm)(D->cb[jh], v[0], vjh);
+        FN(crm)(D->cb[ja], v[bx], vja);
+    }
+    for (int b = 0; b < NBODY; ++b) { /* bias force: v x* (I v) - gravity wrench */
+        REAL Iv[6], f[6], fg[3] = {0, 0, -mass[b] * K->g}, ng[3];
+        FN(matvec6)(Iv, IA[b], v[b]);
+        FN(crf)(f, v[b], Iv);
+        FN(v3cross)(ng, com[b], fg);
+        for (int k = 0; k < 3; ++k) { pA[b][k] = f[k] - ng[k]; pA[b][3 + k] = f[3 + k] - fg[k]; }
+    }
+    /* backward pass: ankle then hip of every leg; leg contributions are summed (l0+l1)+(l2+l3) into the base */
+    REAL Ileg[4][6][6], pleg[4][6];
+    for (int l = 0; l < 4; ++l) {
+        for (int s = 1; s >= 0; --s) {
+            int j = 2 * l + s, child = 1 + j;
+            FN(matvec6)(D->U[j], IA[child], D->S[j]);
+            REAL Dj = FN(dot6)(D->S[j], D->U[j]);
+            D->invD[j] = R_(1) / Dj;
+            D->uterm[j] = (tau ? tau[j] : R_(0)) - FN(dot6)(D->S[j], pA[child]);
+            REAL Ia[6][6], pa_[6], Iac[6];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) Ia[a][b] = IA[child][a][b] - (D->U[j][a] * D->invD[j]) * D->U[j][b];
+            FN(matvec6)(Iac, Ia, D->cb[j]);
+            REAL ud = D->uterm[j] * D->invD[j];
+            for (int a = 0; a < 6; ++a) pa_[a] = (pA[child][a] + Iac[a]) + D->U[j][a] * ud;
+            if (s == 1) { /* ankle -> accumulate into aux body */
+                int par = 1 + 2 * l;
+                for (int a = 0; a < 6; ++a) { for (int b = 0; b < 6; ++b) IA[par][a][b] += Ia[a][b]; pA[par][a] += pa_[a]; }
+            } else {
+                memcpy(Ileg[l], Ia, sizeof(Ia)); memcpy(pleg[l], pa_, sizeof(pa_));
+            }
+        }
+    }
+    REAL p0[6];
+    for (int a = 0; a < 6; ++a) {
+        for (int b = 0; b < 6; ++b) IA[0][a][b] += (Ileg[0][a][b] + Ileg[1][a][b]) + (Ileg[2][a][b] + Ileg[3][a][b]);
+        p0[a] = pA[0][a] + ((pleg[0][a] + pleg[1][a]) + (pleg[2][a] + pleg[3][a]));
+    }
+    FN(spd6_inverse)(D->I0inv, IA[0]);
+    for (int a = 0; a < 6; ++a) D->a0[a] = -FN(dot6)(D->I0inv[a], p0);
+    for (int l = 0; l < 4; ++l) { /* forward pass */
+        REAL ap[6], ax_[6];
+        int jh = 2 * l, ja = jh + 1;
+        for (int k = 0; k < 6; ++k) ap[k] = D->a0[k] + D->cb[jh][k];
+        D->qdd[jh] = (D->uterm[jh] - FN(dot6)(D->U[jh], ap)) * D->invD[jh];
+        for (int k = 0; k < 6; ++k) ax_[k] = (ap[k] + D->S[jh][k] * D->qdd[jh]) + D->cb[ja][k];
+        D->qdd[ja] = (D->uterm[ja] - FN(dot6)(D->U[ja], ax_)) * D->invD[ja];
+    }
+}
+
+/* Velocity response du = M^-1 * (generalized impulse): spatial impulse `phi` (6, about O) on the body at
+ * `level` (0 torso, 1 aux, 2 foot) of leg `leg`, plus direct joint impulses th (hip) / ta (ankle) of that leg. */
+static void FN(orc_response)(const FN(orc_dyn) * D, const REAL *phi, int level, int leg, REAL th, REAL ta, REAL *du) {
+    int jh = 2 * leg, ja = jh + 1;
+    REAL p[6] = {0, 0, 0, 0, 0, 0}, ua = ta, uh = th;
+    if (level == 2) {
+        for (int k = 0; k < 6; ++k) p[k] = -phi[k];
+        ua = ta - FN(dot6)(D->S[ja], p);
+    }
+    { REAL s = ua * D->invD[ja]; for (int k = 0; k < 6; ++k) p[k] = p[k] + D->U[ja][k] * s; }
+    if (level == 1) for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
+    uh = th - FN(dot6)(D->S[jh], p);
+    { REAL s = uh * D->invD[jh]; for (int k = 0; k < 6; ++k) p[k] = p[k] + D->U[jh][k] * s; }
+    if (level == 0) for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
+    REAL dv0[6];
+    for (int a = 0; a < 6; ++a) dv0[a] = -FN(dot6)(D->I0inv[a], p);
+    for (int k = 0; k < 6; ++k) du[k] = dv0[k];
+    for (int l = 0; l < 4; ++l) {
+        int h_ = 2 * l, a_ = h_ + 1;
+        REAL uhl = (l == leg) ? uh : R_(0), ual = (l == leg) ? ua : R_(0), dvx[6];
+        REAL dqh = (uhl - FN(dot6)(D->U[h_], dv0)) * D->invD[h_];
+        for (int k = 0; k < 6; ++k) dvx[k] = dv0[k] + D->S[h_][k] * dqh;
+        REAL dqa = (ual - FN(dot6)(D->U[a_], dvx)) * D->invD[a_];
+        du[6 + h_] = dqh; du[6 + a_] = dqa;
+    }
+}
+
+/* btPlaneSpace1-style tangent basis for a unit normal */
+static void FN(tangent_basis)(const REAL *n, REAL *t1, REAL *t2) {
+    if (RFABS(n[2]) > R_(0.70710678118654752440)) {
+        REAL a = n[1] * n[1] + n[2] * n[2], k = R_(1) / RSQRT(a);
+        FN(v3set)(t1, 0, -n[2] * k, n[1] * k);
+        FN(v3set)(t2, a * k, -n[0] * t1[2], n[0] * t1[1]);
+    } else {
+        REAL a = n[0] * n[0] + n[1] * n[1], k = R_(1) / RSQRT(a);
+        FN(v3set)(t1, -n[1] * k, n[0] * k, 0);
+        FN(v3set)(t2, -n[2] * t1[1], n[2] * t1[0], a * k);
+    }
+}
+
+typedef struct FN(orc_contact) { int level, leg, sphere; REAL r[3], n[3], dist; } FN(orc_contact);
+
+/* sphere `s` (0 torso, 1+3l hip, 2+3l ankle, 3+3l tip): centre relative to O, radius, owning body */
+static void FN(sphere_info)(const FN(orc_consts) * K, const FN(orc_dyn) * D, int s, REAL *c, REAL *rad, int *level, int *leg) {
+    if (s == 0) { FN(v3set)(c, 0, 0, 0); *rad = K->r_torso; *level = 0; *leg = 0; return; }
+    int l = (s - 1) / 3, w = (s - 1) % 3;
+    const REAL *src = w == 0 ? D->ph[l] : (w == 1 ? D->pa[l] : D->tip[l]);
+    for (int k = 0; k < 3; ++k) c[k] = src[k];
+    *rad = K->r_caps; *level = w; *leg = l;
+}
+
+/* Candidate order: surface-major (ground, planes..., boxes...), sphere-minor; at most MAXC contacts are kept. */
+static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, const FN(orc_dyn) * D, const REAL *pos,
+                          FN(orc_contact) * C, int *ground_touch /* [13] */) {
+    int nc = 0, nsurf = 1 + W->n_planes + W->n_boxes;
+    for (int s = 0; s < 13; ++s) ground_touch[s] = 0;
+    for (int f = 0; f < nsurf; ++f)
+        for (int s = 0; s < 13; ++s) {
+            REAL c[3], rad, n[3], dist, p[3];
+            int level, leg;
+            FN(sphere_info)(K, D, s, c, &rad, &level, &leg);
+            for (int k = 0; k < 3; ++k) p[k] = pos[k] + c[k];
+            if (f == 0) { FN(v3set)(n, 0, 0, 1); dist = (p[2] - K->ground_z) - rad; }
+            else if (f <= W->n_planes) {
+                const REAL *pn = W->plane_n[f - 1];
+                FN(v3set)(n, pn[0], pn[1], pn[2]);
+                dist = (FN(v3dot)(n, p) - W->plane_d[f - 1]) - rad;
+            } else {
+                const REAL *lo = W->box_lo[f - 1 - W->n_planes], *hi = W->box_hi[f - 1 - W->n_planes];
+                REAL d[3], d2 = 0;
+                for (int k = 0; k < 3; ++k) { REAL cp = FN(clampr)(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 += d[k] * d[k]; }
+                if (d2 > 0) { REAL len = RSQRT(d2); for (int k = 0; k < 3; ++k) n[k] = d[k] / len; dist = len - rad; }
+                else { /* centre inside the box: exit through the nearest face */
+                    int best = 0; REAL bd = R_(1e30), sgn = 1;
+                    for (int k = 0; k < 3; ++k) {
+                        REAL dl = p[k] - lo[k], dh = hi[k] - p[k];
+                        if (dl < bd) { bd = dl; best = k; sgn = -1; }
+                        if (dh < bd) { bd = dh; best = k; sgn = 1; }
+                    }
+                    FN(v3set)(n, 0, 0, 0); n[best] = sgn; dist = -bd - rad;
+                }
+            }
+            if (dist < K->cdist) {
+                if (f == 0) ground_touch[s] = 1;
+                if (nc < MAXC) {
+                    FN(orc_contact) *cc = &C[nc++];
+                    cc->level = level; cc->leg = leg; cc->sphere = s; cc->dist = dist;
+                    for (int k = 0; k < 3; ++k) { cc->n[k] = n[k]; cc->r[k] = c[k] - rad * n[k]; }
+                }
+            }
+        }
+    return nc;
+}
+
+typedef struct FN(orc_substep_dbg) { int n_rows, n_limits, n_contacts; REAL lambda[MAXR]; } FN(orc_substep_dbg);
+
+/* One physics substep on internal coordinates q[15] (x,y,z,qx,qy,qz,qw,joints) and u[14] (omega, v, joint rates). */
+void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL *q, REAL *u, const REAL *tau,
+                         int *ground_touch, FN(orc_substep_dbg) * dbg) {
+    FN(orc_dyn) D;
+    REAL h = K->h;
+    FN(orc_dynamics)(K, q, u, tau, &D);
+    /* (1) unconstrained velocity update; classical linear acceleration of the torso COM = a_O + omega x v */
+    REAL wxv[3];
+    FN(v3cross)(wxv, u, u + 3);
+    REAL un[16];
+    for (int k = 0; k < 3; ++k) { un[k] = u[k] + h * D.a0[k]; un[3 + k] = u[3 + k] + h * (D.a0[3 + k] + wxv[k]); }
+    for (int j = 0; j < NJ; ++j) un[6 + j] = u[6 + j] + h * D.qdd[j];
+    un[14] = un[15] = 0;
+    /* (2) constraint rows: joint limits, contact normals, friction pairs */
+    REAL J[MAXR][16], B[MAXR][16], bias[MAXR], invd[MAXR], lo[MAXR], hi[MAXR], lam[MAXR];
+    int fr_normal[MAXR];
+    int nr = 0, nl = 0;
+    REAL zero6[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < NJ; ++j) {
+        REAL dlo = q[7 + j] - K->lo[j], dhi = K->hi[j] - q[7 + j];
+        int act = 0; REAL sgn = 0, dist = 0;
+        if (dlo < K->lmargin) { act = 1; sgn = 1; dist = dlo; }
+        else if (dhi < K->lmargin) { act = 1; sgn = -1; dist = dhi; }
+        if (!act) continue;
+        memset(J[nr], 0, sizeof(J[nr]));
+        J[nr][6 + j] = sgn;
+        FN(orc_response)(&D, zero6, 0, j / 2, (j & 1) ? R_(0) : sgn, (j & 1) ? sgn : R_(0), B[nr]);
+        B[nr][14] = B[nr][15] = 0;
+        bias[nr] = (dist > 0 ? dist : K->erp_l * dist) / h;
+        lo[nr] = 0; hi[nr] = K->limp_max; fr_normal[nr] = -1;
+        ++nr; ++nl;
+    }
+    FN(orc_contact) C[MAXC];
+    int nc = FN(orc_detect)(K, W, &D, q, C, ground_touch);
+    /* rows nl..nl+nc-1: normals; then rows nl+nc+2c (t1), nl+nc+2c+1 (t2) */
+    for (int row = 0; row < 3 * nc; ++row) {
+        int c = row < nc ? row : (row - nc) / 2, which = row < nc ? 0 : 1 + ((row - nc) & 1);
+        REAL t1[3], t2[3], phi[6];
+        FN(tangent_basis)(C[c].n, t1, t2);
+        const REAL *d = which == 0 ? C[c].n : (which == 1 ? t1 : t2);
+        FN(v3cross)(phi, C[c].r, d);
+        for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
+        memset(J[nr], 0, sizeof(J[nr]));
+        for (int k = 0; k < 6; ++k) J[nr][k] = phi[k];
+        if (C[c].level >= 1) J[nr][6 + 2 * C[c].leg] = FN(dot6)(phi, D.S[2 * C[c].leg]);
+        if (C[c].level >= 2) J[nr][7 + 2 * C[c].leg] = FN(dot6)(phi, D.S[2 * C[c].leg + 1]);
+        FN(orc_response)(&D, phi, C[c].level, C[c].leg, 0, 0, B[nr]);
+        B[nr][14] = B[nr][15] = 0;
+        if (which == 0) {
+            bias[nr] = (C[c].dist > 0 ? C[c].dist : K->erp_c * C[c].dist) / h;
+            lo[nr] = 0; hi[nr] = R_(1e30); fr_normal[nr] = -1;
+        } else { bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fr_normal[nr] = nl + c; }
+        ++nr;
+    }
+    for (int r = 0; r < nr; ++r) {
+        REAL prod[16];
+        for (int k = 0; k < 16; ++k) prod[k] = J[r][k] * B[r][k];
+        invd[r] = R_(1) / FN(sum16_tree)(prod);
+        lam[r] = 0;
+    }
+    /* (3) projected Gauss-Seidel, rows in order, friction bounds from the current normal impulse */
+    for (int it = 0; it < K->iters; ++it)
+        for (int r = 0; r < nr; ++r) {
+            REAL prod[16], l_lo = lo[r], l_hi = hi[r];
+            if (fr_normal[r] >= 0) { l_hi = K->mu * lam[fr_normal[r]]; l_lo = -l_hi; }
+            for (int k = 0; k < 16; ++k) prod[k] = J[r][k] * un[k];
+            REAL wv = FN(sum16_tree)(prod);
+            REAL ln = FN(clampr)(lam[r] - (wv + bias[r]) * invd[r], l_lo, l_hi);
+            REAL dl = ln - lam[r];
+            lam[r] = ln;
+            for (int k = 0; k < 16; ++k) un[k] = un[k] + B[r][k] * dl;
+        }
+    /* (4) joint-rate clamp and position integration (semi-implicit Euler, exponential map for the quaternion) */
+    for (int j = 0; j < NJ; ++j) un[6 + j] = FN(clampr)(un[6 + j], -K->vmax, K->vmax);
+    for (int k = 0; k < NDOF; ++k) u[k] = un[k];
+    for (int k = 0; k < 3; ++k) q[k] = q[k] + h * u[3 + k];
+    {
+        REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
+        if (th > R_(1e-6)) { REAL s = RSIN(R_(0.5) * th) / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = RCOS(R_(0.5) * th); }
+        else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
+        REAL x = q[3], y = q[4], z = q[5], w = q[6]; /* q <- dq (x) q */
+        REAL nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
+        REAL ny = dq[3] * y - dq[0] * z + dq[1] * w + dq[2] * x;
+        REAL nz = dq[3] * z + dq[0] * y - dq[1] * x + dq[2] * w;
+        REAL nw = dq[3] * w - dq[0] * x - dq[1] * y - dq[2] * z;
+        REAL inv = R_(1) / RSQRT((nx * nx + ny * ny) + (nz * nz + nw * nw));
+        q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
+    }
+    for (int j = 0; j < NJ; ++j) q[7 + j] = q[7 + j] + h * u[6 + j];
+    if (dbg) { dbg->n_rows = nr; dbg->n_limits = nl; dbg->n_contacts = nc; for (int r = 0; r < nr; ++r) dbg->lambda[r] = lam[r]; }
+}
+
+/* ---------------------------------------------------------------------------------------------- point bot body
+ * point_bot.py:10-74 + assets/player_cube.xml:8: free 10 kg cube, half extent 0.35, friction 0.1.  A solid cube's
+ * inertia is isotropic (m s^2/6), so M^-1 is diagonal and omega x I omega = 0. */
+void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL *q, REAL *u, const REAL *force) {
+    const REAL m = 10, he = R_(0.35), I = m * (R_(0.7) * R_(0.7)) / 6, h = K->h;
+    REAL x = q[3], y = q[4], z = q[5], w = q[6], X[3], Y[3], Z[3];
+    FN(v3set)(X, 1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y));
+    FN(v3set)(Y, 2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x));
+    FN(v3set)(Z, 2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y));
+    REAL un[6];
+    for (int k = 0; k < 3; ++k) un[k] = u[k];
+    un[3] = u[3] + h * (force[0] / m); un[4] = u[4] + h * (force[1] / m); un[5] = u[5] + h * (force[2] / m - K->g);
+    /* contacts: 8 corners vs ground + lateral planes, surface-major order, at most MAXC */
+    REAL Jr[3 * MAXC][6], Br[3 * MAXC][6], bias[3 * MAXC], invd[3 * MAXC], lam[3 * MAXC];
+    int frn[3 * MAXC], nc = 0;
+    REAL cr[MAXC][3], cn[MAXC][3], cd[MAXC];
+    for (int f = 0; f < 1 + W->n_planes; ++f)
+        for (int s = 0; s < 8; ++s) {
+            REAL c[3], n[3], dist;
+            REAL sx = (s & 1) ? he : -he, sy = (s & 2) ? he : -he, sz = (s & 4) ? he : -he;
+            for (int k = 0; k < 3; ++k) c[k] = (sx * X[k] + sy * Y[k]) + sz * Z[k];
+            if (f == 0) { FN(v3set)(n, 0, 0, 1); dist = (q[2] + c[2]) - K->ground_z; }
+            else {
+                const REAL *pn = W->plane_n[f - 1];
+                REAL p[3] = {q[0] + c[0], q[1] + c[1], q[2] + c[2]};
+                FN(v3set)(n, pn[0], pn[1], pn[2]);
+                dist = FN(v3dot)(n, p) - W->plane_d[f - 1];
+            }
+            if (dist < K->cdist && nc < MAXC) {
+                for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
+                cd[nc] = dist; ++nc;
+            }
+        }
+    int nr = 0;
+    for (int row = 0; row < 3 * nc; ++row) {
+        int c = row < nc ? row : (row - nc) / 2, which = row < nc ? 0 : 1 + ((row - nc) & 1);
+        REAL t1[3], t2[3];
+        FN(tangent_basis)(cn[c], t1, t2);
+        const REAL *d = which == 0 ? cn[c] : (which == 1 ? t1 : t2);
+        FN(v3cross)(Jr[nr], cr[c], d);
+        for (int k = 0; k < 3; ++k) { Jr[nr][3 + k] = d[k]; Br[nr][k] = Jr[nr][k] / I; Br[nr][3 + k] = d[k] / m; }
+        invd[nr] = R_(1) / FN(dot6)(Jr[nr], Br[nr]);
+        bias[nr] = which == 0 ? (cd[c] > 0 ? cd[c] : K->erp_c * cd[c]) / h : R_(0);
+        frn[nr] = which == 0 ? -1 : c;
+        lam[nr] = 0; ++nr;
+    }
+    for (int it = 0; it < K->iters; ++it)
+        for (int r = 0; r < nr; ++r) {
+            REAL l_lo = 0, l_hi = R_(1e30);
+            if (frn[r] >= 0) { l_hi = K->mu * lam[frn[r]]; l_lo = -l_hi; }
+            REAL wv = FN(dot6)(Jr[r], un);
+            REAL ln = FN(clampr)(lam[r] - (wv + bias[r]) * invd[r], l_lo, l_hi), dl = ln - lam[r];
+            lam[r] = ln;
+            for (int k = 0; k < 6; ++k) un[k] = un[k] + Br[r][k] * dl;
+        }
+    for (int k = 0; k < 6; ++k) u[k] = un[k];
+    for (int k = 0; k < 3; ++k) q[k] = q[k] + h * u[3 + k];
+    {
+        REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
+        if (th > R_(1e-6)) { REAL s = RSIN(R_(0.5) * th) / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = RCOS(R_(0.5) * th); }
+        else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
+        REAL nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
+        REAL ny = dq[3] * y - dq[0] * z + dq[1] * w + dq[2] * x;
+        REAL nz = dq[3] * z + dq[0] * y - dq[1] * x + dq[2] * w;
+        REAL nw = dq[3] * w - dq[0] * x - dq[1] * y - dq[2] * z;
+        REAL inv = R_(1) / RSQRT((nx * nx + ny * ny) + (nz * nz + nw * nw));
+        q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
+    }
+}
+
+/* =================================================================================================================
+ * PART 3 -- observation packing + env-level reset/step on the packed buffers of include/hrl_envs.h
+ * ================================================================================================================= */
+
+/* pybullet getEulerFromQuaternion (upstream, restated from memory): ZYX angles with a gimbal-lock guard */
+void FN(orc_quat_to_rpy)(const REAL *qq, REAL *rpy) {
+    REAL x = qq[0], y = qq[1], z = qq[2], w = qq[3];
+    REAL sarg = R_(-2) * (x * z - w * y);
+    const REAL hp = R_(1.5707963267948966);
+    if (sarg <= R_(-0.99999)) { rpy[0] = 0; rpy[1] = -hp; rpy[2] = 2 * RATAN2(x, -y); }
+    else if (sarg >= R_(0.99999)) { rpy[0] = 0; rpy[1] = hp; rpy[2] = 2 * RATAN2(-x, y); }
+    else {
+        REAL sqx = x * x, sqy = y * y, sqz = z * z, sqw = w * w;
+        rpy[0] = RATAN2(2 * (y * z + w * x), ((sqw - sqx) - sqy) + sqz);
+        rpy[1] = RASIN(sarg);
+        rpy[2] = RATAN2(2 * (x * y + w * z), ((sqw + sqx) - sqy) - sqz);
+    }
+}
+
+/* upstream WalkerBase.calc_state (restated from memory): 28-vector clipped to +-5.
+ * Also returns joints_at_limit, walk_target_dist (centroid based) and yaw. */
+void FN(orc_ant_calc_state)(const hrl_config *cfg, const FN(orc_consts) * K, const REAL *qpos, const REAL *qvel,
+                            REAL initial_z, const REAL *target, const REAL *feet_contact, REAL *out28,
+                            int *joints_at_limit, REAL *walk_target_dist, REAL *rpy_out) {
+    REAL rpy[3];
+    FN(orc_quat_to_rpy)(qpos + 3, rpy);
+    /* centroid over robot.parts: 13 link COMs + the scene statics */
+    FN(orc_dyn) D;
+    REAL u0[14] = {0}, q[15];
+    for (int i = 0; i < 15; ++i) q[i] = qpos[i];
+    FN(orc_dynamics)(K, q, u0, 0, &D);
+    REAL sx = 0, sy = 0;
+    for (int l = 0; l < 4; ++l) {
+        /* fixed leg COM = ph/2; aux COM = (ph+pa)/2; foot COM = (pa+tip)/2 -- all relative to the torso */
+        sx += (R_(0.5) * D.ph[l][0] + R_(0.5) * (D.ph[l][0] + D.pa[l][0])) + R_(0.5) * (D.pa[l][0] + D.tip[l][0]);
+        sy += (R_(0.5) * D.ph[l][1] + R_(0.5) * (D.ph[l][1] + D.pa[l][1])) + R_(0.5) * (D.pa[l][1] + D.tip[l][1]);
+    }
+    REAL np_ = R_(13 + cfg->centroid_n_static);
+    REAL cx = ((R_(13) * qpos[0] + sx) + R_(cfg->centroid_static_sum[0])) / np_;
+    REAL cy = ((R_(13) * qpos[1] + sy) + R_(cfg->centroid_static_sum[1])) / np_;
+    REAL dx = target[0] - cx, dy = target[1] - cy;
+    REAL theta = RATAN2(dy, dx);
+    *walk_target_dist = RSQRT(dy * dy + dx * dx);
+    REAL ang = theta - rpy[2];
+    REAL c = RCOS(-rpy[2]), s = RSIN(-rpy[2]);
+    REAL vx = c * qvel[0] - s * qvel[1], vy = s * qvel[0] + c * qvel[1], vz = qvel[2];
+    out28[0] = qpos[2] - initial_z; out28[1] = RSIN(ang); out28[2] = RCOS(ang);
+    out28[3] = R_(0.3) * vx; out28[4] = R_(0.3) * vy; out28[5] = R_(0.3) * vz; out28[6] = rpy[0]; out28[7] = rpy[1];
+    int nlim = 0;
+    for (int j = 0; j < NJ; ++j) {
+        REAL mid = R_(0.5) * (K->lo[j] + K->hi[j]);
+        REAL rel = 2 * (qpos[7 + j] - mid) / (K->hi[j] - K->lo[j]);
+        out28[8 + 2 * j] = rel; out28[9 + 2 * j] = R_(0.1) * qvel[6 + j];
+        if (RFABS(rel) > R_(0.99)) ++nlim;
+    }
+    for (int i = 0; i < 4; ++i) out28[24 + i] = feet_contact[i];
+    for (int i = 0; i < 28; ++i) out28[i] = FN(clampr)(out28[i], -5, 5); /* NaN passes through like np.clip */
+    *joints_at_limit = nlim;
+    for (int i = 0; i < 3; ++i) rpy_out[i] = rpy[i];
+}
+
+static REAL FN(u01)(uint32_t x) { return R_(x >> 8) * R_(5.9604644775390625e-08); }
+
+/* uniform pair for (env, index, purpose, sub, attempt) -- counter-based, no stored RNG state */
+static void FN(draw_pair)(const hrl_config *cfg, int64_t env, uint32_t index, uint32_t purpose, uint32_t sub, uint32_t attempt, REAL *out) {
+    uint32_t r[4];
+    orc_philox4x32(cfg->seed, env, index, (purpose << 16) | sub, attempt, r);
+    out[0] = FN(u01)(r[0]); out[1] = FN(u01)(r[1]);
+}
+
+/* gather_scene.py:52-62 with Philox draws; at most 64 attempts (the last is kept) */
+static void FN(respawn_item)(const hrl_config *cfg, int64_t env, uint32_t index, uint32_t purpose, int item, const REAL *avoid, REAL *pos) {
+    REAL sxw = R_(cfg->world_size[0]) - 1, syw = R_(cfg->world_size[1]) - 1, sp = R_(cfg->robot_object_spacing);
+    for (uint32_t a = 0; a < 64; ++a) {
+        REAL d[2];
+        FN(draw_pair)(cfg, env, index, purpose, (uint32_t)item, a, d);
+        pos[0] = d[0] * sxw - sxw / 2; pos[1] = d[1] * syw - syw / 2;
+        REAL dx = avoid[0] - pos[0], dy = avoid[1] - pos[1];
+        if (!(RSQRT(dx * dx + dy * dy) < sp)) break;
+    }
+}
+
+static void FN(gather_obs_tail)(const hrl_config *cfg, const REAL *xy, REAL yaw, const REAL *items, REAL *obs) {
+    REAL d2[HRL_MAX_ITEMS];
+    int n = cfg->n_food + cfg->n_poison;
+    for (int i = 0; i < n; ++i) d2[i] = FN(orc_sq_dist)(items + 2 * i, xy);
+    if (cfg->use_sensor) FN(orc_food_sensor)(cfg->n_bins, FN(cfg_angle)(cfg->sensor_span), R_(cfg->sensor_range), xy, yaw, items,
+                                             cfg->n_food, cfg->n_poison, d2, obs, obs + cfg->n_bins);
+    else {
+        int nfo = 2 * (cfg->n_food < cfg->n_bins ? cfg->n_food : cfg->n_bins);
+        FN(orc_abs_pos)(cfg->n_bins, items, cfg->n_food, cfg->n_poison, d2, obs, obs + nfo);
+    }
+}
+
+static const REAL FN(maze_lines)[7][4] = { /* MazeScene.bounds: maze_scene.py:15-21 + sizeable_enclosed_scene.py:28-34 */
+    {5, 9, -5, 9}, {5, 9, 5, -9}, {-5, -9, -5, 9}, {-5, -9, 5, -9}, {1, 2, 1, -2}, {-5, -2, -5, 2}, {-5, -2, 1, -2}};
+
+typedef struct FN(orc_env) {
+    hrl_config cfg;
+    FN(orc_consts) K;
+    FN(orc_world) W;
+} FN(orc_env);
+
+void FN(orc_env_init)(const hrl_config *cfg, FN(orc_env) * E) {
+    E->cfg = *cfg;
+    FN(orc_consts_init)(&cfg->model, &E->K);
+    FN(orc_world_init)(cfg, &E->W);
+}
+
+/* observation of the CURRENT state (used by reset and by step) for ant kinds that do not need step-only data */
+static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *items, const int32_t *aux, const REAL *feet,
+                         REAL *obs, REAL *wtd_out, int *nlim_out, REAL *s28_out) {
+    const hrl_config *cfg = &E->cfg;
+    if (cfg->env_kind == HRL_POINT_GATHER) {
+        REAL rpy[3], tgt[2] = {0, 0};
+        FN(orc_quat_to_rpy)(st + 3, rpy);
+        FN(orc_pointbot_state)(st, rpy, st + HRL_QVEL_OFF, tgt, 1, obs);
+        FN(gather_obs_tail)(cfg, st, rpy[2], items, obs + 8);
+        return;
+    }
+    REAL s28[28], rpy[3], wtd, tgt[2] = {R_(cfg->walk_target[0]), R_(cfg->walk_target[1])};
+    int nlim;
+    if (cfg->env_kind == HRL_ANT_MAZE) { tgt[0] = R_(cfg->targets[aux[3]][0]); tgt[1] = R_(cfg->targets[aux[3]][1]); }
+    FN(orc_ant_calc_state)(cfg, &E->K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+    if (wtd_out) *wtd_out = wtd;
+    if (nlim_out) *nlim_out = nlim;
+    if (s28_out) for (int i = 0; i < 28; ++i) s28_out[i] = s28[i];
+    if (cfg->env_kind == HRL_ANT_FLAT) { for (int i = 0; i < 29; ++i) obs[i] = st[i]; return; } /* MjAnt.py:17-25 */
+    if (cfg->env_kind == HRL_ANT_GATHER) {
+        obs[0] = s28[0];
+        for (int i = 3; i < 28; ++i) obs[i - 2] = s28[i];
+        FN(gather_obs_tail)(cfg, st, rpy[2], items, obs + 26);
+        return;
+    }
+    /* maze: ant_maze_bullet_env.py:63-75 (reward/done unused here) */
+    REAL r; int d;
+    FN(orc_maze_task)(cfg, s28, 0, 0, st, rpy[2], tgt, wtd, -1000000, &FN(maze_lines)[0][0], 7, 3, obs, &r, &d);
+}
+
+void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, REAL *obs) {
+    const hrl_config *cfg = &E->cfg;
+    uint32_t ep = (uint32_t)aux[2];
+    for (int i = 0; i < HRL_STATE_STRIDE; ++i) st[i] = 0;
+    st[6] = 1; /* identity quaternion (x,y,z,w) */
+    if (cfg->env_kind == HRL_POINT_GATHER) { st[2] = R_(0.5); st[HRL_INITZ_OFF] = 1; } /* point_bot.py:12,18 */
+    else {
+        if (cfg->env_kind == HRL_ANT_MAZE) { /* ant_maze_bullet_env.py:108-118 */
+            uint32_t r[4];
+            orc_philox4x32(cfg->seed, env, ep, (3u << 16), 0, r);
+            aux[3] = (int32_t)(r[0] % (uint32_t)cfg->n_targets);
+            st[0] = R_(cfg->start_pos[0]); st[1] = R_(cfg->start_pos[1]); st[2] = R_(cfg->start_pos[2]);
+        } else st[2] = R_(0.75); /* assets/ant.xml:12 */
+        for (int j = 0; j < NJ; ++j) { /* upstream robot_specific_reset: joints ~ U(-0.1, 0.1), zero rates */
+            uint32_t r[4];
+            orc_philox4x32(cfg->seed, env, ep, (2u << 16) | (uint32_t)(j / 4), 0, r);
+            st[7 + j] = R_(-0.1) + R_(0.2) * FN(u01)(r[j % 4]);
+        }
+        st[HRL_INITZ_OFF] = st[2];
+    }
+    if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) { /* gather_scene.py:38-50 */
+        REAL origin[2] = {0, 0};
+        for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+        for (int i = 0; i < cfg->n_food + cfg->n_poison; ++i) FN(respawn_item)(cfg, env, ep, 1, i, origin, items + 2 * i);
+    }
+    aux[0] = 0; aux[2] = (int32_t)(ep + 1);
+    REAL feet[4] = {0, 0, 0, 0}, wtd = 0;
+    FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0);
+    st[HRL_POTENTIAL_OFF] = -wtd / (E->K.h * R_(E->K.nsub)); /* upstream calc_potential = -dist/dt */
+}
+
+/* One env step on the packed record.  Mirrors hrl_step() of include/hrl_envs.h. */
+void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, const REAL *act,
+                          REAL *obs, REAL *rew_out, uint8_t *done_out, REAL *info) {
+    const hrl_config *cfg = &E->cfg;
+    const FN(orc_consts) *K = &E->K;
+    REAL q[15], u[14], feet[4] = {0, 0, 0, 0};
+    uint32_t t_life = (uint32_t)aux[1];
+    for (int i = 0; i < 15; ++i) q[i] = st[i];
+    for (int k = 0; k < 3; ++k) { u[k] = st[HRL_QVEL_OFF + 3 + k]; u[3 + k] = st[HRL_QVEL_OFF + k]; }
+    for (int j = 0; j < NJ; ++j) u[6 + j] = st[HRL_QVEL_OFF + 6 + j];
+    if (cfg->env_kind == HRL_POINT_GATHER) { /* point_bot.py:28-31: a/|a|*500 N in the world xy plane */
+        REAL n = RSQRT(act[0] * act[0] + act[1] * act[1]), f[3] = {act[0] / n * R_(cfg->model.point_force), act[1] / n * R_(cfg->model.point_force), 0};
+        for (int s = 0; s < K->nsub; ++s) FN(orc_point_substep)(K, &E->W, q, u, f);
+    } else {
+        REAL tau[NJ];
+        for (int j = 0; j < NJ; ++j) tau[j] = R_(cfg->model.torque_scale) * FN(clampr)(act[j], -1, 1);
+        int gt[13];
+        for (int s = 0; s < K->nsub; ++s) FN(orc_ant_substep)(K, &E->W, q, u, tau, gt, 0);
+        for (int l = 0; l < 4; ++l) feet[l] = (gt[2 + 3 * l] || gt[3 + 3 * l]) ? R_(1) : R_(0);
+    }
+    for (int i = 0; i < 15; ++i) st[i] = q[i];
+    for (int k = 0; k < 3; ++k) { st[HRL_QVEL_OFF + 3 + k] = u[k]; st[HRL_QVEL_OFF + k] = u[3 + k]; }
+    for (int j = 0; j < NJ; ++j) st[HRL_QVEL_OFF + 6 + j] = u[6 + j];
+
+    REAL rew = 0, food_rew = 0, dead_rew = 0;
+    int done = 0;
+    if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) {
+        /* pickups (ant_gather_env.py:84-92) -- item order = food slots then poison slots */
+        int n = cfg->n_food + cfg->n_poison;
+        if (cfg->robot_coll_dist > 0)
+            for (int i = 0; i < n; ++i)
+                if (FN(orc_sq_dist)(items + 2 * i, st) < R_(cfg->robot_coll_dist)) {
+                    food_rew += (i < cfg->n_food) ? 1 : -1;
+                    if (cfg->respawn) FN(respawn_item)(cfg, env, t_life, 0, i, st, items + 2 * i);
+                    else { items[2 * i] = 100; items[2 * i + 1] = 0; }
+                }
+        int no = orc_obs_dim(cfg);
+        if (cfg->env_kind == HRL_ANT_GATHER) feet[0] = feet[1] = feet[2] = feet[3] = 0; /* ant_gather_env.py:105-111 */
+        FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0);
+        REAL alive = 1;
+        if (cfg->env_kind == HRL_ANT_GATHER) alive = (obs[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
+        done = alive < 0;
+        for (int i = 0; i < no; ++i) if (!isfinite(obs[i])) done = 1;
+        dead_rew = alive < 0 ? R_(cfg->dying_cost) : 0;
+        rew = food_rew + dead_rew;
+    } else if (cfg->env_kind == HRL_ANT_FLAT) {
+        REAL wtd; int nlim;
+        FN(make_obs)(E, st, items, aux, feet, obs, &wtd, &nlim, 0);
+        REAL pot = -wtd / (K->h * R_(K->nsub));
+        FN(orc_antmj_reward)(obs, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &rew, &done);
+        st[HRL_POTENTIAL_OFF] = pot;
+    } else { /* maze: upstream WalkerBaseBulletEnv.step then ant_maze_bullet_env.py:77-97 */
+        REAL wtd, s28[28], rpy[3], tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};
+        int nlim;
+        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+        REAL alive = (s28[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
+        int idone = alive < 0;
+        for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
+        REAL pot = -wtd / (K->h * R_(K->nsub)), progress = pot - st[HRL_POTENTIAL_OFF];
+        st[HRL_POTENTIAL_OFF] = pot;
+        REAL e1 = 0, e2 = 0;
+        for (int j = 0; j < NJ; ++j) { REAL a = act[j]; e1 += RFABS(a * s28[9 + 2 * j]); e2 += a * a; }
+        REAL electricity = R_(-2.0) * (e1 / NJ) + R_(-0.1) * (e2 / NJ);
+        REAL inner = (((alive + progress) + electricity) + R_(-0.1) * R_(nlim)) + 0;
+        FN(orc_maze_task)(cfg, s28, inner, idone, st, rpy[2], tgt, wtd, aux[0] + 1, &FN(maze_lines)[0][0], 7, 3, obs, &rew, &done);
+    }
+    aux[0] += 1; aux[1] += 1;
+    if (cfg->max_episode_steps > 0 && aux[0] >= cfg->max_episode_steps) done = 1; /* gym TimeLimit, __init__.py:15 */
+    st[HRL_EPRET_OFF] += rew;
+    *rew_out = rew; *done_out = (uint8_t)done;
+    info[0] = food_rew; info[1] = dead_rew; info[2] = st[HRL_EPRET_OFF]; info[3] = R_(aux[0]);
+    if (done && cfg->auto_reset) FN(orc_env_reset_one)(E, env, st, items, aux, obs);
+}
+
+/* batched drivers over host buffers laid out exactly like the device buffers */
+void FN(orc_reset_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const uint8_t *mask, REAL *obs) {
+    FN(orc_env) E;
+    FN(orc_env_init)(cfg, &E);
+    int od = orc_obs_dim(cfg);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < cfg->num_envs; ++i) {
+        if (mask && !mask[i]) continue;
+        FN(orc_env_reset_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE,
+                              items ? items + (size_t)i * HRL_ITEMS_STRIDE : 0, aux + (size_t)i * HRL_AUX_STRIDE, obs + (size_t)i * od);
+    }
+}
+void FN(orc_step_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
+                        REAL *reward, uint8_t *done, REAL *info) {
+    FN(orc_env) E;
+    FN(orc_env_init)(cfg, &E);
+    int od = orc_obs_dim(cfg), ad = orc_act_dim(cfg);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < cfg->num_envs; ++i)
+        FN(orc_env_step_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE,
+                             items ? items + (size_t)i * HRL_ITEMS_STRIDE : 0, aux + (size_t)i * HRL_AUX_STRIDE,
+                             actions + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, info + (size_t)i * HRL_INFO_STRIDE);
+}
+
+/* ---------------------------------------------------------------------------------------------- KAT helpers (tests) */
+/* kinetic energy + linear/angular momentum (about the world origin) of the ant by plain per-body sums */
+void FN(orc_ant_energy_momentum)(const hrl_model *M, const REAL *q, const REAL *u, REAL *out /* T, V, P[3], L[3] */) {
+    FN(orc_consts) K; FN(orc_dyn) D;
+    FN(orc_consts_init)(M, &K);
+    FN(orc_dynamics)(&K, q, u, 0, &D);
+    REAL T = 0, V = 0, P[3] = {0, 0, 0}, L[3] = {0, 0, 0};
+    for (int b = 0; b < NBODY; ++b) {
+        REAL m, al, be, e[3], c[3], w[3], vO[3];
+        for (int k = 0; k < 3; ++k) { w[k] = u[k]; vO[k] = u[3 + k]; }
+        if (b == 0) { m = K.m0; al = K.a0; be = K.b0; for (int k = 0; k < 3; ++k) { e[k] = D.Z[k]; c[k] = 0; } }
+        else {
+            int l = (b - 1) / 2, foot = (b - 1) & 1;
+            const REAL *p0 = foot ? D.pa[l] : D.ph[l], *p1 = foot ? D.tip[l] : D.pa[l];
+            REAL len = foot ? K.L2 : K.L1;
+            m = foot ? K.m2 : K.m1; al = foot ? K.a2 : K.a1; be = foot ? K.b2 : K.b1;
+            for (int k = 0; k < 3; ++k) { e[k] = (p1[k] - p0[k]) / len; c[k] = R_(0.5) * (p0[k] + p1[k]); }
+            for (int k = 0; k < 6; ++k) { REAL sv = D.S[2 * l][k] * u[6 + 2 * l]; if (k < 3) w[k] += sv; else vO[k - 3] += sv; }
+            if (foot) for (int k = 0; k < 6; ++k) { REAL sv = D.S[2 * l + 1][k] * u[7 + 2 * l]; if (k < 3) w[k] += sv; else vO[k - 3] += sv; }
+        }
+        REAL wxc[3], vc[3], Iw[3], ew = FN(v3dot)(e, w), pw[3], cw[3], lw[3];
+        FN(v3cross)(wxc, w, c);
+        for (int k = 0; k < 3; ++k) { vc[k] = vO[k] + wxc[k]; Iw[k] = al * w[k] + be * e[k] * ew; pw[k] = q[k] + c[k]; }
+        T += R_(0.5) * (m * FN(v3dot)(vc, vc) + FN(v3dot)(w, Iw));
+        V += m * K.g * pw[2];
+        for (int k = 0; k < 3; ++k) { cw[k] = m * vc[k]; P[k] += cw[k]; }
+        FN(v3cross)(lw, pw, cw);
+        for (int k = 0; k < 3; ++k) L[k] += lw[k] + Iw[k];
+    }
+    out[0] = T; out[1] = V; for (int k = 0; k < 3; ++k) { out[2 + k] = P[k]; out[5 + k] = L[k]; }
+}
+/* accelerations [a0(6) | qdd(8)] for tests */
+void FN(orc_ant_accel)(const hrl_model *M, const REAL *q, const REAL *u, const REAL *tau, REAL *out14) {
+    FN(orc_consts) K; FN(orc_dyn) D;
+    FN(orc_consts_init)(M, &K);
+    FN(orc_dynamics)(&K, q, u, tau, &D);
+    for (int k = 0; k < 6; ++k) out14[k] = D.a0[k];
+    for (int j = 0; j < NJ; ++j) out14[6 + j] = D.qdd[j];
+}
+/* M^-1 (14x14, row-major) assembled column by column from unit generalized impulses via orc_response */
+void FN(orc_ant_minv)(const hrl_model *M, const REAL *q, REAL *out196) {
+    FN(orc_consts) K; FN(orc_dyn) D;
+    REAL u0[14] = {0};
+    FN(orc_consts_init)(M, &K);
+    FN(orc_dynamics)(&K, q, u0, 0, &D);
+    for (int c = 0; c < NDOF; ++c) {
+        REAL phi[6] = {0, 0, 0, 0, 0, 0}, du[16];
+        if (c < 6) { phi[c] = 1; FN(orc_response)(&D, phi, 0, 0, 0, 0, du); }
+        else { int j = c - 6; FN(orc_response)(&D, phi, 0, j / 2, (j & 1) ? R_(0) : R_(1), (j & 1) ? R_(1) : R_(0), du); }
+        for (int r = 0; r < NDOF; ++r) out196[r * NDOF + c] = du[r];
+    }
+}
+void FN(orc_ant_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *tau, int n, int *info3) {
+    FN(orc_env) E; FN(orc_substep_dbg) dbg; int gt[13];
+    FN(orc_env_init)(cfg, &E);
+    memset(&dbg, 0, sizeof(dbg));
+    for (int s = 0; s < n; ++s) FN(orc_ant_substep)(&E.K, &E.W, q, u, tau, gt, &dbg);
+    if (info3) { info3[0] = dbg.n_rows; info3[1] = dbg.n_limits; info3[2] = dbg.n_contacts; }
+}
+
+#undef NJ
+#undef NBODY
+#undef NDOF
+#undef MAXC
+#undef MAXR
+#undef RSQRT
+#undef RSIN
+#undef RCOS
+#undef RATAN2
+#undef RASIN
+#undef RFABS
+#undef RFMOD

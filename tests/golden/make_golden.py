@@ -1,0 +1,465 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the reference's own in-tree Python task logic.
+
+Runs ONLY in the build container (needs /root/reference). Writes small JSON fixtures
+(inputs + expected outputs, float64) next to this file; the fixtures travel to the GPU
+box, the reference does not.
+
+The reference's physics lives in third-party packages that are absent here (pybullet,
+pybullet_envs, pybulletgym, gym -> ModuleNotFoundError).  Those modules are replaced in
+sys.modules by EMPTY stand-ins (base classes with no behaviour) so that the in-tree
+modules import; every function called below is in-tree reference code, called on
+duck-typed `self` objects that carry only the attributes the function reads.  Nothing
+from the stand-ins contributes arithmetic to a fixture (the one exception is
+pybullet.getQuaternionFromEuler, used by the reference only as a class constant that the
+fixtures never read).
+
+Usage:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+"""
+import json
+import math
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+OUT_DIR = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+
+# ----------------------------------------------------------------------------------------------
+# stand-ins for the absent third-party packages
+# ----------------------------------------------------------------------------------------------
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Empty:
+    def __init__(self, *a, **k):
+        pass
+
+
+def install_stubs():
+    class Box(_Empty):
+        def __init__(self, low=None, high=None, shape=None, **k):
+            self.low, self.high, self.shape = low, high, shape
+
+    class Scene(_Empty):
+        def episode_restart(self, bullet_client):
+            pass
+
+    class AntBulletEnv(_Empty):
+        """Stand-in base: step() returns whatever the test parked on the instance."""
+
+        def step(self, a):
+            return self._super_step_result
+
+    class WalkerBaseMuJoCoEnv(_Empty):
+        def HUD(self, *a):
+            pass
+
+    class WalkerBase(_Empty):
+        def calc_state(self):
+            return None
+
+    _mod('pybullet', getQuaternionFromEuler=lambda e: (0.0, 0.0, 0.0, 1.0),
+         COV_ENABLE_PLANAR_REFLECTION=0, GUI=1)
+    _mod('pybullet_data', getDataPath=lambda: '/nonexistent')
+    _mod('pybullet_envs')
+    _mod('pybullet_envs.robot_bases', BodyPart=_Empty, MJCFBasedRobot=_Empty, Pose_Helper=_Empty)
+    _mod('pybullet_envs.env_bases', MJCFBaseBulletEnv=_Empty)
+    _mod('pybullet_envs.scene_abstract', Scene=Scene)
+    _mod('pybullet_envs.gym_locomotion_envs', AntBulletEnv=AntBulletEnv, WalkerBaseBulletEnv=_Empty)
+    for n in ('pybulletgym', 'pybulletgym.envs', 'pybulletgym.envs.mujoco', 'pybulletgym.envs.mujoco.envs',
+              'pybulletgym.envs.mujoco.envs.locomotion', 'pybulletgym.envs.mujoco.robots',
+              'pybulletgym.envs.mujoco.robots.locomotors'):
+        _mod(n)
+    _mod('pybulletgym.envs.mujoco.envs.locomotion.walker_base_env', WalkerBaseMuJoCoEnv=WalkerBaseMuJoCoEnv)
+    _mod('pybulletgym.envs.mujoco.robots.locomotors.walker_base', WalkerBase=WalkerBase)
+    _mod('pybulletgym.envs.mujoco.robots.robot_bases', MJCFBasedRobot=_Empty)
+    _mod('pybulletgym.envs.mujoco.robots.locomotors.ant', Ant=_Empty)
+    seeding = _mod('gym.utils.seeding', np_random=lambda s=None: (np.random.RandomState(s), s))
+    utils = _mod('gym.utils', seeding=seeding)
+    spaces = _mod('gym.spaces', Box=Box)
+    envs = _mod('gym.envs', register=lambda **k: None)
+    _mod('gym', utils=utils, spaces=spaces, envs=envs)
+
+
+def NS(**k):
+    return types.SimpleNamespace(**k)
+
+
+class Pose:
+    def __init__(self, xyz, rpy):
+        self._xyz, self._rpy = list(xyz), list(rpy)
+
+    def xyz(self):
+        return self._xyz
+
+    def rpy(self):
+        return self._rpy
+
+
+class Body:
+    """Duck-typed BodyPart: only what the in-tree code reads."""
+
+    def __init__(self, xyz, rpy, speed=(0, 0, 0)):
+        self._pose = Pose(xyz, rpy)
+        self._speed = np.array(speed, dtype=float)
+
+    def pose(self):
+        return self._pose
+
+    def get_pose(self):
+        return list(self._pose.xyz()) + [0, 0, 0, 1]
+
+    def get_position(self):
+        return list(self._pose.xyz())
+
+    def speed(self):
+        return self._speed
+
+
+class LoggingRS:
+    """RandomState wrapper that records every uniform pair handed out by .rand(2)."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.log = []
+
+    def rand(self, n):
+        v = self.rs.rand(n)
+        self.log.append(v.tolist())
+        return v
+
+    def randint(self, lo, hi):
+        return self.rs.randint(lo, hi)
+
+
+class FakeClient:
+    def __init__(self):
+        self.next_id = 11
+
+    def loadURDF(self, path, basePosition=None, *a, **k):
+        i = self.next_id
+        self.next_id += 1
+        return i
+
+    def configureDebugVisualizer(self, *a, **k):
+        pass
+
+    def resetBasePositionAndOrientation(self, *a, **k):
+        pass
+
+    def changeDynamics(self, *a, **k):
+        pass
+
+
+def tolist(x):
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if isinstance(x, (list, tuple)):
+        return [tolist(v) for v in x]
+    if isinstance(x, (np.floating, np.integer)):
+        return x.item()
+    return x
+
+
+def main():
+    warnings.simplefilter('ignore')
+    install_stubs()
+    sys.path.insert(0, REF)
+    import hrl_pybullet_envs.envs.intersection_utils as iu
+    from hrl_pybullet_envs.envs.sizeable_enclosed_scene import SizeableEnclosedScene
+    from hrl_pybullet_envs.envs.ant_maze.maze_scene import MazeScene
+    from hrl_pybullet_envs.envs.gather.gather_scene import GatherScene
+    from hrl_pybullet_envs.envs.gather.ant_gather_env import AntGatherBulletEnv
+    from hrl_pybullet_envs.envs.gather.gather_base import GatherBulletEnv
+    from hrl_pybullet_envs.envs.gather.point_bot import PointBot
+    from hrl_pybullet_envs.envs.ant_maze.ant_maze_bullet_env import AntMazeBulletEnv
+    from hrl_pybullet_envs.envs.MjAnt import AntMjEnv, MjAnt
+    from hrl_pybullet_envs.utils import PositionEncoding
+
+    rng = np.random.RandomState(20261003)
+    G = {}
+
+    # ---------------------------------------------------------------- intersection_utils
+    P = iu.Point
+    cases = []
+    fixed = [((0, 0), (1, 1), (0, 2), (2, 0)), ((0, 0), (1, 0), (0, 1), (1, 1)), ((0, 0), (0, 1), (3, -2), (3, 5)),
+             ((1, 1), (2, 2), (3, 3), (4, 4)), ((-2, -5), (-2, 0), (5, 9), (-5, 9))]
+    for c in fixed:
+        cases.append([list(map(float, p)) for p in c])
+    for _ in range(60):
+        cases.append(rng.uniform(-10, 10, size=(4, 2)).round(3).tolist())
+    inter = []
+    for p1, p2, p3, p4 in cases:
+        r = iu.inf_intersection(P(*p1), P(*p2), P(*p3), P(*p4))
+        s = iu.segment_intersection(P(*p1), P(*p2), P(*p3), P(*p4))
+        inter.append({'p': [p1, p2, p3, p4], 'inf': None if r is None else [r.x, r.y], 'seg': bool(s)})
+    # collinear / touching segment special cases (reference's geeksforgeeks branches)
+    seg_special = [((0, 0), (2, 0), (1, 0), (3, 0)), ((0, 0), (1, 0), (2, 0), (3, 0)), ((0, 0), (2, 2), (2, 2), (3, 0)),
+                   ((0, 0), (2, 2), (1, 1), (1, 5)), ((0, 0), (0, 2), (0, 3), (0, 4)), ((0, 0), (4, 0), (2, 0), (2, 0))]
+    for p1, p2, p3, p4 in seg_special:
+        r = iu.inf_intersection(P(*p1), P(*p2), P(*p3), P(*p4))
+        s = iu.segment_intersection(P(*p1), P(*p2), P(*p3), P(*p4))
+        inter.append({'p': [list(map(float, p)) for p in (p1, p2, p3, p4)],
+                      'inf': None if r is None else [r.x, r.y], 'seg': bool(s)})
+    quad_pts = [(1, 1), (1, -1), (-1, 1), (-1, -1), (0, 0), (0, 1), (0, -1), (1, 0), (-1, 0)] + \
+        rng.uniform(-3, 3, size=(20, 2)).tolist()
+    quads = [{'p': [float(x), float(y)], 'q': iu.quadrant(P(x, y))} for x, y in quad_pts]
+    pol = [{'rho': float(r), 'phi': float(ph), 'xy': list(map(float, iu.pol2cart(r, ph)))}
+           for r, ph in rng.uniform(-7, 7, size=(10, 2))]
+    G['intersection'] = {'lines': inter, 'quadrant': quads, 'pol2cart': pol}
+
+    # ---------------------------------------------------------------- sense_walls
+    maze = MazeScene(None, 9.8, 0.0165 / 4, 4)
+    arena = SizeableEnclosedScene(None, 9.8, 0.0165 / 4, 4, (15, 15))
+
+    def bounds_list(scene):
+        return [[[a.x, a.y], [b.x, b.y]] for a, b in scene.bounds]
+
+    sw = {'maze_bounds': bounds_list(maze), 'arena_bounds': bounds_list(arena),
+          'maze_box_pos': list(maze.box_pos), 'cases': []}
+
+    def sw_case(scene_name, scene, bins, span, rng_, pos, yaw):
+        out = scene.sense_walls(bins, span, rng_, np.array(pos, dtype=float), yaw)
+        sw['cases'].append({'scene': scene_name, 'bins': bins, 'span': span, 'range': rng_,
+                            'pos': list(map(float, pos)), 'yaw': float(yaw), 'out': tolist(out)})
+
+    sw_case('maze', maze, 10, 2 * np.pi, 5.0, (-2, -5), 0.0)
+    sw_case('maze', maze, 10, 2 * np.pi, 5.0, (2, 0), 0.7)
+    for _ in range(120):
+        pos = (rng.uniform(-4.9, 4.9), rng.uniform(-8.9, 8.9))
+        sw_case('maze', maze, 10, 2 * np.pi, 5.0, pos, rng.uniform(-np.pi, np.pi))
+    for _ in range(30):
+        pos = (rng.uniform(-4.9, 4.9), rng.uniform(-8.9, 8.9))
+        sw_case('maze', maze, 8, np.pi, 4.0, pos, rng.uniform(-np.pi, np.pi))
+    for _ in range(30):
+        pos = (rng.uniform(-7.4, 7.4), rng.uniform(-7.4, 7.4))
+        sw_case('arena', arena, 10, 2 * np.pi, 5.0, pos, rng.uniform(-np.pi, np.pi))
+    G['sense_walls'] = sw
+
+    # ---------------------------------------------------------------- food sensor / abs pos / sq dist
+    def sensor_case(cls, n_bins, span, srange, n_food, n_poison, robot_xy, yaw, layout_rs):
+        food = {11 + i: (layout_rs.rand(2) * 14 - 7).tolist() + [0.1] for i in range(n_food)}
+        poison = {11 + n_food + i: (layout_rs.rand(2) * 14 - 7).tolist() + [0.1] for i in range(n_poison)}
+        body = Body([robot_xy[0], robot_xy[1], 0.5], [0.01, -0.02, yaw])
+        scene = NS(food=food, poison=poison, all_items={**food, **poison})
+        if cls is AntGatherBulletEnv:
+            self = NS(n_bins=n_bins, sensor_span=span, sensor_range=srange, robot_body=body, stadium_scene=scene,
+                      FOOD='food', POISON='poison', debug=False, parts={'torso': body})
+        else:
+            self = NS(n_bins=n_bins, sensor_span=span, sensor_range=srange, robot=NS(robot_body=body),
+                      stadium_scene=scene, FOOD='food', POISON='poison', debug=False)
+        dists = {i: cls.sq_dist_robot(self, p) for i, p in scene.all_items.items()}
+        fr, pr = cls.get_sensor_readings(self, dists)
+        af, ap = cls.get_abs_pos(self, dists)
+        return {'cls': cls.__name__, 'n_bins': n_bins, 'span': span, 'range': srange,
+                'robot_xy': list(map(float, robot_xy)), 'yaw': float(yaw),
+                'food': [food[k][:2] for k in food], 'poison': [poison[k][:2] for k in poison],
+                'sq_dists': [dists[k] for k in scene.all_items], 'food_readings': tolist(fr),
+                'poison_readings': tolist(pr), 'abs_food': tolist(af), 'abs_poison': tolist(ap)}
+
+    sens = [sensor_case(AntGatherBulletEnv, 10, np.pi, 20., 8, 8, (0.3, -0.2), 0.4, np.random.RandomState(0))]
+    for k in range(80):
+        sens.append(sensor_case(AntGatherBulletEnv, 10, np.pi, 20., 8, 8, rng.uniform(-7, 7, 2),
+                                rng.uniform(-np.pi, np.pi), np.random.RandomState(1000 + k)))
+    for k in range(40):
+        sens.append(sensor_case(GatherBulletEnv, 5, np.pi, 20., 8, 8, rng.uniform(-7, 7, 2),
+                                rng.uniform(-np.pi, np.pi), np.random.RandomState(2000 + k)))
+    for k in range(10):
+        sens.append(sensor_case(AntGatherBulletEnv, 7, 2.0, 9.0, 5, 3, rng.uniform(-7, 7, 2),
+                                rng.uniform(-np.pi, np.pi), np.random.RandomState(3000 + k)))
+    G['food_sensor'] = sens
+
+    # ---------------------------------------------------------------- GatherScene spawn / respawn
+    def scene_run(seed, world, n_food, n_poison, spacing, respawn, hits):
+        sc = GatherScene(None, 9.8, 0.0165 / 4, 4, world, n_food, n_poison, spacing, respawn)
+        sc.rs = LoggingRS(seed)
+        sc.loaded = True  # skip plane/wall loading (pybullet calls only)
+        cl = FakeClient()
+        sc._p = cl
+        sc.episode_restart(cl)
+        after_restart = {'food': [sc.food[k] for k in sc.food], 'poison': [sc.poison[k] for k in sc.poison]}
+        n_draws_restart = len(sc.rs.log)
+        events = []
+        for obj_idx, agent in hits:
+            ids = list(sc.food.keys()) + list(sc.poison.keys()) + [999]
+            oid = ids[obj_idx]
+            n0 = len(sc.rs.log)
+            rew = sc.reward_collision(oid, list(agent))
+            pos = sc.all_items.get(oid)
+            events.append({'obj_index': obj_idx, 'agent_xyz': list(map(float, agent)), 'rew': rew,
+                           'new_pos': None if pos is None else list(map(float, pos)),
+                           'draws': sc.rs.log[n0:]})
+        return {'seed': seed, 'world': list(world), 'n_food': n_food, 'n_poison': n_poison, 'spacing': spacing,
+                'respawn': respawn, 'restart_draws': sc.rs.log[:n_draws_restart], 'after_restart': after_restart,
+                'events': events}
+
+    hits = [(0, (1, 1, .5)), (8, (1, 1, .5)), (16, (0, 0, .5)), (3, (6.5, 6.5, .5)), (12, (-6.9, 6.9, .5)),
+            (0, (0.2, -0.1, .5)), (5, (-3, 2, .5))]
+    G['gather_scene'] = [scene_run(123, (15, 15), 8, 8, 2.0, True, hits),
+                         scene_run(7, (15, 15), 8, 8, 2.0, True, hits),
+                         scene_run(99, (15, 15), 8, 8, 2.0, False, hits),
+                         scene_run(5, (9, 11), 4, 6, 3.0, True, [(0, (0, 0, .5)), (4, (2, 2, .5)), (9, (-3, 1, .5))])]
+
+    # ---------------------------------------------------------------- AntGather / Gather(Point) full step (task half)
+    def gather_step_case(cls, k, force=None):
+        lrs = np.random.RandomState(5000 + k)
+        n_bins = 10 if cls is AntGatherBulletEnv else 5
+        sc = GatherScene(None, 9.8, 0.0165 / 4, 4, (15, 15), 8, 8, 2.0, True)
+        sc.rs = LoggingRS(6000 + k)
+        sc.loaded = True
+        cl = FakeClient()
+        sc._p = cl
+        sc.episode_restart(cl)
+        n_restart = len(sc.rs.log)
+        items0 = [list(sc.all_items[i]) for i in sc.all_items]
+        # robot placed near a random item so pickups happen often
+        ids = list(sc.all_items.keys())
+        if force == 'far':
+            xy = np.array([0.0, 0.0])
+        else:
+            tgt = sc.all_items[ids[lrs.randint(0, 16)]]
+            xy = np.array(tgt[:2]) + lrs.uniform(-0.9, 0.9, 2)
+        z = 0.2 if force == 'dead' else lrs.uniform(0.3, 0.9)
+        rpy = [lrs.uniform(-.3, .3), lrs.uniform(-.3, .3), lrs.uniform(-np.pi, np.pi)]
+        body = Body([xy[0], xy[1], z], rpy)
+        nstate = 28 if cls is AntGatherBulletEnv else 8
+        st = lrs.uniform(-1, 1, nstate)
+        initial_z = 0.75 if cls is AntGatherBulletEnv else 1.0
+        st[0] = z - initial_z
+        if force == 'nan':
+            st[5] = np.nan
+        st = st.astype(np.float32)
+        if cls is AntGatherBulletEnv:
+            robot = NS(apply_action=lambda a: None, calc_state=lambda: st.copy(), initial_z=initial_z,
+                       body_rpy=rpy, alive_bonus=lambda zz, p: +1 if zz > 0.26 else -1)
+            self = cls.__new__(cls)
+            self.__dict__.update(dict(robot=robot, scene=NS(global_step=lambda: None), stadium_scene=sc,
+                                      parts={'torso': body}, robot_body=body, robot_coll_dist=1, use_sensor=True,
+                                      n_bins=n_bins, sensor_span=np.pi, sensor_range=20., dying_cost=-10,
+                                      debug=False, _p=cl))
+        else:
+            robot = NS(apply_action=lambda a: None, calc_state=lambda: st.copy(), initial_z=initial_z,
+                       robot_body=body, alive_bonus=lambda zz, p: 1)
+            self = cls.__new__(cls)
+            self.__dict__.update(dict(robot=robot, scene=NS(global_step=lambda: None), stadium_scene=sc,
+                                      robot_coll_dist=1, use_sensor=True, n_bins=n_bins, sensor_span=np.pi,
+                                      sensor_range=20., dying_cost=-10, debug=False, _p=cl))
+        obs, rew, done, info = cls.step(self, np.zeros(8))
+        return {'cls': cls.__name__, 'n_bins': n_bins, 'state_in': st.astype(float).tolist(), 'initial_z': initial_z,
+                'torso_xyz': [float(xy[0]), float(xy[1]), float(z)], 'rpy': list(map(float, rpy)),
+                'items_before': [p[:2] for p in items0], 'respawn_draws': sc.rs.log[n_restart:],
+                'items_after': [list(sc.all_items[i])[:2] for i in sc.all_items],
+                'obs': tolist(obs), 'rew': float(rew), 'done': bool(done), 'food_rew': float(info['food_rew']),
+                'dead_rew': float(info['dead_rew'])}
+
+    gs = []
+    for k in range(60):
+        gs.append(gather_step_case(AntGatherBulletEnv, k))
+    gs.append(gather_step_case(AntGatherBulletEnv, 100, 'dead'))
+    gs.append(gather_step_case(AntGatherBulletEnv, 101, 'nan'))
+    gs.append(gather_step_case(AntGatherBulletEnv, 102, 'far'))
+    for k in range(30):
+        gs.append(gather_step_case(GatherBulletEnv, 200 + k))
+    gs.append(gather_step_case(GatherBulletEnv, 300, 'nan'))
+    G['gather_step'] = gs
+
+    # ---------------------------------------------------------------- maze: target obs + full step (task half)
+    def maze_case(k, encoding, sense_target=False, force_target=None, near=False):
+        lrs = np.random.RandomState(7000 + k)
+        xy = np.array([lrs.uniform(-4.5, 4.5), lrs.uniform(-8.5, 8.5)])
+        rpy = [lrs.uniform(-.2, .2), lrs.uniform(-.2, .2), lrs.uniform(-np.pi, np.pi)]
+        body = Body([xy[0], xy[1], 0.45], rpy)
+        targets = ([2, -3], [2, 0], [2, 3], [-2, 4])
+        target = np.array(targets[lrs.randint(0, 4)] if force_target is None else force_target)
+        if near:  # put the robot next to its target -> sparse-reward / done branch
+            xy = target + lrs.uniform(-1.0, 1.0, 2)
+            body = Body([xy[0], xy[1], 0.45], rpy)
+        ant_obs = lrs.uniform(-1, 1, 28).astype(np.float32)
+        inner_rew = float(lrs.uniform(-1, 1))
+        centroid = xy + lrs.uniform(-0.3, 0.3, 2)
+        wtd = float(np.linalg.norm(target - centroid))
+        self = AntMazeBulletEnv.__new__(AntMazeBulletEnv)
+        self.__dict__.update(dict(
+            n_bins=10, sensor_range=5.0, sensor_span=2 * np.pi, targets=targets, sense_walls=True,
+            sense_target=sense_target, done_at_target=True, max_steps=-1, t=int(lrs.randint(0, 50)), tol=1.5,
+            inner_rew_weight=0, targ_dist_rew=False, target_encoding=PositionEncoding(encoding), target=target,
+            debug=0, scene=maze, robot=NS(body_real_xyz=[xy[0], xy[1], 0.45], walk_target_dist=wtd),
+            robot_body=body, _super_step_result=(ant_obs, inner_rew, False, {})))
+        obs, rew, d, _ = AntMazeBulletEnv.step(self, np.zeros(8))
+        tv = AntMazeBulletEnv.get_target_vec_obs(self)
+        ts = AntMazeBulletEnv.get_target_sensor_obs(self)
+        return {'encoding': encoding, 'sense_target': sense_target, 'torso_xy': xy.tolist(), 'rpy': list(map(float, rpy)),
+                'target': target.tolist(), 'ant_obs': ant_obs.astype(float).tolist(), 'inner_rew': inner_rew,
+                'walk_target_dist': wtd, 'obs': tolist(obs), 'rew': float(rew), 'done': bool(d),
+                'target_vec_obs': tolist(tv), 'target_sensor_obs': tolist(ts)}
+
+    mz = [maze_case(k, 0) for k in range(40)] + [maze_case(100 + k, 1) for k in range(15)] + \
+        [maze_case(200 + k, 0, sense_target=True) for k in range(25)]
+    # robot close to the target -> sparse reward branch
+    for k in range(12):
+        c = maze_case(300 + k, 0, near=True)
+        mz.append(c)
+    G['maze_step'] = mz
+    # SURVEY Appendix D spot values
+    body = Body([0.3, -0.2, 0.5], [0, 0, 0.4])
+    s0 = NS(target=np.array([-2, 4]), robot_body=body, target_encoding=PositionEncoding.normed_vec)
+    s1 = NS(target=np.array([-2, 4]), robot_body=body, target_encoding=PositionEncoding.angle)
+    G['target_vec_spot'] = {'normed': tolist(AntMazeBulletEnv.get_target_vec_obs(s0)),
+                            'angle': tolist(AntMazeBulletEnv.get_target_vec_obs(s1))}
+
+    # ---------------------------------------------------------------- PointBot.calc_state
+    pb = []
+    spot = NS(robot_body=Body([0.3, -0.2, 0.6], [0.05, -0.1, 0.4], [1, 2, -0.5]), walk_target_x=0, walk_target_y=0,
+              initial_z=1)
+    pb.append({'xyz': [0.3, -0.2, 0.6], 'rpy': [0.05, -0.1, 0.4], 'speed': [1, 2, -0.5], 'target': [0, 0],
+               'out': PointBot.calc_state(spot).astype(float).tolist()})
+    for _ in range(30):
+        xyz = rng.uniform(-7, 7, 3).tolist()
+        rpy = rng.uniform(-np.pi, np.pi, 3).tolist()
+        sp = rng.uniform(-5, 5, 3).tolist()
+        s = NS(robot_body=Body(xyz, rpy, sp), walk_target_x=0, walk_target_y=0, initial_z=1)
+        pb.append({'xyz': xyz, 'rpy': rpy, 'speed': sp, 'target': [0, 0],
+                   'out': PointBot.calc_state(s).astype(float).tolist()})
+    G['pointbot_state'] = pb
+
+    # ---------------------------------------------------------------- AntMjEnv.step reward assembly (MjAnt.py:36-97)
+    mj = []
+    for k in range(30):
+        lrs = np.random.RandomState(9000 + k)
+        state = lrs.uniform(-1, 1, 29)
+        state[2] = lrs.uniform(0.2, 0.8)
+        if k == 29:
+            state[10] = np.inf
+        initial_z = 0.75
+        pot_old = float(lrs.uniform(-70000, -50000))
+        pot_new = pot_old + float(lrs.uniform(-30, 30))
+        n_lim = int(lrs.randint(0, 5))
+        robot = NS(apply_action=lambda a: None, calc_state=lambda: state.copy(), initial_z=initial_z,
+                   body_rpy=[0, 0.1, 0], calc_potential=lambda: pot_new, feet=[], feet_contact=np.zeros(4),
+                   joints_at_limit=n_lim)
+        robot.alive_bonus = lambda z, pitch: MjAnt.alive_bonus(robot, z, pitch)
+        self = AntMjEnv.__new__(AntMjEnv)
+        self.__dict__.update(dict(robot=robot, scene=NS(global_step=lambda: None), potential=pot_old,
+                                  joints_at_limit_cost=-0.1, ground_ids=set(), reward=0.0))
+        obs, rew, done, _ = AntMjEnv.step(self, np.zeros(8))
+        mj.append({'state': state.tolist(), 'initial_z': initial_z, 'potential_old': pot_old, 'potential_new': pot_new,
+                   'joints_at_limit': n_lim, 'joints_at_limit_cost': -0.1, 'rew': float(rew), 'done': bool(done)})
+    G['antmj_step'] = mj
+
+    for name, val in G.items():
+        with open(os.path.join(OUT_DIR, name + '.json'), 'w') as f:
+            json.dump(val, f, allow_nan=True)
+        print(name, os.path.getsize(os.path.join(OUT_DIR, name + '.json')), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,96 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hrl_pybullet_envs_amd import _capi as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, 'oracle', 'liborc.so')
+        if not os.path.exists(path):
+            subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')])
+        _LIB = C.CDLL(path)
+        _LIB.orc_sq_dist_f64.restype = C.c_double
+        _LIB.orc_sq_dist_f32.restype = C.c_float
+    return _LIB
+
+
+def suffix(dtype):
+    return '_f64' if np.dtype(dtype) == np.float64 else '_f32'
+
+
+def fn(name, dtype=np.float64):
+    return getattr(lib(), name + suffix(dtype))
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def creal(dtype):
+    return C.c_double if np.dtype(dtype) == np.float64 else C.c_float
+
+
+def default_config(kind, **over):
+    cfg = K.hrl_config()
+    lib().orc_default_config(C.c_int32(kind), C.byref(cfg))
+    for k, v in over.items():
+        if k.startswith('model_'):
+            setattr(cfg.model, k[6:], v)
+        elif k == 'world_size':
+            cfg.world_size[0], cfg.world_size[1] = v
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def obs_dim(cfg):
+    return lib().orc_obs_dim(C.byref(cfg))
+
+
+def act_dim(cfg):
+    return lib().orc_act_dim(C.byref(cfg))
+
+
+class OracleEnv:
+    """Batched env on host numpy buffers with the device buffer layout (include/hrl_envs.h)."""
+
+    def __init__(self, cfg, dtype=np.float32):
+        self.cfg, self.dtype = cfg, np.dtype(dtype)
+        n = cfg.num_envs
+        self.N, self.od, self.ad = n, obs_dim(cfg), act_dim(cfg)
+        self.state = np.zeros((n, K.HRL_STATE_STRIDE), self.dtype)
+        self.items = np.zeros((n, K.HRL_ITEMS_STRIDE), self.dtype)
+        self.aux = np.zeros((n, K.HRL_AUX_STRIDE), np.int32)
+        self.obs = np.zeros((n, self.od), self.dtype)
+        self.rew = np.zeros(n, self.dtype)
+        self.done = np.zeros(n, np.uint8)
+        self.info = np.zeros((n, K.HRL_INFO_STRIDE), self.dtype)
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        fn('orc_reset_batch', self.dtype)(C.byref(self.cfg), ptr(self.state), ptr(self.items), ptr(self.aux), ptr(m),
+                                          ptr(self.obs))
+        return self.obs
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, self.dtype).reshape(self.N, self.ad)
+        fn('orc_step_batch', self.dtype)(C.byref(self.cfg), ptr(self.state), ptr(self.items), ptr(self.aux), ptr(a),
+                                         ptr(self.obs), ptr(self.rew), ptr(self.done), ptr(self.info))
+        return self.obs, self.rew, self.done, self.info
+
+    @property
+    def qpos(self):
+        return self.state[:, :15]
+
+    @property
+    def qvel(self):
+        return self.state[:, 15:29]
