@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched AntGather step on N MI355X (BASELINE.json metric).
+
+A "step" is one hrl_step() over the shard's envs: one HIP kernel launch that advances every env by one env step
+(4 physics substeps + observation/reward).  Workload at N=1: AntGatherBulletEnv-v0, 4096 envs (BASELINE.json
+configs[2], the config the metric is quoted on); weak scaling: every rank owns 4096 envs, RNG keyed by global id.
+Inputs (state, items, pre-generated U(-1,1) actions) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--kind gather|flat|maze|point]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hrl_pybullet_envs_amd import _capi as K  # noqa: E402
+from hrl_pybullet_envs_amd import _lib  # noqa: E402
+from hrl_pybullet_envs_amd.dist import ReturnGatherer, init_distributed  # noqa: E402
+from hrl_pybullet_envs_amd.vec_env import BatchedEnv  # noqa: E402
+
+KINDS = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER}
+NAMES = {'flat': 'AntMjEnv (flat ground)', 'gather': 'AntGatherBulletEnv-v0', 'maze': 'AntMazeBulletEnv-v0',
+         'point': 'PointGatherBulletEnv-v0'}
+# algorithmic HBM bytes per env-step, fp32, state read once + written once (SURVEY.md 8d / BASELINE.md 4)
+ALG_BYTES = {'gather': 581, 'flat': 385, 'maze': 429, 'point': 317}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(kind, seconds_budget=15.0):
+    """Times the CPU oracle (a port: the pybullet reference is not installable here) on ONE host core, N = 1 env,
+    the like-for-like of the reference's single-process loop (README.md:29-34).  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import orc
+    L = orc.lib()
+    L.orc_bench_f32.restype = C.c_double
+    cfg = orc.default_config(KINDS[kind], num_envs=1, seed=0, auto_reset=1)
+    cs = C.c_double()
+    dt = L.orc_bench_f32(C.byref(cfg), 2000, 1, C.byref(cs))  # calibrate
+    steps = max(2000, int(2000 / dt * seconds_budget))
+    dt = L.orc_bench_f32(C.byref(cfg), steps, 1, C.byref(cs))
+    out = {'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+           'sample': f'CPU oracle (oracle/liborc.so, fp32), {NAMES[kind]}, 1 env x {steps} random-action steps, '
+                     f'1 thread, {dt:.1f} s'}
+    ncpu = os.cpu_count() or 1
+    cfg_n = orc.default_config(KINDS[kind], num_envs=4096, seed=0, auto_reset=1)
+    dtn = L.orc_bench_f32(C.byref(cfg_n), 4, ncpu, C.byref(cs))
+    nsteps = max(4, int(4 / dtn * 5.0))
+    dtn = L.orc_bench_f32(C.byref(cfg_n), nsteps, ncpu, C.byref(cs))
+    out['all_cores'] = {'value': 4096 * nsteps / dtn, 'cores': ncpu,
+                        'sample': f'same oracle, 4096 envs x {nsteps} steps, OpenMP over {ncpu} threads, {dtn:.1f} s'}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
+    ap.add_argument('--kind', default='gather', choices=sorted(KINDS))
+    ap.add_argument('--gather-every', type=int, default=100, help='all-gather episode returns every K steps (N>1)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local_rank = init_distributed(args.gpus)
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    n = args.envs
+    cfg = _lib.default_config(KINDS[args.kind], num_envs=n, seed=0, auto_reset=1, env_id_offset=rank * n)
+    env = BatchedEnv(cfg, dev)
+    env.reset()
+    # pre-generated actions, resident in HBM: [T, N, A] ~ U(-1, 1), seed 0 (+rank)
+    T = 256
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    actions = torch.rand(T, n, env.act_dim, device=dev, generator=gen) * 2 - 1
+    gatherer = ReturnGatherer(env, world) if world > 1 else None
+
+    def run(k0, k):
+        for t in range(k0, k0 + k):
+            env.step(actions[t % T])
+            if gatherer is not None and (t + 1) % args.gather_every == 0:
+                gatherer.launch()
+
+    run(0, args.warmup)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # the kernels are launched on torch's current stream, which is where these events are recorded
+    run(args.warmup, args.steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([wall], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        wall = float(tt.item())
+    assert bool(torch.isfinite(env.state).all()), 'non-finite state after the timed region'
+
+    if rank == 0:
+        total_steps = world * n * args.steps
+        launch_s = dev_ms / 1e3 / args.steps  # one kernel per step: HIP-event time / launches
+        achieved = ALG_BYTES[args.kind] * n / launch_s / 1e9
+        out = {
+            'metric': 'env-steps/sec, AntGatherBulletEnv-v0 @4096 envs, 1/2/4/8 MI355X' if args.kind == 'gather' and n == 4096
+            else f'env-steps/sec, {NAMES[args.kind]} @{n} envs/GPU',
+            'value': total_steps / wall, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{NAMES[args.kind]}, {n} envs per GPU, U(-1,1) actions pre-generated on device, auto-reset, '
+                                   f'max_episode_steps 2000', 'envs_per_gpu': n, 'global_envs': world * n,
+                       'substeps_per_step': 4, 'parallelism': f'env-sharded x{world}, no data-path collective; '
+                                                              f'RCCL all-gather of episode returns every {args.gather_every} steps'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel': 'k_step', 'kernel_avg_us': launch_s * 1e6,
+                         'algorithmic_bytes_per_launch': ALG_BYTES[args.kind] * n,
+                         'note': 'latency/VALU-bound by construction (~1.4e5 flop per env-step, ~240 flop/B): see DESIGN.md 5'},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.kind)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,66 @@
+"""Loader of the HIP C-ABI library (include/hrl_envs.h).  There is no CPU fallback: a missing library or a
+missing GPU is an error."""
+import ctypes as C
+import os
+
+from . import _capi as K
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libhrl_envs_hip.so')
+_lib = None
+
+# every symbol include/hrl_envs.h declares
+SYMBOLS = ['hrl_default_config', 'hrl_obs_dim', 'hrl_act_dim', 'hrl_create', 'hrl_destroy', 'hrl_reset', 'hrl_step',
+           'hrl_get_state', 'hrl_set_state', 'hrl_last_error', 'hrl_backend']
+
+
+class HrlError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HrlError(f'{LIB_PATH} is missing: build it with `python -m hrl_pybullet_envs_amd.build` '
+                           '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+        L = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(L, s)  # AttributeError if the library does not export the ABI
+        L.hrl_last_error.restype = C.c_char_p
+        L.hrl_backend.restype = C.c_char_p
+        L.hrl_create.argtypes = [C.POINTER(K.hrl_config), C.POINTER(C.c_void_p)]
+        L.hrl_destroy.argtypes = [C.c_void_p]
+        L.hrl_reset.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p]
+        L.hrl_step.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p]
+        L.hrl_get_state.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hrl_set_state.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hrl_default_config.argtypes = [C.c_int32, C.POINTER(K.hrl_config)]
+        L.hrl_obs_dim.argtypes = [C.POINTER(K.hrl_config)]
+        L.hrl_act_dim.argtypes = [C.POINTER(K.hrl_config)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != K.HRL_OK:
+        raise HrlError(f'hrl error {rc}: {lib().hrl_last_error().decode()}')
+
+
+def default_config(kind, **over):
+    cfg = K.hrl_config()
+    check(lib().hrl_default_config(kind, C.byref(cfg)))
+    for k, v in over.items():
+        if k.startswith('model_'):
+            setattr(cfg.model, k[6:], v)
+        elif k in ('world_size', 'start_pos', 'walk_target', 'centroid_static_sum'):
+            arr = getattr(cfg, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        elif k == 'targets':
+            cfg.n_targets = len(v)
+            for i, t in enumerate(v):
+                cfg.targets[i][0], cfg.targets[i][1] = float(t[0]), float(t[1])
+        else:
+            setattr(cfg, k, v)
+    return cfg

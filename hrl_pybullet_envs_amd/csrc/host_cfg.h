@@ -1,0 +1,157 @@
+/*
+ * host_cfg.h -- host side of the C-ABI that does not touch the GPU: reference constructor defaults,
+ * observation/action widths, argument validation and the derivation of the kernel constants (DevCfg).
+ */
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/hrl_envs.h"
+#include "step_core.h"
+
+namespace hrl {
+
+/* reference constructor defaults: ant_gather_env.py:16-29, point_gather_env.py:8-21,
+ * ant_maze_bullet_env.py:13-27, MjAnt.py:31-34; scene constants ant_gather_env.py:58 */
+inline int default_config(int32_t kind, hrl_config *c) {
+    if (!c || kind < HRL_ANT_FLAT || kind > HRL_POINT_GATHER) return HRL_ERR_BAD_ARG;
+    memset(c, 0, sizeof(*c));
+    c->abi_version = HRL_ABI_VERSION;
+    c->env_kind = kind;
+    c->num_envs = 1;
+    c->max_episode_steps = 2000; /* hrl_pybullet_envs/__init__.py:15 */
+    c->n_food = 8; c->n_poison = 8;
+    c->n_bins = kind == HRL_POINT_GATHER ? 5 : 10;
+    c->use_sensor = 1; c->respawn = 1;
+    c->world_size[0] = 15.f; c->world_size[1] = 15.f;
+    c->sensor_range = 20.f;
+    c->sensor_span = 3.14159265358979323846f;
+    c->robot_coll_dist = 1.f; c->robot_object_spacing = 2.f; c->dying_cost = -10.f;
+    c->centroid_n_static = 2; c->centroid_static_sum[0] = -7.5f; /* floor (0,0) + last wall (-size_x/2, 0) */
+    hrl_model &m = c->model;
+    m.gravity = 9.8f; m.timestep = 0.0165f / 4; m.frame_skip = 4; /* ant_gather_env.py:58 */
+    m.solver_iters = 5; m.density = 1000.f; m.torque_scale = 250.f;
+    m.contact_erp = 0.9f; m.limit_erp = 0.2f;
+    m.friction_ground = 0.8f;                                 /* sizeable_enclosed_scene.py:60 */
+    m.friction_robot = kind == HRL_POINT_GATHER ? 0.1f : 1.5f; /* player_cube.xml:8, ant.xml:9 */
+    m.contact_dist = 0.02f; m.limit_margin = 0.25f; m.max_joint_vel = 100.f; m.limit_max_impulse = 100.f;
+    m.ground_z = 0.005f;  /* plane.xml:19 */
+    m.point_force = 500.f; /* point_bot.py:29 */
+    if (kind == HRL_ANT_MAZE) {
+        static const float t[4][2] = {{2, -3}, {2, 0}, {2, 3}, {-2, 4}}; /* ant_maze_bullet_env.py:13-14 */
+        c->sensor_range = 5.f; c->sensor_span = 6.28318530717958647692f; c->n_targets = 4;
+        for (int i = 0; i < 4; ++i) { c->targets[i][0] = t[i][0]; c->targets[i][1] = t[i][1]; }
+        c->sense_walls = 1; c->done_at_target = 1; c->max_steps = -1; c->tol = 1.5f;
+        c->start_pos[0] = -2.f; c->start_pos[1] = -5.f; c->start_pos[2] = 0.25f; /* :27 */
+        c->centroid_n_static = 3; c->centroid_static_sum[0] = -7.f; /* floor + wall (-5,0) + obstacle (-2,0) */
+    }
+    if (kind == HRL_ANT_FLAT) {
+        c->walk_target[0] = 1000.f; c->centroid_n_static = 0; c->centroid_static_sum[0] = 0.f; m.ground_z = 0.f;
+    }
+    return HRL_OK;
+}
+
+inline int obs_dim(const hrl_config *c) {
+    const int nfo = c->use_sensor ? 2 * c->n_bins
+                                  : 2 * ((c->n_food < c->n_bins ? c->n_food : c->n_bins) + (c->n_poison < c->n_bins ? c->n_poison : c->n_bins));
+    switch (c->env_kind) {
+        case HRL_ANT_FLAT: return 29;                /* MjAnt.py:15 */
+        case HRL_ANT_GATHER: return 28 - 2 + nfo;    /* ant_gather_env.py:53-55 */
+        case HRL_POINT_GATHER: return 8 + nfo;       /* gather_base.py:53-55, point_bot.py:16 */
+        case HRL_ANT_MAZE: return 28 - 2 + (c->sense_walls ? c->n_bins : 0) + (c->sense_target ? c->n_bins : 2); /* ant_maze_bullet_env.py:54-57 */
+    }
+    return -1;
+}
+inline int act_dim(const hrl_config *c) { return c->env_kind == HRL_POINT_GATHER ? 2 : 8; }
+
+/* returns "" when the config is usable, else the reason */
+inline std::string validate(const hrl_config *c) {
+    char buf[256];
+    if (!c) return "null config";
+    if (c->abi_version != HRL_ABI_VERSION) return "abi_version mismatch";
+    if (c->env_kind < HRL_ANT_FLAT || c->env_kind > HRL_POINT_GATHER) return "unknown env_kind";
+    if (c->num_envs <= 0) return "num_envs must be positive";
+    const bool gather = c->env_kind == HRL_ANT_GATHER || c->env_kind == HRL_POINT_GATHER;
+    if (gather) {
+        if (c->n_food < 0 || c->n_poison < 0 || c->n_food + c->n_poison > HRL_MAX_ITEMS) return "n_food + n_poison must be within 0..16";
+        if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
+        if (!c->use_sensor) return "use_sensor=False (absolute item positions, ant_gather_env.py:179-196) is not implemented on the device path";
+        if (!(c->robot_coll_dist > 0)) return "robot_coll_dist <= 0 (contact based pickup, ant_gather_env.py:113-116) is not implemented";
+        if (!(c->world_size[0] > 1 && c->world_size[1] > 1 && c->world_size[0] < 50 && c->world_size[1] < 50)) return "world_size must be within (1, 50)";
+        if (!(c->sensor_range > 0) || !(c->sensor_span > 0)) return "sensor_range and sensor_span must be positive";
+    }
+    if (c->env_kind == HRL_ANT_MAZE) {
+        if (c->n_targets < 1 || c->n_targets > HRL_MAX_TARGETS) return "n_targets must be within 1..8";
+        if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
+        if (c->target_encoding != 0 && c->target_encoding != 1) return "target_encoding must be 0 (normed_vec) or 1 (angle)"; /* utils.py:66-68 */
+        if (!c->sense_walls && !(c->sensor_span > 0)) return "sensor_span must be positive";
+        if (!(c->sensor_range > 0)) return "sensor_range must be positive";
+    }
+    if (obs_dim(c) > 64) { snprintf(buf, sizeof buf, "observation width %d exceeds 64", obs_dim(c)); return buf; }
+    const hrl_model &m = c->model;
+    if (!(m.timestep > 0) || m.frame_skip < 1 || m.frame_skip > 64 || m.solver_iters < 1 || m.solver_iters > 64) return "bad timestep / frame_skip / solver_iters";
+    if (!(m.density > 0)) return "density must be positive";
+    return "";
+}
+
+/* kernel constants; the mass model is computed in double and rounded once to fp32 */
+inline void build_devcfg(const hrl_config &c, DevCfg &d) {
+    memset(&d, 0, sizeof(d));
+    d.kind = c.env_kind; d.n_envs = c.num_envs; d.max_episode_steps = c.max_episode_steps; d.auto_reset = c.auto_reset;
+    d.env_id_offset = c.env_id_offset; d.seed_lo = (unsigned)c.seed; d.seed_hi = (unsigned)(c.seed >> 32);
+    d.n_food = c.n_food; d.n_poison = c.n_poison; d.n_bins = c.n_bins; d.use_sensor = c.use_sensor; d.respawn = c.respawn;
+    d.world_sx = c.world_size[0]; d.world_sy = c.world_size[1];
+    d.sensor_range = c.sensor_range; d.sensor_span = c.sensor_span; d.coll_dist = c.robot_coll_dist;
+    d.spacing = c.robot_object_spacing; d.dying_cost = c.dying_cost;
+    d.target_encoding = c.target_encoding; d.sense_target = c.sense_target; d.sense_walls = c.sense_walls;
+    d.done_at_target = c.done_at_target; d.max_steps = c.max_steps; d.targ_dist_rew = c.targ_dist_rew; d.n_targets = c.n_targets;
+    d.tol = c.tol; d.inner_rew_weight = c.inner_rew_weight;
+    for (int i = 0; i < HRL_MAX_TARGETS; ++i) { d.targets[i][0] = c.targets[i][0]; d.targets[i][1] = c.targets[i][1]; }
+    for (int k = 0; k < 3; ++k) d.start_pos[k] = c.start_pos[k];
+    d.centroid_n_static = c.centroid_n_static; d.centroid_sx = c.centroid_static_sum[0]; d.centroid_sy = c.centroid_static_sum[1];
+    d.walk_tx = c.walk_target[0]; d.walk_ty = c.walk_target[1];
+    d.span_is_2pi = c.sensor_span == 6.28318530717958647692f; /* sizeable_enclosed_scene.py:68 `s_span == 2*pi` */
+    const hrl_model &m = c.model;
+    d.h = m.timestep; d.g = m.gravity; d.erp_c = m.contact_erp; d.erp_l = m.limit_erp;
+    d.mu = m.friction_ground * m.friction_robot; d.cdist = m.contact_dist; d.lmargin = m.limit_margin;
+    d.vmax = m.max_joint_vel; d.limp_max = m.limit_max_impulse; d.ground_z = m.ground_z;
+    d.torque_scale = m.torque_scale; d.point_force = m.point_force;
+    d.iters = m.solver_iters; d.nsub = m.frame_skip;
+    d.dt = d.h * (float)d.nsub;
+    /* Ant bodies (assets/ant.xml:12-58): torso sphere r .25; capsules r .08 of length |(.2,.2)| and |(.4,.4)| */
+    const double pi = 3.14159265358979323846, s2 = 1.41421356237309504880;
+    const double rho = m.density, rt = 0.25, rc = 0.08, Ls[2] = {0.2 * s2, 0.4 * s2};
+    const double msph = rho * 4.0 / 3.0 * pi * rt * rt * rt, Isph = 0.4 * msph * rt * rt;
+    double mk[2], Ia[2], It[2];
+    for (int k = 0; k < 2; ++k) {
+        const double mc = rho * pi * rc * rc * Ls[k], ms = rho * 4.0 / 3.0 * pi * rc * rc * rc, L = Ls[k];
+        mk[k] = mc + ms;
+        Ia[k] = mc * rc * rc / 2 + ms * 0.4 * rc * rc;
+        It[k] = mc * (L * L / 12 + rc * rc / 4) + ms * (0.4 * rc * rc + L * L / 4 + 3 * L * rc / 8);
+    }
+    const double cl = Ls[0] / 2, common = Isph + 4 * (It[0] + mk[0] * cl * cl), dz = Ia[0] - It[0] - mk[0] * cl * cl;
+    d.m0 = (float)(msph + 4 * mk[0]); d.a0 = (float)(common + 2 * dz); d.b0 = (float)(common - (common + 2 * dz));
+    d.m1 = (float)mk[0]; d.a1 = (float)It[0]; d.b1 = (float)(Ia[0] - It[0]);
+    d.m2 = (float)mk[1]; d.a2 = (float)It[1]; d.b2 = (float)(Ia[1] - It[1]);
+    d.L1 = (float)Ls[0]; d.L2 = (float)Ls[1]; d.r_torso = (float)rt; d.r_caps = (float)rc;
+    const double lo[NJ] = {-40, 30, -40, -100, -40, -100, -40, 30}, hi[NJ] = {40, 100, 40, -30, 40, -30, 40, 100}; /* ant.xml:18-54 */
+    const double d2r = pi / 180.0;
+    for (int j = 0; j < NJ; ++j) { d.jlo[j] = (float)(lo[j] * d2r); d.jhi[j] = (float)(hi[j] * d2r); }
+    /* static world: walls 0.1 thick centred on +-size/2 (sizeable_enclosed_scene.py:46-57, wall.xml:19); maze box (box.xml:19) */
+    float hx = 0.f, hy = 0.f;
+    if (c.env_kind == HRL_ANT_GATHER || c.env_kind == HRL_POINT_GATHER) { hx = c.world_size[0] / 2; hy = c.world_size[1] / 2; }
+    if (c.env_kind == HRL_ANT_MAZE) { hx = 5.f; hy = 9.f; } /* maze_scene.py:10 */
+    if (hx > 0.f) {
+        const float t = 0.05f, n[4][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}};
+        const float dd[4] = {-(hx - t), -(hx - t), -(hy - t), -(hy - t)};
+        d.n_planes = 4;
+        for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) d.plane_n[i][k] = n[i][k]; d.plane_d[i] = dd[i]; }
+    }
+    if (c.env_kind == HRL_ANT_MAZE) { d.n_boxes = 1; d.box_lo[0] = -5; d.box_lo[1] = -2; d.box_lo[2] = 0; d.box_hi[0] = 1; d.box_hi[1] = 2; d.box_hi[2] = 2; }
+    d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
+}
+
+}  // namespace hrl

@@ -1,0 +1,176 @@
+/*
+ * hrl_hip.hip -- gfx950 (MI355X) implementation of include/hrl_envs.h.
+ *
+ * One 64-thread workgroup = one wavefront = one environment.  The wave runs the phases of step_core.h with
+ *   - per-wave state staged in LDS (WaveLds < 10 KB and <= 128 VGPRs -> 16 waves per CU, 4 per SIMD),
+ *   - coalesced 128-byte loads/stores of the packed state / item records (lane i <-> float i of the record),
+ *   - a DPP row-rotate butterfly for the 16-lane J.u reductions of the contact/limit solver (no LDS, no barrier),
+ *   - ballot + mbcnt for compacting active contacts / limits into solver rows.
+ * There is no cross-workgroup communication, so no XCD-aware block remap is needed: blockIdx.x = env index and the
+ * dispatcher's round-robin over the 8 XCDs spreads the envs evenly.
+ */
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "host_cfg.h"
+
+using namespace hrl;
+
+namespace {
+
+thread_local std::string g_err;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+/* butterfly over a 16-lane DPP row: pairs at distance 8, 4, 2, 1 -- every lane ends with the same bits */
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v); /* row_ror:8 */
+    v += dpp_mov<0x124>(v); /* row_ror:4 */
+    v += dpp_mov<0x122>(v); /* row_ror:2 */
+    v += dpp_mov<0x121>(v); /* row_ror:1 */
+    return v;
+}
+
+struct GpuExec {
+    WaveLds &L;
+    LaneRegs r;
+    int lane;
+    __device__ __forceinline__ WaveLds &lds() { return L; }
+    __device__ __forceinline__ LaneRegs &reg(int) { return r; }
+    __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    template <class F>
+    __device__ __forceinline__ void each(F f) {
+        f(lane);
+        __syncthreads();
+    }
+    template <class P, class W, class Q>
+    __device__ __forceinline__ int each_compact(P pred, W write, Q post) {
+        auto h = pred(lane);
+        const unsigned long long m = __ballot(h.ok);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (h.ok) write(lane, rank, h);
+        post(lane, h);
+        __syncthreads();
+        return __popcll(m);
+    }
+    template <class P, class C>
+    __device__ __forceinline__ void each_reduce16(P produce, C consume) {
+        const float v = row16_sum(produce(lane));
+        consume(lane, v);
+    }
+};
+
+__global__ __launch_bounds__(64, 4) void k_step(DevBufs b, DevCfg c) {
+    __shared__ WaveLds L;
+    GpuExec x{L, {0.f, 0.f}, (int)threadIdx.x};
+    step_entry(x, b, c, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, DevCfg c) {
+    __shared__ WaveLds L;
+    GpuExec x{L, {0.f, 0.f}, (int)threadIdx.x};
+    reset_entry(x, b, c, (int)blockIdx.x);
+}
+/* packed record <-> split qpos[N][15], qvel[N][14] */
+__global__ void k_get_state(const float *state, float *qpos, float *qvel, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, e = i >> 5, k = i & 31;
+    if (e >= n) return;
+    const float v = state[i];
+    if (k < 15) qpos[e * 15 + k] = v;
+    else if (k < 29) qvel[e * 14 + (k - 15)] = v;
+}
+__global__ void k_set_state(float *state, const float *qpos, const float *qvel, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, e = i >> 5, k = i & 31;
+    if (e >= n) return;
+    if (k < 15) state[i] = qpos[e * 15 + k];
+    else if (k < 29) state[i] = qvel[e * 14 + (k - 15)];
+}
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) { return fail(HRL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+
+DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
+    DevBufs d;
+    d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
+    d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask;
+    return d;
+}
+
+}  // namespace
+
+struct hrl_handle {
+    hrl_config cfg;
+    DevCfg dc;
+};
+
+extern "C" {
+
+int hrl_default_config(int32_t env_kind, hrl_config *cfg) {
+    const int rc = default_config(env_kind, cfg);
+    return rc == HRL_OK ? rc : fail(rc, "hrl_default_config: bad env_kind or null cfg");
+}
+int hrl_obs_dim(const hrl_config *cfg) { return cfg ? obs_dim(cfg) : -1; }
+int hrl_act_dim(const hrl_config *cfg) { return cfg ? act_dim(cfg) : -1; }
+
+int hrl_create(const hrl_config *cfg, hrl_handle **out) {
+    if (!out) return fail(HRL_ERR_BAD_ARG, "hrl_create: null out");
+    *out = nullptr;
+    const std::string why = validate(cfg);
+    if (!why.empty()) return fail(HRL_ERR_BAD_ARG, "hrl_create: " + why);
+    int ndev = 0;
+    const hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(HRL_ERR_NO_DEVICE, "hrl_create: no HIP device (this library has no CPU path)");
+    hrl_handle *h = new hrl_handle;
+    h->cfg = *cfg;
+    build_devcfg(*cfg, h->dc);
+    *out = h;
+    return HRL_OK;
+}
+int hrl_destroy(hrl_handle *h) {
+    delete h;
+    return HRL_OK;
+}
+
+int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *stream) {
+    if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_reset: null handle or buffer");
+    const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
+    if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: gather kinds need the items buffer");
+    hipLaunchKernelGGL(k_reset, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), h->dc);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_reset launch");
+}
+
+int hrl_step(hrl_handle *h, const hrl_buffers *b, void *stream) {
+    if (!h || !b || !b->state || !b->aux || !b->obs || !b->actions || !b->reward || !b->done || !b->info)
+        return fail(HRL_ERR_BAD_ARG, "hrl_step: null handle or buffer");
+    const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
+    if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: gather kinds need the items buffer");
+    hipLaunchKernelGGL(k_step, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), h->dc);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_step launch");
+}
+
+int hrl_get_state(hrl_handle *h, const hrl_buffers *b, float *qpos, float *qvel, void *stream) {
+    if (!h || !b || !b->state || !qpos || !qvel) return fail(HRL_ERR_BAD_ARG, "hrl_get_state: null argument");
+    const int n = h->dc.n_envs, total = n * 32;
+    hipLaunchKernelGGL(k_get_state, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->state, qpos, qvel, n);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_get_state launch");
+}
+int hrl_set_state(hrl_handle *h, const hrl_buffers *b, const float *qpos, const float *qvel, void *stream) {
+    if (!h || !b || !b->state || !qpos || !qvel) return fail(HRL_ERR_BAD_ARG, "hrl_set_state: null argument");
+    const int n = h->dc.n_envs, total = n * 32;
+    hipLaunchKernelGGL(k_set_state, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->state, qpos, qvel, n);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_set_state launch");
+}
+
+const char *hrl_last_error(void) { return g_err.c_str(); }
+const char *hrl_backend(void) { return "hip-gfx950"; }
+
+}  // extern "C"

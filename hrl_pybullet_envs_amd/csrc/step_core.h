@@ -1,0 +1,1210 @@
+/*
+ * step_core.h -- one-wavefront-per-environment step of the batched Ant / Point simulator (gfx950).
+ *
+ * This is the product's hot path: everything behind Env.step() of the reference
+ *   robot.apply_action + scene.global_step + robot.calc_state     ant_gather_env.py:77-80 (pybullet, upstream)
+ *   pickups / respawn / food sensor / alive / reward              ant_gather_env.py:84-119, gather_scene.py:52-114
+ *   wall sensor / target obs / sparse reward                      ant_maze_bullet_env.py:63-97,
+ *                                                                 sizeable_enclosed_scene.py:63-97, intersection_utils.py:74-104
+ *   PointBot force + state                                        point_bot.py:28-31,48-67
+ *   raw-state obs + locomotion reward                             MjAnt.py:17-25,36-97
+ * written as a sequence of wave-wide PHASES.  A phase is a function of (lane, LDS); lanes communicate only
+ * through the per-wave LDS record `WaveLds` between phases (plus three wave primitives supplied by the executor:
+ * a 16-lane rotate-add reduction, a ballot/prefix compaction and per-lane persistent registers).  The executor `X`
+ * is the HIP wave (hrl_hip.hip: one 64-thread workgroup = one wavefront = one env, phases separated by a
+ * workgroup barrier); tests/emu provides a lock-step host executor so the same phases can be checked on a box
+ * without a GPU -- that executor is test infrastructure and is never used by the product.
+ *
+ * Lane maps used by the phases:
+ *   leg map : leg = lane >> 4 (four 16-lane rows, one per leg; the 16 lanes of a row compute the same values)
+ *   dof map : dof = lane & 15 (0-2 omega, 3-5 v, 6-13 joint rates, 14-15 zero padding)
+ *   row map : lane = constraint row (limits, contact normals, friction pairs; <= 48 rows)
+ *   item map: lane = food/poison slot (<= 16);  bin map: lane = sensor bin
+ *
+ * Numerics: fp32 throughout.  The algorithm is the build's own specification of the
+ * rigid-body step; oracle/orc_impl.h restates it independently on the CPU and tests compare the two.
+ */
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef HRL_EMU
+#define HRL_DEV inline
+#else
+#define HRL_DEV __device__ __forceinline__
+#endif
+
+namespace hrl {
+
+constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (assets/ant.xml:18-54) */
+constexpr int MAXC = 12;  /* contacts kept per substep */
+constexpr int MAXR = 44;  /* constraint rows per substep: 8 limits + 12 * (normal + 2 friction) */
+constexpr int JBS = 17;   /* row stride of the J/B table in float2 units (16 dofs + 1 pad: spreads rows over LDS banks) */
+
+struct F2 { float x, y; };
+struct alignas(16) F4 { float x, y, z, w; };
+
+/* Everything the kernels need from hrl_config, plus constants derived from it on the host (host_cfg.h). */
+struct DevCfg {
+    int kind, n_envs, max_episode_steps, auto_reset;
+    long long env_id_offset;
+    unsigned seed_lo, seed_hi;
+    int n_food, n_poison, n_bins, use_sensor, respawn;
+    float world_sx, world_sy, sensor_range, sensor_span, coll_dist, spacing, dying_cost;
+    int target_encoding, sense_target, sense_walls, done_at_target, max_steps, targ_dist_rew, n_targets;
+    float tol, inner_rew_weight;
+    float targets[8][2];
+    float start_pos[3];
+    int centroid_n_static;
+    float centroid_sx, centroid_sy, walk_tx, walk_ty;
+    int span_is_2pi;
+    float h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z, torque_scale, point_force, dt;
+    int iters, nsub;
+    float m0, a0, b0, m1, a1, b1, m2, a2, b2, L1, L2, r_torso, r_caps;
+    float jlo[NJ], jhi[NJ];
+    int n_planes;
+    float plane_n[4][3], plane_d[4];
+    int n_boxes;
+    float box_lo[3], box_hi[3];
+    int obs_dim, act_dim;
+};
+
+struct DevBufs {
+    float *state, *items;
+    int32_t *aux;
+    const float *actions;
+    float *obs, *reward;
+    uint8_t *done;
+    float *info;
+    const uint8_t *mask;
+};
+
+/* Per-wave LDS record ("LDS-staged link/joint state").  Two overlays keep it under 10 KB so that 16 waves fit a CU:
+ * the task scratch (observation packing, after the substeps) shares storage with the solver's J/B table, and the
+ * per-leg articulated inertias handed to the base (phase K -> phase B) share storage with the row parameters
+ * (written later, in phase R). */
+struct WaveLds {
+    union {
+        F2 JB[MAXR * JBS];       /* (J[r][d], B[r][d] = (M^-1 J^T)[d]) */
+        struct {
+            float s28[32];       /* upstream 28-vector (WalkerBase.calc_state) */
+            float obs[64];
+            float ibin[16];      /* per item: sensor bin (as float, -1 = none) */
+            float iint[16];      /* per item: intensity */
+            float irew[16];      /* per item: pickup reward */
+            float red[16];
+            int flags[4];        /* 0: non-finite obs seen, 1: done */
+            float scal[8];       /* 0: reward, 1: food_rew, 2: dead_rew, 3: walk_target_dist, 4: yaw, 5: joints_at_limit */
+        };
+    };
+    union {
+        F4 rowp[MAXR];           /* bias, 1/diag, lo, hi */
+        struct { float legI[4][24], legp[4][8]; };
+    };
+    float lam[2][MAXR];  /* accumulated impulses, ping-pong by iteration parity */
+    int frn[MAXR];       /* friction rows: index of their normal row, else -1 */
+    float st[32];        /* packed state record as stored in HBM */
+    float items[32];
+    float act[8];
+    int aux[4];
+    float q[2][16];      /* ping-pong: substep s reads q[s&1], writes q[(s+1)&1] */
+    float u[16], tau[8];
+    float XYZ[12];
+    float ph[4][4], pa[4][4], tip[4][4];
+    float S[NJ][8], U[NJ][8], cb[NJ][8];
+    float invD[NJ], uterm[NJ];
+    float I0inv[36];
+    float a0[8];
+    float cr[MAXC][4], cn[MAXC][4];
+    float cdist_[MAXC];
+    int clink[MAXC];     /* level | leg << 2 */
+    int ljoint[NJ];
+    float lsign[NJ], ldist[NJ];
+    int gtouch[16];
+};
+
+struct LaneRegs { float ud, jby; };
+
+/* ------------------------------------------------------------------------------------------------ small math */
+HRL_DEV void cross3(float *o, const float *a, const float *b) {
+    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+HRL_DEV float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+HRL_DEV float dot6(const float *a, const float *b) {
+    return ((((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]) + a[4] * b[4]) + a[5] * b[5];
+}
+/* sin and cos for the dynamics (joint rotations, quaternion increment), specified operation by operation so that
+ * every fp32 implementation of the step produces the same bits: quadrant k = rint(x * 2/pi), three-term
+ * Cody-Waite reduction r = x - k*pi/2, then the classic single-precision minimax polynomials on [-pi/4, pi/4].
+ * Accurate to ~1.5 ulp for |x| < 100; the library sinf/cosf are only used for observations. */
+HRL_DEV void sincos_spec(float x, float *sn, float *cs) {
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z + -1.6666654611e-1f;
+    const float sr = (ps * z) * r + r;
+    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    const float cr = ((pc * z) * z - 0.5f * z) + 1.0f;
+    const int q = ((int)k) & 3;
+    const float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+HRL_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* symmetric 6x6 stored as the upper triangle, row-major (21 floats) */
+HRL_DEV constexpr int si(int a, int b) { return a <= b ? a * 6 - (a * (a - 1)) / 2 + (b - a) : b * 6 - (b * (b - 1)) / 2 + (a - b); }
+HRL_DEV void sym6_matvec(float *o, const float *A, const float *x) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        o[i] = ((((A[si(i, 0)] * x[0] + A[si(i, 1)] * x[1]) + A[si(i, 2)] * x[2]) + A[si(i, 3)] * x[3]) + A[si(i, 4)] * x[4]) + A[si(i, 5)] * x[5];
+}
+/* spatial inertia about O of a body with mass m, central inertia alpha*1 + beta*e e^T, COM offset c */
+HRL_DEV void spatial_inertia(float *I, float m, float alpha, float beta, const float *e, const float *c) {
+    float cc = dot3(c, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+            float d = (i == j) ? 1.f : 0.f;
+            I[si(i, j)] = (alpha * d + beta * e[i] * e[j]) + m * (cc * d - c[i] * c[j]);
+            I[si(3 + i, 3 + j)] = m * d;
+        }
+    /* top-right block = m [c]x */
+    I[si(0, 3)] = m * 0.f;   I[si(0, 4)] = m * -c[2]; I[si(0, 5)] = m * c[1];
+    I[si(1, 3)] = m * c[2];  I[si(1, 4)] = m * 0.f;   I[si(1, 5)] = m * -c[0];
+    I[si(2, 3)] = m * -c[1]; I[si(2, 4)] = m * c[0];  I[si(2, 5)] = m * 0.f;
+}
+HRL_DEV void crm(float *o, const float *v, const float *m) { /* spatial motion cross product */
+    float a[3], b[3], c[3];
+    cross3(a, v, m); cross3(b, v, m + 3); cross3(c, v + 3, m);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+HRL_DEV void crf(float *o, const float *v, const float *f) { /* spatial force cross product */
+    float a[3], b[3], c[3];
+    cross3(a, v, f); cross3(b, v + 3, f + 3); cross3(c, v, f + 3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+/* balanced butterfly sum over 16 slots: the order the 16-lane rotate-add reduction produces */
+HRL_DEV float tree16(const float *x) {
+    float a[8], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = x[i] + x[i + 8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = a[i] + a[i + 4];
+    return (b[0] + b[2]) + (b[1] + b[3]);
+}
+HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
+    if (fabsf(n[2]) > 0.70710678118654752440f) {
+        float a = n[1] * n[1] + n[2] * n[2], k = 1.f / sqrtf(a);
+        t1[0] = 0.f; t1[1] = -n[2] * k; t1[2] = n[1] * k;
+        t2[0] = a * k; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
+    } else {
+        float a = n[0] * n[0] + n[1] * n[1], k = 1.f / sqrtf(a);
+        t1[0] = -n[1] * k; t1[1] = n[0] * k; t1[2] = 0.f;
+        t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
+    }
+}
+/* explicit inverse of an SPD 6x6 (upper-triangle storage in, full 36 out) via Cholesky */
+HRL_DEV void spd6_inverse(float *Ainv, const float *A) {
+    float L[6][6], Li[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { L[i][j] = 0.f; Li[i][j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float s = A[si(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        float d = sqrtf(s), id = 1.f / d;
+        L[j][j] = d;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            float t = A[si(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            L[i][j] = t * id;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        Li[j][j] = 1.f / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = j; k < i; ++k) t -= L[i][k] * Li[k][j];
+            Li[i][j] = t / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = i; k < 6; ++k) t += Li[k][i] * Li[k][j];
+            Ainv[i * 6 + j] = t; Ainv[j * 6 + i] = t;
+        }
+}
+/* Philox4x32-10, keyed like the oracle: key = (seed_lo, seed_hi ^ env_hi), counter = (env_lo, index, w2, w3) */
+HRL_DEV void philox4x32(const DevCfg &c, long long env, uint32_t index, uint32_t w2, uint32_t w3, uint32_t *out) {
+    uint32_t k0 = c.seed_lo, k1 = c.seed_hi ^ (uint32_t)((unsigned long long)env >> 32);
+    uint32_t c0 = (uint32_t)(unsigned long long)env, c1 = index, c2 = w2, c3 = w3;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+HRL_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
+/* ================================================================================================= ANT SUBSTEP */
+
+/* Phase K (leg map): kinematics of one leg, its two articulated-body joints (ankle, hip), results to LDS. */
+HRL_DEV void phase_kin_aba(const DevCfg &c, WaveLds &L, const float *q, int lane) {
+    const float is2 = 0.70710678118654752440f;
+    const int l = (lane >> 4) & 3;
+    float x = q[3], y = q[4], z = q[5], w = q[6];
+    float X[3] = {1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)};
+    float Y[3] = {2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)};
+    float Z[3] = {2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)};
+    float qh = q[7 + 2 * l], qa = q[8 + 2 * l], qdh = L.u[6 + 2 * l], qda = L.u[7 + 2 * l];
+    float ch, sh, ca, sa;
+    sincos_spec(qh, &sh, &ch);
+    sincos_spec(qa, &sa, &ca);
+    /* leg direction signs, ankle axes and sigma = (ankle axis) x (leg dir) . z : assets/ant.xml:15-58 */
+    float sx = (l == 0 || l == 3) ? 1.f : -1.f, sy = (l < 2) ? 1.f : -1.f;
+    float ax = (l & 1) ? 1.f : -1.f, ay = 1.f, sg = (l == 1 || l == 2) ? 1.f : -1.f;
+    float e1x = (sx * ch - sy * sh) * is2, e1y = (sx * sh + sy * ch) * is2;
+    float axx = (ax * ch - ay * sh) * is2, axy = (ax * sh + ay * ch) * is2;
+    float e1[3], axw[3], e2[3], ph[3], pa[3], tip[3], caux[3], cfoot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        e1[k] = e1x * X[k] + e1y * Y[k];
+        axw[k] = axx * X[k] + axy * Y[k];
+        e2[k] = ca * e1[k] + (sg * sa) * Z[k];
+        ph[k] = 0.2f * (sx * X[k] + sy * Y[k]);
+        pa[k] = ph[k] + c.L1 * e1[k];
+        tip[k] = pa[k] + c.L2 * e2[k];
+        caux[k] = ph[k] + (c.L1 * 0.5f) * e1[k];
+        cfoot[k] = pa[k] + (c.L2 * 0.5f) * e2[k];
+    }
+    float Sh[6], Sa[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Sh[k] = Z[k]; Sa[k] = axw[k]; }
+    cross3(Sh + 3, ph, Z);
+    cross3(Sa + 3, pa, axw);
+    float v0[6], vjh[6], vx[6], vja[6], vf[6], cbh[6], cba[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { v0[k] = L.u[k]; vjh[k] = Sh[k] * qdh; vx[k] = v0[k] + vjh[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { vja[k] = Sa[k] * qda; vf[k] = vx[k] + vja[k]; }
+    crm(cbh, v0, vjh);
+    crm(cba, vx, vja);
+    float Ix[21], If[21], Iv[6], f[6], pAx[6], pAf[6], ng[3];
+    spatial_inertia(Ix, c.m1, c.a1, c.b1, e1, caux);
+    spatial_inertia(If, c.m2, c.a2, c.b2, e2, cfoot);
+    { /* bias forces: v x* (I v) - gravity wrench */
+        float fg[3] = {0.f, 0.f, -c.m1 * c.g};
+        sym6_matvec(Iv, Ix, vx); crf(f, vx, Iv); cross3(ng, caux, fg);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pAx[k] = f[k] - ng[k]; pAx[3 + k] = f[3 + k] - fg[k]; }
+        float fg2[3] = {0.f, 0.f, -c.m2 * c.g};
+        sym6_matvec(Iv, If, vf); crf(f, vf, Iv); cross3(ng, cfoot, fg2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pAf[k] = f[k] - ng[k]; pAf[3 + k] = f[3 + k] - fg2[k]; }
+    }
+    /* ankle: foot -> aux */
+    float Ua[6], Iac[6];
+    sym6_matvec(Ua, If, Sa);
+    float invDa = 1.f / dot6(Sa, Ua);
+    float uta = L.tau[2 * l + 1] - dot6(Sa, pAf);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) If[si(a, b)] = If[si(a, b)] - (Ua[a] * invDa) * Ua[b];
+    sym6_matvec(Iac, If, cba);
+    {
+        float ud = uta * invDa;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) pAx[a] += (pAf[a] + Iac[a]) + Ua[a] * ud;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) Ix[k] += If[k];
+    }
+    /* hip: aux -> torso */
+    float Uh[6], plg[6];
+    sym6_matvec(Uh, Ix, Sh);
+    float invDh = 1.f / dot6(Sh, Uh);
+    float uth = L.tau[2 * l] - dot6(Sh, pAx);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) Ix[si(a, b)] = Ix[si(a, b)] - (Uh[a] * invDh) * Uh[b];
+    sym6_matvec(Iac, Ix, cbh);
+    {
+        float ud = uth * invDh;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) plg[a] = (pAx[a] + Iac[a]) + Uh[a] * ud;
+    }
+    const int jh = 2 * l, ja = jh + 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        L.S[jh][k] = Sh[k]; L.S[ja][k] = Sa[k]; L.U[jh][k] = Uh[k]; L.U[ja][k] = Ua[k];
+        L.cb[jh][k] = cbh[k]; L.cb[ja][k] = cba[k]; L.legp[l][k] = plg[k];
+    }
+    L.invD[jh] = invDh; L.invD[ja] = invDa; L.uterm[jh] = uth; L.uterm[ja] = uta;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) L.legI[l][k] = Ix[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        L.ph[l][k] = ph[k]; L.pa[l][k] = pa[k]; L.tip[l][k] = tip[k];
+        L.XYZ[k] = X[k]; L.XYZ[3 + k] = Y[k]; L.XYZ[6 + k] = Z[k];
+    }
+}
+
+/* Phase B (uniform): torso + leg sums, inverse of the base articulated inertia, base acceleration. */
+HRL_DEV void phase_base(const DevCfg &c, WaveLds &L, int lane) {
+    float Z[3] = {L.XYZ[6], L.XYZ[7], L.XYZ[8]}, zero3[3] = {0.f, 0.f, 0.f};
+    float I0[21], v0[6], Iv[6], f[6], p0[6];
+    spatial_inertia(I0, c.m0, c.a0, c.b0, Z, zero3);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v0[k] = L.u[k];
+    sym6_matvec(Iv, I0, v0);
+    crf(f, v0, Iv);
+    float fg[3] = {0.f, 0.f, -c.m0 * c.g}, ng[3];
+    cross3(ng, zero3, fg);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { p0[k] = f[k] - ng[k]; p0[3 + k] = f[3 + k] - fg[k]; }
+#pragma unroll
+    for (int k = 0; k < 21; ++k) I0[k] += (L.legI[0][k] + L.legI[1][k]) + (L.legI[2][k] + L.legI[3][k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p0[k] = p0[k] + ((L.legp[0][k] + L.legp[1][k]) + (L.legp[2][k] + L.legp[3][k]));
+    float Ainv[36];
+    spd6_inverse(Ainv, I0);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) L.a0[a] = -dot6(Ainv + 6 * a, p0);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) L.I0inv[k] = Ainv[k];
+    (void)lane;
+}
+
+/* Phase V (dof map): forward pass of the lane's leg, then the unconstrained velocity update into the lane register. */
+HRL_DEV float phase_forward_vel(const DevCfg &c, const WaveLds &L, int lane) {
+    const int d = lane & 15;
+    float a0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a0[k] = L.a0[k];
+    if (d < 3) return L.u[d] + c.h * a0[d];
+    if (d < 6) {
+        float wxv[3];
+        cross3(wxv, L.u, L.u + 3);
+        return L.u[d] + c.h * (a0[d] + wxv[d - 3]);
+    }
+    if (d >= 14) return 0.f;
+    const int j = d - 6, jh = j & ~1, ja = jh + 1;
+    float ap[6], ax_[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ap[k] = a0[k] + L.cb[jh][k];
+    float qddh = (L.uterm[jh] - dot6(L.U[jh], ap)) * L.invD[jh];
+    if (j == jh) return L.u[d] + c.h * qddh;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ax_[k] = (ap[k] + L.S[jh][k] * qddh) + L.cb[ja][k];
+    float qdda = (L.uterm[ja] - dot6(L.U[ja], ax_)) * L.invD[ja];
+    return L.u[d] + c.h * qdda;
+}
+
+/* velocity response du = M^-1 (generalized impulse) through the articulated-body quantities in LDS */
+HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, float th, float ta, float *du) {
+    const int jh = 2 * leg, ja = jh + 1;
+    float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ua = ta, uh = th;
+    if (level == 2) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = -phi[k];
+        ua = ta - dot6(L.S[ja], p);
+    }
+    {
+        float s = ua * L.invD[ja];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = p[k] + L.U[ja][k] * s;
+    }
+    if (level == 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
+    }
+    uh = th - dot6(L.S[jh], p);
+    {
+        float s = uh * L.invD[jh];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = p[k] + L.U[jh][k] * s;
+    }
+    if (level == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
+    }
+    float dv0[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) dv0[a] = -dot6(L.I0inv + 6 * a, p);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) du[k] = dv0[k];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int h_ = 2 * l, a_ = h_ + 1;
+        float uhl = (l == leg) ? uh : 0.f, ual = (l == leg) ? ua : 0.f, dvx[6];
+        float dqh = (uhl - dot6(L.U[h_], dv0)) * L.invD[h_];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dvx[k] = dv0[k] + L.S[h_][k] * dqh;
+        float dqa = (ual - dot6(L.U[a_], dvx)) * L.invD[a_];
+        du[6 + h_] = dqh; du[6 + a_] = dqa;
+    }
+    du[14] = 0.f; du[15] = 0.f;
+}
+
+struct Hit { bool ok; float dist, n[3], c[3], rad; int link; };
+
+/* Phase C helper (lane = sphere): signed distance of sphere `lane` to surface f (0 ground, planes, boxes) */
+HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q, int lane, int f) {
+    Hit h;
+    h.ok = false; h.dist = 0.f; h.rad = 0.f; h.link = 0;
+    h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f;
+    if (lane >= 13) return h;
+    int level = 0, leg = 0;
+    h.rad = c.r_torso;
+    if (lane > 0) {
+        leg = (lane - 1) / 3; level = (lane - 1) % 3;
+        const float *src = level == 0 ? L.ph[leg] : (level == 1 ? L.pa[leg] : L.tip[leg]);
+        h.c[0] = src[0]; h.c[1] = src[1]; h.c[2] = src[2];
+        h.rad = c.r_caps;
+    }
+    h.link = level | (leg << 2);
+    float p[3] = {q[0] + h.c[0], q[1] + h.c[1], q[2] + h.c[2]};
+    if (f == 0) h.dist = (p[2] - c.ground_z) - h.rad;
+    else if (f <= c.n_planes) {
+        h.n[0] = c.plane_n[f - 1][0]; h.n[1] = c.plane_n[f - 1][1]; h.n[2] = c.plane_n[f - 1][2];
+        h.dist = (dot3(h.n, p) - c.plane_d[f - 1]) - h.rad;
+    } else {
+        float d[3], d2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { float cp = clampf(p[k], c.box_lo[k], c.box_hi[k]); d[k] = p[k] - cp; d2 += d[k] * d[k]; }
+        if (d2 > 0.f) {
+            float len = sqrtf(d2);
+            h.n[0] = d[0] / len; h.n[1] = d[1] / len; h.n[2] = d[2] / len;
+            h.dist = len - h.rad;
+        } else { /* centre inside the box: leave through the nearest face */
+            int best = 0; float bd = 1e30f, sgn = 1.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float dl = p[k] - c.box_lo[k], dh = c.box_hi[k] - p[k];
+                if (dl < bd) { bd = dl; best = k; sgn = -1.f; }
+                if (dh < bd) { bd = dh; best = k; sgn = 1.f; }
+            }
+            h.n[0] = best == 0 ? sgn : 0.f; h.n[1] = best == 1 ? sgn : 0.f; h.n[2] = best == 2 ? sgn : 0.f;
+            h.dist = -bd - h.rad;
+        }
+    }
+    h.ok = h.dist < c.cdist;
+    return h;
+}
+
+struct LimitHit { bool ok; float sgn, dist; };
+
+/* Phase R (row map): Jacobian row, its response B = M^-1 J^T, diagonal, bias and bounds -> LDS */
+HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, int lane, int nL, int nC) {
+    const int nR = nL + 3 * nC;
+    if (lane >= nR) return;
+    float J[16], B[16], bias, lo = 0.f, hi = 0.f;
+    int frn = -1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) J[k] = 0.f;
+    if (lane < nL) {
+        const int j = L.ljoint[lane];
+        const float sgn = L.lsign[lane], dist = L.ldist[lane];
+        float zero6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) J[6 + k] = (k == j) ? sgn : 0.f;
+        response(L, zero6, 0, j >> 1, (j & 1) ? 0.f : sgn, (j & 1) ? sgn : 0.f, B);
+        bias = (dist > 0.f ? dist : c.erp_l * dist) / c.h;
+        hi = c.limp_max;
+    } else {
+        const int row = lane - nL;
+        const int ci = row < nC ? row : (row - nC) >> 1, which = row < nC ? 0 : 1 + ((row - nC) & 1);
+        float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
+        float t1[3], t2[3], phi[6];
+        tangent_basis(n, t1, t2);
+        float d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = which == 0 ? n[k] : (which == 1 ? t1[k] : t2[k]);
+        cross3(phi, r, d);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
+        const int level = L.clink[ci] & 3, leg = L.clink[ci] >> 2;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[k] = phi[k];
+        const float jh = dot6(phi, L.S[2 * leg]), ja = dot6(phi, L.S[2 * leg + 1]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            J[6 + 2 * k] = (k == leg && level >= 1) ? jh : 0.f;
+            J[7 + 2 * k] = (k == leg && level >= 2) ? ja : 0.f;
+        }
+        response(L, phi, level, leg, 0.f, 0.f, B);
+        if (which == 0) {
+            const float dist = L.cdist_[ci];
+            bias = (dist > 0.f ? dist : c.erp_c * dist) / c.h;
+            hi = 1e30f;
+        } else { bias = 0.f; frn = nL + ci; }
+    }
+    float prod[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) prod[k] = J[k] * B[k];
+    const float invd = 1.f / tree16(prod);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { F2 jb; jb.x = J[k]; jb.y = B[k]; L.JB[lane * JBS + k] = jb; }
+    F4 rp; rp.x = bias; rp.y = invd; rp.z = lo; rp.w = hi;
+    L.rowp[lane] = rp; L.frn[lane] = frn; L.lam[0][lane] = 0.f;
+}
+
+/* Phase I (uniform): clamp joint rates was done in the dof map; integrate positions */
+HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float *qn, int lane) {
+    float u[16];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) u[k] = L.u[k];
+    const float h = c.h;
+    float wn = sqrtf(dot3(u, u)), th = wn * h, dq[4];
+    if (th > 1e-6f) { float sh_, ch_; sincos_spec(0.5f * th, &sh_, &ch_); float s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
+    else { float s = 0.5f * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1.f; }
+    float x = q[3], y = q[4], z = q[5], w = q[6];
+    float nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
+    float ny = dq[3] * y - dq[0] * z + dq[1] * w + dq[2] * x;
+    float nz = dq[3] * z + dq[0] * y - dq[1] * x + dq[2] * w;
+    float nw = dq[3] * w - dq[0] * x - dq[1] * y - dq[2] * z;
+    float inv = 1.f / sqrtf((nx * nx + ny * ny) + (nz * nz + nw * nw));
+    float nq[16];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nq[k] = q[k] + h * u[3 + k];
+    nq[3] = nx * inv; nq[4] = ny * inv; nq[5] = nz * inv; nq[6] = nw * inv;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) nq[7 + j] = q[7 + j] + h * u[6 + j];
+    nq[15] = 0.f;
+    /* every lane holds the same 16 values; lane k < 16 stores element k */
+    float mine = nq[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mine = (lane == k) ? nq[k] : mine;
+    if (lane < 16) qn[lane] = mine;
+}
+
+/* Projected Gauss-Seidel in the dof map: every row update is one LDS read of (J,B)[r][dof], one 16-lane
+ * rotate-add reduction for J.u, a handful of wave-uniform scalar ops and one FMA on the lane's velocity register.
+ * Rows run in order (limits, normals, friction pairs); friction bounds use the normal impulse of this sweep. */
+template <class X>
+HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nR) {
+    WaveLds &L = x.lds();
+    for (int it = 0; it < c.iters; ++it) {
+        const int cur = it & 1, nxt = cur ^ 1;
+        for (int r = 0; r < nR; ++r) {
+            x.each_reduce16(
+                [&](int lane) {
+                    const F2 jb = L.JB[r * JBS + (lane & 15)];
+                    x.reg(lane).jby = jb.y;
+                    return jb.x * x.reg(lane).ud;
+                },
+                [&](int lane, float wv) {
+                    const F4 rp = L.rowp[r];
+                    const float lam = L.lam[cur][r];
+                    float lo = rp.z, hi = rp.w;
+                    const int fn = L.frn[r];
+                    if (fn >= 0) { hi = c.mu * L.lam[nxt][fn]; lo = -hi; }
+                    const float ln = clampf(lam - (wv + rp.x) * rp.y, lo, hi);
+                    const float dl = ln - lam;
+                    x.reg(lane).ud = x.reg(lane).ud + x.reg(lane).jby * dl;
+                    L.lam[nxt][r] = ln;
+                });
+        }
+    }
+}
+
+/* One physics substep.  On entry L.q[qi] / L.u / L.tau hold the state; on exit L.q[qi ^ 1] / L.u are advanced by h. */
+template <class X>
+HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
+    WaveLds &L = x.lds();
+    const float *q = L.q[qi];
+    float *qn = L.q[qi ^ 1];
+    x.each([&](int lane) { phase_kin_aba(c, L, q, lane); });
+    x.each([&](int lane) { phase_base(c, L, lane); });
+    x.each([&](int lane) { x.reg(lane).ud = phase_forward_vel(c, L, lane); });
+    /* contacts: surface-major, sphere-minor; at most MAXC kept */
+    int nC = 0;
+    const int nsurf = 1 + c.n_planes + c.n_boxes;
+    for (int f = 0; f < nsurf; ++f) {
+        const int base = nC;
+        int cnt = x.each_compact(
+            [&](int lane) { return sphere_vs_surface(c, L, q, lane, f); },
+            [&](int lane, int rank, const Hit &h) {
+                const int i = base + rank;
+                if (i < MAXC) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { L.cn[i][k] = h.n[k]; L.cr[i][k] = h.c[k] - h.rad * h.n[k]; }
+                    L.cdist_[i] = h.dist; L.clink[i] = h.link;
+                }
+            },
+            [&](int lane, const Hit &h) { if (f == 0 && lane < 16) L.gtouch[lane] = h.ok ? 1 : 0; });
+        nC += cnt;
+        if (nC > MAXC) nC = MAXC;
+    }
+    /* joint limits (lane = joint) */
+    int nL = x.each_compact(
+        [&](int lane) {
+            LimitHit r; r.ok = false; r.sgn = 0.f; r.dist = 0.f;
+            if (lane < NJ) {
+                float dlo = q[7 + lane] - c.jlo[lane], dhi = c.jhi[lane] - q[7 + lane];
+                if (dlo < c.lmargin) { r.ok = true; r.sgn = 1.f; r.dist = dlo; }
+                else if (dhi < c.lmargin) { r.ok = true; r.sgn = -1.f; r.dist = dhi; }
+            }
+            return r;
+        },
+        [&](int lane, int rank, const LimitHit &r) { L.ljoint[rank] = lane; L.lsign[rank] = r.sgn; L.ldist[rank] = r.dist; },
+        [&](int, const LimitHit &) {});
+    x.each([&](int lane) { phase_build_row(c, L, lane, nL, nC); });
+    pgs_solve(x, c, nL + 3 * nC);
+    x.each([&](int lane) {
+        const int d = lane & 15;
+        float v = x.reg(lane).ud;
+        if (d >= 6 && d < 14) v = clampf(v, -c.vmax, c.vmax);
+        if (lane < 16) L.u[lane] = v;
+    });
+    x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });
+}
+
+
+/* ================================================================================================= POINT SUBSTEP
+ * point_bot.py:10-74 + assets/player_cube.xml:8: free 10 kg cube (half extent 0.35).  Solid-cube inertia is
+ * isotropic, so M^-1 = diag(1/I,1/I,1/I,1/m,1/m,1/m) and there is no gyroscopic term. */
+struct CornerHit { bool ok; float dist, n[3], c[3]; };
+
+template <class X>
+HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
+    WaveLds &L = x.lds();
+    const float *q = L.q[qi];
+    float *qn = L.q[qi ^ 1];
+    const float m = 10.f, he = 0.35f, I = m * (0.7f * 0.7f) / 6.f;
+    x.each([&](int lane) {
+        const int d = lane & 15;
+        float v = L.u[d];
+        if (d == 3) v = L.u[3] + c.h * (L.tau[0] / m);
+        if (d == 4) v = L.u[4] + c.h * (L.tau[1] / m);
+        if (d == 5) v = L.u[5] + c.h * (L.tau[2] / m - c.g);
+        x.reg(lane).ud = d < 6 ? v : 0.f;
+        float qx = q[3], qy = q[4], qz = q[5], qw = q[6];
+        L.XYZ[0] = 1 - 2 * (qy * qy + qz * qz); L.XYZ[1] = 2 * (qx * qy + qw * qz); L.XYZ[2] = 2 * (qx * qz - qw * qy);
+        L.XYZ[3] = 2 * (qx * qy - qw * qz); L.XYZ[4] = 1 - 2 * (qx * qx + qz * qz); L.XYZ[5] = 2 * (qy * qz + qw * qx);
+        L.XYZ[6] = 2 * (qx * qz + qw * qy); L.XYZ[7] = 2 * (qy * qz - qw * qx); L.XYZ[8] = 1 - 2 * (qx * qx + qy * qy);
+    });
+    int nC = 0;
+    for (int f = 0; f < 1 + c.n_planes; ++f) {
+        const int base = nC;
+        int cnt = x.each_compact(
+            [&](int lane) {
+                CornerHit h; h.ok = false; h.dist = 0.f; h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f;
+                if (lane < 8) {
+                    float sx = (lane & 1) ? he : -he, sy = (lane & 2) ? he : -he, sz = (lane & 4) ? he : -he;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) h.c[k] = (sx * L.XYZ[k] + sy * L.XYZ[3 + k]) + sz * L.XYZ[6 + k];
+                    if (f == 0) h.dist = (q[2] + h.c[2]) - c.ground_z;
+                    else {
+                        float p[3] = {q[0] + h.c[0], q[1] + h.c[1], q[2] + h.c[2]};
+                        h.n[0] = c.plane_n[f - 1][0]; h.n[1] = c.plane_n[f - 1][1]; h.n[2] = c.plane_n[f - 1][2];
+                        h.dist = dot3(h.n, p) - c.plane_d[f - 1];
+                    }
+                    h.ok = h.dist < c.cdist;
+                }
+                return h;
+            },
+            [&](int, int rank, const CornerHit &h) {
+                const int i = base + rank;
+                if (i < MAXC) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { L.cn[i][k] = h.n[k]; L.cr[i][k] = h.c[k]; }
+                    L.cdist_[i] = h.dist;
+                }
+            },
+            [&](int, const CornerHit &) {});
+        nC += cnt;
+        if (nC > MAXC) nC = MAXC;
+    }
+    x.each([&](int lane) { /* row map */
+        if (lane >= 3 * nC) return;
+        const int ci = lane < nC ? lane : (lane - nC) >> 1, which = lane < nC ? 0 : 1 + ((lane - nC) & 1);
+        float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
+        float t1[3], t2[3], d[3], J[16], B[16], prod[16];
+        tangent_basis(n, t1, t2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = which == 0 ? n[k] : (which == 1 ? t1[k] : t2[k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { J[k] = 0.f; B[k] = 0.f; }
+        cross3(J, r, d);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { J[3 + k] = d[k]; B[k] = J[k] / I; B[3 + k] = d[k] / m; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) prod[k] = J[k] * B[k];
+        const float dist = L.cdist_[ci];
+        F4 rp; rp.x = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) / c.h : 0.f; rp.y = 1.f / tree16(prod); rp.z = 0.f; rp.w = which == 0 ? 1e30f : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { F2 jb; jb.x = J[k]; jb.y = B[k]; L.JB[lane * JBS + k] = jb; }
+        L.rowp[lane] = rp; L.frn[lane] = which == 0 ? -1 : ci; L.lam[0][lane] = 0.f;
+    });
+    pgs_solve(x, c, 3 * nC);
+    x.each([&](int lane) { if (lane < 16) L.u[lane] = x.reg(lane).ud; });
+    x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });
+}
+
+/* ================================================================================================= OBSERVATIONS */
+
+/* pybullet getEulerFromQuaternion (upstream, restated from memory) */
+HRL_DEV void quat_to_rpy(const float *qq, float *rpy) {
+    float x = qq[0], y = qq[1], z = qq[2], w = qq[3];
+    float sarg = -2.f * (x * z - w * y);
+    const float hp = 1.5707963267948966f;
+    if (sarg <= -0.99999f) { rpy[0] = 0.f; rpy[1] = -hp; rpy[2] = 2.f * atan2f(x, -y); }
+    else if (sarg >= 0.99999f) { rpy[0] = 0.f; rpy[1] = hp; rpy[2] = 2.f * atan2f(-x, y); }
+    else {
+        float sqx = x * x, sqy = y * y, sqz = z * z, sqw = w * w;
+        rpy[0] = atan2f(2.f * (y * z + w * x), ((sqw - sqx) - sqy) + sqz);
+        rpy[1] = asinf(sarg);
+        rpy[2] = atan2f(2.f * (x * y + w * z), ((sqw + sqx) - sqy) - sqz);
+    }
+}
+/* ant_gather_env.py:148-155: python `%` then fold to (-pi, pi] */
+HRL_DEV float wrap_angle(float a) {
+    const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+    a = fmodf(a, two_pi);
+    if (a < 0.f) a += two_pi;
+    if (a >= two_pi) a -= two_pi;
+    if (a > pi) a = a - two_pi;
+    if (a < -pi) a = a + two_pi;
+    return a;
+}
+/* intersection_utils.py:93-104 */
+HRL_DEV int quadrant(float x, float y) {
+    if (x >= 0.f && y >= 0.f) return 1;
+    if (x >= 0.f && y <= 0.f) return 4;
+    if (x <= 0.f && y >= 0.f) return 2;
+    if (x <= 0.f && y <= 0.f) return 3;
+    return -1;
+}
+/* intersection_utils.py:84-90 */
+HRL_DEV bool inf_intersection(float x1, float y1, float x2, float y2, float x3, float y3, float x4, float y4, float *px, float *py) {
+    float d = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+    if (d == 0.f) return false;
+    *px = ((x1 * y2 - y1 * x2) * (x3 - x4) - (x1 - x2) * (x3 * y4 - y3 * x4)) / d;
+    *py = ((x1 * y2 - y1 * x2) * (y3 - y4) - (y1 - y2) * (x3 * y4 - y3 * x4)) / d;
+    return true;
+}
+/* intersection_utils.py:14-71 */
+HRL_DEV int orientation(float px, float py, float qx, float qy, float rx, float ry) {
+    float val = ((qy - py) * (rx - qx)) - ((qx - px) * (ry - qy));
+    return val > 0.f ? 1 : (val < 0.f ? 2 : 0);
+}
+HRL_DEV bool on_segment(float px, float py, float qx, float qy, float rx, float ry) {
+    return (qx <= fmaxf(px, rx)) && (qx >= fminf(px, rx)) && (qy <= fmaxf(py, ry)) && (qy >= fminf(py, ry));
+}
+HRL_DEV bool segment_intersection(float p1x, float p1y, float q1x, float q1y, float p2x, float p2y, float q2x, float q2y) {
+    int o1 = orientation(p1x, p1y, q1x, q1y, p2x, p2y), o2 = orientation(p1x, p1y, q1x, q1y, q2x, q2y);
+    int o3 = orientation(p2x, p2y, q2x, q2y, p1x, p1y), o4 = orientation(p2x, p2y, q2x, q2y, q1x, q1y);
+    if (o1 != o2 && o3 != o4) return true;
+    if (o1 == 0 && on_segment(p1x, p1y, p2x, p2y, q1x, q1y)) return true;
+    if (o2 == 0 && on_segment(p1x, p1y, q2x, q2y, q1x, q1y)) return true;
+    if (o3 == 0 && on_segment(p2x, p2y, p1x, p1y, q2x, q2y)) return true;
+    if (o4 == 0 && on_segment(p2x, p2y, q1x, q1y, q2x, q2y)) return true;
+    return false;
+}
+/* MazeScene.bounds (maze_scene.py:15-21, sizeable_enclosed_scene.py:28-34): 4 world lines + 3 box lines */
+HRL_DEV void maze_line(int l, float *a) {
+    const float T[7][4] = {{5, 9, -5, 9}, {5, 9, 5, -9}, {-5, -9, -5, 9}, {-5, -9, 5, -9}, {1, 2, 1, -2}, {-5, -2, -5, 2}, {-5, -2, 1, -2}};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = T[0][k];
+#pragma unroll
+        for (int i = 1; i < 7; ++i) v = (l == i) ? T[i][k] : v;
+        a[k] = v;
+    }
+}
+
+/* Phase O1: upstream WalkerBase.calc_state (28-vector clipped to +-5) into L.s28, plus walk_target_dist, yaw and
+ * joints_at_limit into L.scal.  `with_centroid` needs L.ph/pa/tip of the CURRENT qpos (phase_kin_aba on L.st). */
+HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_feet, bool with_centroid) {
+    const float *qp = L.st, *qv = L.st + 15;
+    float rpy[3];
+    quat_to_rpy(qp + 3, rpy);
+    float tx = c.walk_tx, ty = c.walk_ty;
+    if (c.kind == 2) { /* maze: the episode's target */
+        const int ti = L.aux[3];
+        tx = c.targets[0][0]; ty = c.targets[0][1];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { tx = (ti == i) ? c.targets[i][0] : tx; ty = (ti == i) ? c.targets[i][1] : ty; }
+    }
+    float cx = qp[0], cy = qp[1];
+    if (with_centroid) {
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            sx += (0.5f * L.ph[l][0] + 0.5f * (L.ph[l][0] + L.pa[l][0])) + 0.5f * (L.pa[l][0] + L.tip[l][0]);
+            sy += (0.5f * L.ph[l][1] + 0.5f * (L.ph[l][1] + L.pa[l][1])) + 0.5f * (L.pa[l][1] + L.tip[l][1]);
+        }
+        const float np_ = (float)(13 + c.centroid_n_static);
+        cx = ((13.f * qp[0] + sx) + c.centroid_sx) / np_;
+        cy = ((13.f * qp[1] + sy) + c.centroid_sy) / np_;
+    }
+    const float dx = tx - cx, dy = ty - cy;
+    const float theta = atan2f(dy, dx), wtd = sqrtf(dy * dy + dx * dx), ang = theta - rpy[2];
+    const float cs = cosf(-rpy[2]), sn = sinf(-rpy[2]);
+    const float vx = cs * qv[0] - sn * qv[1], vy = sn * qv[0] + cs * qv[1], vz = qv[2];
+    int nlim = 0;
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float mid = 0.5f * (c.jlo[j] + c.jhi[j]);
+        const float rel = 2.f * (qp[7 + j] - mid) / (c.jhi[j] - c.jlo[j]);
+        if (fabsf(rel) > 0.99f) ++nlim;
+        mine = (lane == 8 + 2 * j) ? rel : mine;
+        mine = (lane == 9 + 2 * j) ? 0.1f * qv[6 + j] : mine;
+    }
+    mine = (lane == 0) ? qp[2] - L.st[30] : mine;
+    mine = (lane == 1) ? sinf(ang) : mine;
+    mine = (lane == 2) ? cosf(ang) : mine;
+    mine = (lane == 3) ? 0.3f * vx : mine;
+    mine = (lane == 4) ? 0.3f * vy : mine;
+    mine = (lane == 5) ? 0.3f * vz : mine;
+    mine = (lane == 6) ? rpy[0] : mine;
+    mine = (lane == 7) ? rpy[1] : mine;
+    if (lane >= 24 && lane < 28) {
+        const int l = lane - 24;
+        mine = (use_feet && (L.gtouch[2 + 3 * l] || L.gtouch[3 + 3 * l])) ? 1.f : 0.f;
+    }
+    if (lane < 28) L.s28[lane] = clampf(mine, -5.f, 5.f);
+    L.scal[3] = wtd; L.scal[4] = rpy[2]; L.scal[5] = (float)nlim;
+}
+
+/* gather_scene.py:52-62 with counter-based draws: at most 64 attempts, the last one is kept */
+HRL_DEV void respawn_item(const DevCfg &c, long long env, uint32_t index, uint32_t purpose, int item, float ax, float ay, float *px, float *py) {
+    const float sxw = c.world_sx - 1.f, syw = c.world_sy - 1.f;
+    for (uint32_t a = 0; a < 64; ++a) {
+        uint32_t r[4];
+        philox4x32(c, env, index, (purpose << 16) | (uint32_t)item, a, r);
+        *px = u01(r[0]) * sxw - sxw / 2.f; *py = u01(r[1]) * syw - syw / 2.f;
+        const float dx = ax - *px, dy = ay - *py;
+        if (!(sqrtf(dx * dx + dy * dy) < c.spacing)) break;
+    }
+}
+
+/* Phase O2 (item map): pickup + respawn (ant_gather_env.py:84-92, gather_scene.py:95-114) and the item's sensor
+ * contribution (ant_gather_env.py:145-162). */
+HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, bool pickups) {
+    const int n = c.n_food + c.n_poison;
+    if (lane >= 16) return;
+    float rew = 0.f, bin = -1.f, inten = 0.f;
+    if (lane < n) {
+        const float rx = L.st[0], ry = L.st[1], yaw = L.scal[4];
+        float ix = L.items[2 * lane], iy = L.items[2 * lane + 1];
+        float dx = ix - rx, dy = iy - ry, d2 = dx * dx + dy * dy;
+        if (pickups && c.coll_dist > 0.f && d2 < c.coll_dist) {
+            rew = lane < c.n_food ? 1.f : -1.f;
+            if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane, rx, ry, &ix, &iy);
+            else { ix = 100.f; iy = 0.f; }
+            L.items[2 * lane] = ix; L.items[2 * lane + 1] = iy;
+            dx = ix - rx; dy = iy - ry; d2 = dx * dx + dy * dy;
+        }
+        if (!(d2 > c.sensor_range)) {
+            const float half_span = c.sensor_span * 0.5f, bin_res = c.sensor_span / (float)c.n_bins;
+            const float angle = wrap_angle(atan2f(iy - ry, ix - rx) - yaw);
+            if (fabsf(angle) <= half_span) {
+                int b = (int)((angle + half_span) / bin_res);
+                if (b >= c.n_bins) b = c.n_bins - 1;
+                bin = (float)b; inten = 1.0f - d2 / c.sensor_range;
+            }
+        }
+    }
+    L.irew[lane] = rew; L.ibin[lane] = bin; L.iint[lane] = inten;
+}
+
+/* Phase O3: final observation vector into L.obs, non-finite flag into L.flags[0] */
+HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
+    if (lane >= c.obs_dim) return;
+    float v = 0.f;
+    if (c.kind == 0) v = L.st[lane];                       /* MjAnt.py:17-25: qpos | qvel */
+    else if (c.kind == 3) {                                /* point: calc_state(8) | food | poison */
+        if (lane < 8) v = L.s28[lane];
+    } else if (lane < 26) v = L.s28[lane == 0 ? 0 : lane + 2]; /* ant_gather_env.py:81, ant_maze_bullet_env.py:75 */
+    const int nb = (c.kind == 3) ? 8 : 26;
+    if ((c.kind == 1 || c.kind == 3) && lane >= nb) { /* ant_gather_env.py:128-177: nearest in-range item per bin and type */
+        const int b = lane - nb, type = b / c.n_bins, bin = b - type * c.n_bins;
+        const int k0 = type ? c.n_food : 0, k1 = type ? c.n_food + c.n_poison : c.n_food;
+        float best = 0.f;
+        for (int k = k0; k < k1; ++k)
+            if (L.ibin[k] == (float)bin && L.iint[k] > best) best = L.iint[k];
+        v = best;
+    }
+    if (c.kind == 2 && lane >= 26) {
+        const float rx = L.st[0], ry = L.st[1], yaw = L.scal[4];
+        const int ti = L.aux[3];
+        float tx = c.targets[0][0], ty = c.targets[0][1];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { tx = (ti == i) ? c.targets[i][0] : tx; ty = (ti == i) ? c.targets[i][1] : ty; }
+        const int ntar = c.sense_target ? c.n_bins : 2;
+        if (lane < 26 + ntar) {
+            const int i = lane - 26;
+            if (!c.sense_target) { /* ant_maze_bullet_env.py:123-133 */
+                const float vx = tx - rx, vy = ty - ry;
+                if (c.target_encoding == 0) { const float n = sqrtf(vx * vx + vy * vy); v = i == 0 ? vx / n : vy / n; }
+                else { const float a = atan2f(vy, vx) - yaw; v = i == 0 ? sinf(a) : cosf(a); }
+            } else { /* ant_maze_bullet_env.py:135-178 */
+                const float wtd = L.scal[3];
+                bool vis = !(wtd > c.sensor_range);
+                for (int l = 4; l < 7 && vis; ++l) { float a[4]; maze_line(l, a); if (segment_intersection(rx, ry, tx, ty, a[0], a[1], a[2], a[3])) vis = false; }
+                if (vis) {
+                    const float angle = wrap_angle(atan2f(ty - ry, tx - rx) - yaw), half_span = c.sensor_span * 0.5f;
+                    if (fabsf(angle) <= half_span) {
+                        int b = (int)((angle + half_span) / (c.sensor_span / (float)c.n_bins));
+                        if (b >= c.n_bins) b = c.n_bins - 1;
+                        if (b == i) v = 1.0f - wtd / c.sensor_range;
+                    }
+                }
+            }
+        } else { /* sizeable_enclosed_scene.py:63-97 wall sensor, lane = bin */
+            const int i = lane - 26 - ntar;
+            const float half_pi = 1.5707963267948966f;
+            float phi;
+            if (c.span_is_2pi) phi = half_pi + yaw + ((float)(i + 1) / (float)c.n_bins) * c.sensor_span;
+            else phi = half_pi + yaw + ((float)i / (float)(c.n_bins - 1)) * c.sensor_span;
+            const float svx = rx + c.sensor_range * cosf(phi), svy = ry + c.sensor_range * sinf(phi);
+            const int sq = quadrant(svx - rx, svy - ry);
+            float best = 0.f;
+            for (int l = 0; l < 7; ++l) {
+                float a[4], px, py;
+                maze_line(l, a);
+                if (!inf_intersection(rx, ry, svx, svy, a[0], a[1], a[2], a[3], &px, &py)) continue;
+                const float ddx = rx - px, ddy = ry - py, dist = sqrtf(ddx * ddx + ddy * ddy);
+                if (dist > c.sensor_range) continue;
+                if (sq != quadrant(px - rx, py - ry)) continue;
+                const float val = 1.f - dist / c.sensor_range;
+                if (val > best) best = val;
+            }
+            v = best;
+        }
+    }
+    L.obs[lane] = v;
+    if (!isfinite(v)) L.flags[0] = 1;
+}
+
+/* point_bot.py:48-67 into L.s28[0..7] (walk target (0,0), initial_z 1) */
+HRL_DEV void phase_point_state(const DevCfg &c, WaveLds &L, int lane) {
+    const float *qp = L.st, *qv = L.st + 15;
+    float rpy[3];
+    quat_to_rpy(qp + 3, rpy);
+    const float theta = atan2f(0.f - qp[1], 0.f - qp[0]), a = theta - rpy[2];
+    const float cs = cosf(-rpy[2]), sn = sinf(-rpy[2]);
+    const float vx = cs * qv[0] - sn * qv[1], vy = sn * qv[0] + cs * qv[1], vz = qv[2];
+    float mine = qp[2] - 1.f;
+    mine = (lane == 1) ? sinf(a) : mine;
+    mine = (lane == 2) ? cosf(a) : mine;
+    mine = (lane == 3) ? 0.3f * vx : mine;
+    mine = (lane == 4) ? 0.3f * vy : mine;
+    mine = (lane == 5) ? 0.3f * vz : mine;
+    mine = (lane == 6) ? rpy[0] : mine;
+    mine = (lane == 7) ? rpy[1] : mine;
+    if (lane < 8) L.s28[lane] = mine;
+    L.scal[3] = 0.f; L.scal[4] = rpy[2]; L.scal[5] = 0.f;
+    (void)c;
+}
+
+/* Observation of the state in L.st / L.items / L.aux into L.obs (and L.scal).  Used by step and by reset. */
+template <class X>
+HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
+    WaveLds &L = x.lds();
+    x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
+    if (c.kind == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
+    else {
+        const bool centroid = (c.kind == 0 || c.kind == 2);
+        if (centroid) { /* link positions of the final pose for the parts centroid */
+            x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
+            x.each([&](int lane) { phase_kin_aba(c, L, L.q[0], lane); });
+        }
+        const bool feet = step_mode && c.kind == 2; /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
+        x.each([&](int lane) { phase_calc_state(c, L, lane, feet, centroid); });
+    }
+    if (c.kind == 1 || c.kind == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode); });
+    x.each([&](int lane) { phase_pack_obs(c, L, lane); });
+}
+
+/* ================================================================================================= RESET / STEP */
+
+/* Env.reset(): ant_gather_env.py:68-74, gather_scene.py:38-50, ant_maze_bullet_env.py:104-121, point_bot.py:12,25-26 */
+template <class X>
+HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
+    WaveLds &L = x.lds();
+    x.each([&](int lane) {
+        const uint32_t ep = (uint32_t)L.aux[2];
+        if (lane < 32) {
+            float v = 0.f;
+            if (lane == 6) v = 1.f;
+            if (c.kind == 3) { if (lane == 2) v = 0.5f; if (lane == 30) v = 1.f; }
+            else {
+                float z0 = 0.75f;
+                if (c.kind == 2) { z0 = c.start_pos[2]; if (lane == 0) v = c.start_pos[0]; if (lane == 1) v = c.start_pos[1]; }
+                if (lane == 2 || lane == 30) v = z0;
+                if (lane >= 7 && lane < 15) {
+                    const int j = lane - 7;
+                    uint32_t r[4];
+                    philox4x32(c, env, ep, (2u << 16) | (uint32_t)(j >> 2), 0u, r);
+                    const uint32_t rr = (j & 3) == 0 ? r[0] : ((j & 3) == 1 ? r[1] : ((j & 3) == 2 ? r[2] : r[3]));
+                    v = -0.1f + 0.2f * u01(rr);
+                }
+            }
+            L.st[lane] = v;
+        } else if (c.kind == 1 || c.kind == 3) {
+            const int i = lane - 32; /* lanes 32..47: item i */
+            if (i < 16) {
+                float px = 0.f, py = 0.f;
+                if (i < c.n_food + c.n_poison) respawn_item(c, env, ep, 1u, i, 0.f, 0.f, &px, &py);
+                L.items[2 * i] = px; L.items[2 * i + 1] = py;
+            }
+        }
+        if (lane < 16) L.u[lane] = 0.f;
+        if (lane < 8) L.tau[lane] = 0.f;
+        if (lane == 63 && c.kind == 2) {
+            uint32_t r[4];
+            philox4x32(c, env, ep, (3u << 16), 0u, r);
+            L.aux[3] = (int)(r[0] % (uint32_t)c.n_targets);
+        }
+    });
+    x.each([&](int lane) { if (lane == 0) L.aux[0] = 0; if (lane == 2) L.aux[2] = L.aux[2] + 1; });
+    compute_obs(x, c, env, false);
+    x.each([&](int lane) { if (lane == 31) L.st[31] = (c.kind == 0 || c.kind == 2) ? -L.scal[3] / c.dt : 0.f; }); /* upstream calc_potential */
+}
+
+template <class X>
+HRL_DEV void load_env(X &x, const DevBufs &b, const DevCfg &c, int e, bool with_actions) {
+    WaveLds &L = x.lds();
+    x.each([&](int lane) {
+        if (lane < 32) L.st[lane] = b.state[(size_t)e * 32 + lane];
+        else L.items[lane - 32] = b.items ? b.items[(size_t)e * 32 + (lane - 32)] : 0.f;
+        if (lane < 4) L.aux[lane] = b.aux[(size_t)e * 4 + lane];
+        if (lane < 8) L.act[lane] = (with_actions && lane < c.act_dim) ? b.actions[(size_t)e * c.act_dim + lane] : 0.f;
+    });
+}
+template <class X>
+HRL_DEV void store_env(X &x, const DevBufs &b, const DevCfg &c, int e) {
+    WaveLds &L = x.lds();
+    x.each([&](int lane) {
+        if (lane < 32) b.state[(size_t)e * 32 + lane] = L.st[lane];
+        else if (b.items) b.items[(size_t)e * 32 + (lane - 32)] = L.items[lane - 32];
+        if (lane < 4) b.aux[(size_t)e * 4 + lane] = L.aux[lane];
+        if (lane < c.obs_dim) b.obs[(size_t)e * c.obs_dim + lane] = L.obs[lane];
+    });
+}
+
+/* hrl_reset for one env (one wave) */
+template <class X>
+HRL_DEV void reset_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
+    if (b.mask && !b.mask[e]) return;
+    load_env(x, b, c, e, false);
+    reset_env(x, c, c.env_id_offset + e);
+    store_env(x, b, c, e);
+}
+
+/* hrl_step for one env (one wave) */
+template <class X>
+HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
+    WaveLds &L = x.lds();
+    const long long env = c.env_id_offset + e;
+    load_env(x, b, c, e, true);
+    x.each([&](int lane) {
+        if (lane < 16) {
+            L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f;
+            /* qvel (v, omega, joint rates) -> u (omega, v, joint rates) */
+            const int src = lane < 3 ? 15 + 3 + lane : (lane < 6 ? 15 + lane - 3 : 15 + lane);
+            L.u[lane] = lane < 14 ? L.st[src] : 0.f;
+        }
+        if (lane >= 16 && lane < 24) {
+            const int j = lane - 16;
+            if (c.kind == 3) { /* point_bot.py:28-31: a / |a| * 500 N in the world xy plane */
+                const float n = sqrtf(L.act[0] * L.act[0] + L.act[1] * L.act[1]);
+                L.tau[j] = j < 2 ? L.act[j] / n * c.point_force : 0.f;
+            } else L.tau[j] = c.torque_scale * clampf(L.act[j], -1.f, 1.f);
+        }
+    });
+    int qi = 0;
+    for (int s = 0; s < c.nsub; ++s) {
+        if (c.kind == 3) point_substep(x, c, qi); else ant_substep(x, c, qi);
+        qi ^= 1;
+    }
+    x.each([&](int lane) { /* back to the packed record */
+        if (lane < 15) L.st[lane] = L.q[qi][lane];
+        if (lane >= 16 && lane < 30) {
+            const int k = lane - 16; /* qvel index */
+            L.st[15 + k] = k < 3 ? L.u[3 + k] : (k < 6 ? L.u[k - 3] : L.u[k]);
+        }
+    });
+    compute_obs(x, c, env, true);
+    /* reward / done (uniform values, every lane computes them; lane-selected stores) */
+    x.each([&](int lane) {
+        float rew = 0.f, food = 0.f, dead = 0.f;
+        int done = 0;
+        if (c.kind == 1 || c.kind == 3) { /* ant_gather_env.py:99-119 */
+            for (int k = 0; k < c.n_food + c.n_poison; ++k) food += L.irew[k];
+            float alive = 1.f;
+            if (c.kind == 1) alive = (L.obs[0] + L.st[30] > 0.26f) ? 1.f : -1.f;
+            done = (alive < 0.f) || L.flags[0];
+            dead = alive < 0.f ? c.dying_cost : 0.f;
+            rew = food + dead;
+        } else if (c.kind == 0) { /* MjAnt.py:36-97 */
+            const float alive = L.st[2] > 0.26f ? 1.f : -1.f;
+            done = (alive < 0.f) || L.flags[0];
+            const float pot = -L.scal[3] / c.dt, progress = pot - L.st[31];
+            rew = ((alive + progress) + -0.1f * L.scal[5]) + 0.f;
+            L.red[0] = pot;
+        } else { /* upstream WalkerBaseBulletEnv.step, then ant_maze_bullet_env.py:84-95 */
+            const float alive = (L.s28[0] + L.st[30] > 0.26f) ? 1.f : -1.f;
+            int idone = alive < 0.f;
+            for (int i = 0; i < 28; ++i) if (!isfinite(L.s28[i])) idone = 1;
+            const float wtd = L.scal[3], pot = -wtd / c.dt, progress = pot - L.st[31];
+            float e1 = 0.f, e2 = 0.f;
+            for (int j = 0; j < NJ; ++j) { const float a = L.act[j]; e1 += fabsf(a * L.s28[9 + 2 * j]); e2 += a * a; }
+            const float electricity = -2.0f * (e1 / NJ) + -0.1f * (e2 / NJ);
+            const float inner = (((alive + progress) + electricity) + -0.1f * L.scal[5]) + 0.f;
+            rew = inner * c.inner_rew_weight;
+            done = idone;
+            const int t = L.aux[0] + 1;
+            if (wtd < c.tol) { if (c.done_at_target || (!c.done_at_target && t == c.max_steps - 1)) { rew += 1.f; done = 1; } }
+            if (t == c.max_steps - 1) done = 1;
+            if (c.targ_dist_rew && done) rew -= wtd;
+            L.red[0] = pot;
+        }
+        const int t_ep = L.aux[0] + 1;
+        if (c.max_episode_steps > 0 && t_ep >= c.max_episode_steps) done = 1; /* gym TimeLimit (__init__.py:15) */
+        L.scal[0] = rew; L.scal[1] = food; L.scal[2] = dead; L.flags[1] = done;
+        L.red[1] = L.st[29] + rew; L.red[2] = (float)t_ep;
+    });
+    x.each([&](int lane) { /* each LDS word below is read and written by one lane only */
+        if (lane == 0) { L.aux[0] = L.aux[0] + 1; b.reward[e] = L.scal[0]; b.done[e] = (uint8_t)L.flags[1]; }
+        if (lane == 1) L.aux[1] = L.aux[1] + 1;
+        if (lane == 2 && (c.kind == 0 || c.kind == 2)) L.st[31] = L.red[0];
+        if (lane == 3) L.st[29] = L.red[1];
+        if (lane >= 4 && lane < 8) {
+            const int k = lane - 4;
+            b.info[(size_t)e * 4 + k] = k == 0 ? L.scal[1] : (k == 1 ? L.scal[2] : (k == 2 ? L.red[1] : L.red[2]));
+        }
+    });
+    if (x.uniform(L.flags[1]) && c.auto_reset) reset_env(x, c, env);
+    store_env(x, b, c, e);
+}
+
+}  // namespace hrl

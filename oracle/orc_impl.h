@@ -56,6 +56,29 @@ static inline REAL FN(sum16_tree)(const REAL *x) {
 #define RFABS(x) fabs(x)
 #define RFMOD(x, y) fmod(x, y)
 #endif
+/* sin/cos of the dynamics.  The fp32 instantiation follows the operation-by-operation specification of DESIGN.md 3.7
+ * (so that two fp32 implementations agree bit for bit); the fp64 instantiation uses libm. */
+static inline void FN(dyn_sincos)(REAL x, REAL *sn, REAL *cs) {
+#if REAL_IS_FLOAT
+    float k = rintf(x * 0.636619772367581343f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z + -1.6666654611e-1f;
+    float sr = (ps * z) * r + r;
+    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    float cr = ((pc * z) * z - 0.5f * z) + 1.0f;
+    int q = ((int)k) & 3;
+    float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+#else
+    *sn = sin(x); *cs = cos(x);
+#endif
+}
 static inline REAL FN(clampr)(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
 /* hrl_config stores angles as float; the reference kwargs are python floats (np.pi, 2*np.pi): promote exact matches */
 static inline REAL FN(cfg_angle)(float v) {
@@ -360,8 +383,8 @@ void FN(orc_antmj_reward)(const REAL *state29, REAL potential_old, REAL potentia
 #define NJ 8
 #define NBODY 9
 #define NDOF 14
-#define MAXC 13
-#define MAXR 48
+#define MAXC 12
+#define MAXR 44
 
 typedef struct FN(orc_consts) {
     REAL h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z;
@@ -444,10 +467,10 @@ typedef struct FN(orc_dyn) {
 static void FN(spatial_inertia)(REAL I[6][6], REAL m, REAL alpha, REAL beta, const REAL *e, const REAL *c) {
     REAL cc = FN(v3dot)(c, c);
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
+        for (int j = i; j < 3; ++j) { /* upper triangle, mirrored: the matrix is exactly symmetric */
             REAL d = (i == j) ? R_(1) : R_(0);
-            I[i][j] = (alpha * d + beta * e[i] * e[j]) + m * (cc * d - c[i] * c[j]);
-            I[3 + i][3 + j] = m * d;
+            I[i][j] = I[j][i] = (alpha * d + beta * e[i] * e[j]) + m * (cc * d - c[i] * c[j]);
+            I[3 + i][3 + j] = I[3 + j][3 + i] = m * d;
         }
     /* top-right = m [c]x ; bottom-left = its transpose */
     REAL cx[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
@@ -502,7 +525,7 @@ static void FN(spd6_inverse)(REAL Ainv[6][6], REAL A[6][6]) {
 /* Kinematics at q, articulated inertias, and (if u/tau given) forward dynamics qdd, a0.
  * All spatial quantities are in world axes about the point O = current torso COM (an inertial frame that
  * instantaneously coincides with the torso), so parent<->child transforms are the identity. */
-static void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, const REAL *tau, FN(orc_dyn) * D) {
+void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, const REAL *tau, FN(orc_dyn) * D) {
     const REAL is2 = R_(0.70710678118654752440);
     REAL x = q[3], y = q[4], z = q[5], w = q[6];
     FN(v3set)(D->X, 1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y));
@@ -516,7 +539,9 @@ static void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL
     FN(v3set)(com[0], 0, 0, 0); mass[0] = K->m0;
     for (int l = 0; l < 4; ++l) {
         REAL qh = q[7 + 2 * l], qa = q[8 + 2 * l];
-        REAL ch = RCOS(qh), sh = RSIN(qh), ca = RCOS(qa), sa = RSIN(qa);
+        REAL ch, sh, ca, sa;
+        FN(dyn_sincos)(qh, &sh, &ch);
+        FN(dyn_sincos)(qa, &sa, &ca);
         REAL sx = R_(LEG_SX[l]), sy = R_(LEG_SY[l]), ax = R_(ANK_AX[l]), ay = R_(ANK_AY[l]), sg = R_(LEG_SIGMA[l]);
         REAL e1x = (sx * ch - sy * sh) * is2, e1y = (sx * sh + sy * ch) * is2; /* Rz(qh) * leg direction, torso frame */
         REAL axx = (ax * ch - ay * sh) * is2, axy = (ax * sh + ay * ch) * is2; /* Rz(qh) * ankle axis            */
@@ -562,8 +587,8 @@ static void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL
             D->invD[j] = R_(1) / Dj;
             D->uterm[j] = (tau ? tau[j] : R_(0)) - FN(dot6)(D->S[j], pA[child]);
             REAL Ia[6][6], pa_[6], Iac[6];
-            for (int a = 0; a < 6; ++a)
-                for (int b = 0; b < 6; ++b) Ia[a][b] = IA[child][a][b] - (D->U[j][a] * D->invD[j]) * D->U[j][b];
+            for (int a = 0; a < 6; ++a) /* symmetric rank-1 downdate, upper triangle mirrored */
+                for (int b = a; b < 6; ++b) { Ia[a][b] = IA[child][a][b] - (D->U[j][a] * D->invD[j]) * D->U[j][b]; Ia[b][a] = Ia[a][b]; }
             FN(matvec6)(Iac, Ia, D->cb[j]);
             REAL ud = D->uterm[j] * D->invD[j];
             for (int a = 0; a < 6; ++a) pa_[a] = (pA[child][a] + Iac[a]) + D->U[j][a] * ud;
@@ -766,7 +791,7 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
     for (int k = 0; k < 3; ++k) q[k] = q[k] + h * u[3 + k];
     {
         REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
-        if (th > R_(1e-6)) { REAL s = RSIN(R_(0.5) * th) / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = RCOS(R_(0.5) * th); }
+        if (th > R_(1e-6)) { REAL sh_, ch_; FN(dyn_sincos)(R_(0.5) * th, &sh_, &ch_); REAL s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
         else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
         REAL x = q[3], y = q[4], z = q[5], w = q[6]; /* q <- dq (x) q */
         REAL nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
@@ -821,7 +846,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
         const REAL *d = which == 0 ? cn[c] : (which == 1 ? t1 : t2);
         FN(v3cross)(Jr[nr], cr[c], d);
         for (int k = 0; k < 3; ++k) { Jr[nr][3 + k] = d[k]; Br[nr][k] = Jr[nr][k] / I; Br[nr][3 + k] = d[k] / m; }
-        invd[nr] = R_(1) / FN(dot6)(Jr[nr], Br[nr]);
+        { REAL prod[16] = {0}; for (int k = 0; k < 6; ++k) prod[k] = Jr[nr][k] * Br[nr][k]; invd[nr] = R_(1) / FN(sum16_tree)(prod); }
         bias[nr] = which == 0 ? (cd[c] > 0 ? cd[c] : K->erp_c * cd[c]) / h : R_(0);
         frn[nr] = which == 0 ? -1 : c;
         lam[nr] = 0; ++nr;
@@ -830,7 +855,9 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
         for (int r = 0; r < nr; ++r) {
             REAL l_lo = 0, l_hi = R_(1e30);
             if (frn[r] >= 0) { l_hi = K->mu * lam[frn[r]]; l_lo = -l_hi; }
-            REAL wv = FN(dot6)(Jr[r], un);
+            REAL prod[16] = {0};
+            for (int k = 0; k < 6; ++k) prod[k] = Jr[r][k] * un[k];
+            REAL wv = FN(sum16_tree)(prod);
             REAL ln = FN(clampr)(lam[r] - (wv + bias[r]) * invd[r], l_lo, l_hi), dl = ln - lam[r];
             lam[r] = ln;
             for (int k = 0; k < 6; ++k) un[k] = un[k] + Br[r][k] * dl;
@@ -839,7 +866,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
     for (int k = 0; k < 3; ++k) q[k] = q[k] + h * u[3 + k];
     {
         REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
-        if (th > R_(1e-6)) { REAL s = RSIN(R_(0.5) * th) / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = RCOS(R_(0.5) * th); }
+        if (th > R_(1e-6)) { REAL sh_, ch_; FN(dyn_sincos)(R_(0.5) * th, &sh_, &ch_); REAL s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
         else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
         REAL nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
         REAL ny = dq[3] * y - dq[0] * z + dq[1] * w + dq[2] * x;
@@ -1017,7 +1044,8 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     aux[0] = 0; aux[2] = (int32_t)(ep + 1);
     REAL feet[4] = {0, 0, 0, 0}, wtd = 0;
     FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0);
-    st[HRL_POTENTIAL_OFF] = -wtd / (E->K.h * R_(E->K.nsub)); /* upstream calc_potential = -dist/dt */
+    /* upstream calc_potential = -dist/dt; only the flat and maze kinds use it */
+    st[HRL_POTENTIAL_OFF] = (cfg->env_kind == HRL_ANT_FLAT || cfg->env_kind == HRL_ANT_MAZE) ? -wtd / (E->K.h * R_(E->K.nsub)) : R_(0);
 }
 
 /* One env step on the packed record.  Mirrors hrl_step() of include/hrl_envs.h. */
@@ -1116,6 +1144,31 @@ void FN(orc_step_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t
         FN(orc_env_step_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE,
                              items ? items + (size_t)i * HRL_ITEMS_STRIDE : 0, aux + (size_t)i * HRL_AUX_STRIDE,
                              actions + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, info + (size_t)i * HRL_INFO_STRIDE);
+}
+
+/* CPU baseline loop for bench.py: reset, then `steps` env steps of all cfg->num_envs envs with U(-1,1) actions from a
+ * 64-bit LCG, on `threads` OpenMP threads.  Returns wall seconds of the stepping loop; *checksum guards against DCE. */
+double FN(orc_bench)(const hrl_config *cfg, int steps, int threads, double *checksum) {
+    int n = cfg->num_envs, od = orc_obs_dim(cfg), ad = orc_act_dim(cfg);
+    REAL *state = calloc((size_t)n * HRL_STATE_STRIDE, sizeof(REAL)), *items = calloc((size_t)n * HRL_ITEMS_STRIDE, sizeof(REAL));
+    REAL *obs = calloc((size_t)n * od, sizeof(REAL)), *rew = calloc(n, sizeof(REAL)), *info = calloc((size_t)n * HRL_INFO_STRIDE, sizeof(REAL));
+    REAL *act = calloc((size_t)n * ad, sizeof(REAL));
+    int32_t *aux = calloc((size_t)n * HRL_AUX_STRIDE, sizeof(int32_t));
+    uint8_t *done = calloc(n, 1);
+    omp_set_num_threads(threads > 0 ? threads : 1);
+    FN(orc_reset_batch)(cfg, state, items, aux, 0, obs);
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    double t0 = omp_get_wtime(), sum = 0;
+    for (int t = 0; t < steps; ++t) {
+        for (int i = 0; i < n * ad; ++i) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; act[i] = R_((double)(lcg >> 11) * (2.0 / 9007199254740992.0) - 1.0); }
+        FN(orc_step_batch)(cfg, state, items, aux, act, obs, rew, done, info);
+        sum += rew[0];
+    }
+    double dt = omp_get_wtime() - t0;
+    for (int i = 0; i < n; ++i) sum += state[(size_t)i * HRL_STATE_STRIDE + 2];
+    if (checksum) *checksum = sum;
+    free(state); free(items); free(obs); free(rew); free(info); free(act); free(aux); free(done);
+    return dt;
 }
 
 /* ---------------------------------------------------------------------------------------------- KAT helpers (tests) */

@@ -1,0 +1,94 @@
+/*
+ * emu_lib.cpp -- TEST INFRASTRUCTURE: lock-step host executor for the phases of csrc/step_core.h.
+ *
+ * Runs the product's wave phases lane by lane on the CPU so that the kernel logic (indexing, phase ordering,
+ * LDS layout) can be checked against the oracle -- under AddressSanitizer/UBSan -- in a container without a GPU,
+ * before the same code is launched on an MI355X.  The product never loads this library.
+ * `reverse` runs the lanes of every phase in descending order: results must not depend on lane order, which
+ * exposes same-phase cross-lane LDS dependencies that a real wave (and the forward emulation) would hide.
+ */
+#define HRL_EMU 1
+#include "../../hrl_pybullet_envs_amd/csrc/host_cfg.h"
+
+using namespace hrl;
+
+struct CpuExec {
+    WaveLds L;
+    LaneRegs regs[64];
+    bool reverse = false;
+    CpuExec() { memset(&L, 0x7f, sizeof(L)); memset(regs, 0, sizeof(regs)); } /* poison LDS with large finite floats */
+    WaveLds &lds() { return L; }
+    LaneRegs &reg(int lane) { return regs[lane]; }
+    int uniform(int v) { return v; }
+    template <class F> void each(F f) {
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) f(lane);
+        else for (int lane = 63; lane >= 0; --lane) f(lane);
+    }
+    template <class P, class W, class Q> int each_compact(P pred, W write, Q post) {
+        decltype(pred(0)) r[64];
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) r[lane] = pred(lane);
+        else for (int lane = 63; lane >= 0; --lane) r[lane] = pred(lane);
+        int rank[64], n = 0;
+        for (int lane = 0; lane < 64; ++lane) { rank[lane] = n; if (r[lane].ok) ++n; }
+        if (!reverse) { for (int lane = 0; lane < 64; ++lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane]); } }
+        else { for (int lane = 63; lane >= 0; --lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane]); } }
+        return n;
+    }
+    template <class P, class C> void each_reduce16(P produce, C consume) {
+        float v[64];
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) v[lane] = produce(lane);
+        else for (int lane = 63; lane >= 0; --lane) v[lane] = produce(lane);
+        float s[4];
+        for (int g = 0; g < 4; ++g) s[g] = tree16(v + 16 * g);
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, s[lane >> 4]);
+        else for (int lane = 63; lane >= 0; --lane) consume(lane, s[lane >> 4]);
+    }
+};
+
+static DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
+    DevBufs d;
+    d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
+    d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask;
+    return d;
+}
+
+extern "C" {
+int emu_default_config(int32_t kind, hrl_config *c) { return default_config(kind, c); }
+int emu_obs_dim(const hrl_config *c) { return obs_dim(c); }
+int emu_act_dim(const hrl_config *c) { return act_dim(c); }
+const char *emu_validate(const hrl_config *c) { static std::string s; s = validate(c); return s.c_str(); }
+int emu_reset(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, int reverse) {
+    if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
+    DevCfg c; build_devcfg(*cfg, c);
+    DevBufs d = to_dev(b, mask);
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; reset_entry(x, d, c, e); }
+    return HRL_OK;
+}
+int emu_step(const hrl_config *cfg, const hrl_buffers *b, int reverse) {
+    if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
+    DevCfg c; build_devcfg(*cfg, c);
+    DevBufs d = to_dev(b, nullptr);
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; step_entry(x, d, c, e); }
+    return HRL_OK;
+}
+int emu_lds_bytes(void) { return (int)sizeof(WaveLds); }
+}
+
+/* debug dump of the articulated-body quantities after phases K and B (same layout as orc_dyn_dump_f32 minus qdd) */
+extern "C" void emu_dyn_dump(const hrl_config *cfg, const float *q, const float *u, const float *tau, float *out) {
+    DevCfg c; build_devcfg(*cfg, c);
+    CpuExec x;
+    WaveLds &L = x.lds();
+    for (int i = 0; i < 16; ++i) { L.q[0][i] = i < 15 ? q[i] : 0.f; L.u[i] = i < 14 ? u[i] : 0.f; }
+    for (int j = 0; j < 8; ++j) L.tau[j] = tau[j];
+    x.each([&](int lane) { phase_kin_aba(c, L, L.q[0], lane); });
+    x.each([&](int lane) { phase_base(c, L, lane); });
+    int o = 0;
+    for (int j = 0; j < 8; ++j) for (int k = 0; k < 6; ++k) out[o++] = L.S[j][k];
+    for (int j = 0; j < 8; ++j) for (int k = 0; k < 6; ++k) out[o++] = L.U[j][k];
+    for (int j = 0; j < 8; ++j) for (int k = 0; k < 6; ++k) out[o++] = L.cb[j][k];
+    for (int j = 0; j < 8; ++j) out[o++] = L.invD[j];
+    for (int j = 0; j < 8; ++j) out[o++] = L.uterm[j];
+    for (int k = 0; k < 36; ++k) out[o++] = L.I0inv[k];
+    for (int k = 0; k < 6; ++k) out[o++] = L.a0[k];
+}

@@ -1,0 +1,108 @@
+"""Kernel logic on the CPU: the product's wave phases (csrc/step_core.h) run by the lock-step host executor
+(tests/emu) against the independent scalar oracle.  Same compiler flags (-ffp-contract=off), same libm, and the
+algorithm pins every operation order, so the two implementations must agree BIT FOR BIT.  This is what lets the GPU
+tests attribute any difference to device arithmetic rather than to kernel logic."""
+import numpy as np
+import pytest
+
+import emu_env
+import orc
+from hrl_pybullet_envs_amd import _capi as K
+
+KINDS = [K.HRL_ANT_FLAT, K.HRL_ANT_GATHER, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER]
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_reset_bit_exact(kind):
+    cfg = orc.default_config(kind, num_envs=64, seed=7)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    assert np.array_equal(o.state, e.state) and np.array_equal(o.items, e.items) and np.array_equal(o.aux, e.aux)
+    assert np.array_equal(o.obs, e.obs)
+    # masked reset touches only the selected envs
+    mask = np.zeros(64, np.uint8); mask[::3] = 1
+    s0 = e.state.copy()
+    e.reset(mask); o.reset(mask)
+    assert np.array_equal(e.state[mask == 0], s0[mask == 0]) and np.array_equal(o.state, e.state)
+    assert np.all(e.aux[mask == 1, 2] == 2) and np.all(e.aux[mask == 0, 2] == 1)
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_free_running_bit_exact(kind):
+    """Both implementations run free (no state copying) for 120 steps with auto-reset and a short time limit."""
+    n = 24
+    cfg = orc.default_config(kind, num_envs=n, seed=3, auto_reset=1, max_episode_steps=50)
+    o, e, er = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg), emu_env.EmuEnv(cfg, reverse=True)
+    o.reset(); e.reset(); er.reset()
+    rng = np.random.RandomState(kind)
+    for t in range(120):
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        if kind == K.HRL_POINT_GATHER and t == 7:
+            a[0] = 0  # point_bot.py:29 divides by |a| -> NaN -> done -> auto-reset
+        o.step(a); e.step(a); er.step(a)
+        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
+            x, y, z = getattr(o, name), getattr(e, name), getattr(er, name)
+            assert np.array_equal(x, y, equal_nan=True), (t, name)
+            assert np.array_equal(y, z, equal_nan=True), (t, name, 'lane-order dependence')
+    assert o.aux[:, 2].min() >= 3  # every env went through at least two auto-resets
+
+
+def test_gather_pickups_happen_and_match():
+    """Drive the ants onto food: pickup, respawn draws and rewards must match exactly."""
+    n = 32
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=11, auto_reset=1)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    rng = np.random.RandomState(5)
+    picked = 0
+    for t in range(40):
+        # teleport every torso next to one of its items (identical in both copies)
+        k = rng.randint(0, 16, n)
+        xy = o.items.reshape(n, 16, 2)[np.arange(n), k] + rng.uniform(-0.6, 0.6, (n, 2)).astype(np.float32)
+        o.state[:, 0:2] = xy; e.state[:, 0:2] = xy
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        picked += int((o.info[:, 0] != 0).sum())
+        assert np.array_equal(o.items, e.items) and np.array_equal(o.rew, e.rew) and np.array_equal(o.obs, e.obs)
+    assert picked > 50
+
+
+def test_maze_reaches_targets_and_matches():
+    n = 32
+    cfg = orc.default_config(K.HRL_ANT_MAZE, num_envs=n, seed=2, auto_reset=1)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    rng = np.random.RandomState(9)
+    hits = 0
+    for t in range(20):
+        tgt = np.array([[2, -3], [2, 0], [2, 3], [-2, 4]], np.float32)[o.aux[:, 3]]
+        xy = tgt + rng.uniform(-2.5, 2.5, (n, 2)).astype(np.float32)
+        xy[:, 0] = np.clip(xy[:, 0], 1.6, 4.5)  # stay out of the box
+        o.state[:, 0:2] = xy; e.state[:, 0:2] = xy
+        o.state[:, 2] = 0.6; e.state[:, 2] = 0.6
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        hits += int((o.rew > 0).sum())
+        assert np.array_equal(o.rew, e.rew) and np.array_equal(o.done, e.done) and np.array_equal(o.state, e.state)
+    assert hits > 20
+
+
+def test_validation_errors():
+    import ctypes as C
+    L = emu_env.lib()
+    bad = orc.default_config(K.HRL_ANT_GATHER, n_food=12, n_poison=12)
+    assert b'n_food' in L.emu_validate(C.byref(bad))
+    bad = orc.default_config(K.HRL_ANT_GATHER, use_sensor=0)
+    assert b'use_sensor' in L.emu_validate(C.byref(bad))
+    bad = orc.default_config(K.HRL_ANT_MAZE, n_targets=0)
+    assert b'n_targets' in L.emu_validate(C.byref(bad))
+    assert L.emu_validate(C.byref(orc.default_config(K.HRL_ANT_MAZE))) == b''
+    assert L.emu_lds_bytes() <= 10240  # 16 waves per CU x 10 KB <= 160 KB LDS
+
+
+def test_product_defaults_equal_oracle_defaults():
+    import ctypes as C
+    for kind in KINDS:
+        a = K.hrl_config(); emu_env.lib().emu_default_config(kind, C.byref(a))
+        assert bytes(a) == bytes(orc.default_config(kind))
+        assert emu_env.lib().emu_obs_dim(C.byref(a)) == orc.obs_dim(a) == {0: 29, 1: 46, 2: 38, 3: 18}[kind]
