@@ -1,0 +1,36 @@
+"""AntMazeBulletEnv -- mirror of hrl_pybullet_envs/envs/ant_maze/ant_maze_bullet_env.py:17-178 on the HIP step."""
+from enum import Enum
+
+import numpy as np
+
+from ... import _capi as K
+from ... import _lib
+from ..base import BatchedGymEnv
+
+_eval_target = [-2, 4]
+_targets = ([2, -3], [2, 0], [2, 3], _eval_target)  # ant_maze_bullet_env.py:13-14
+
+
+class PositionEncoding(Enum):  # hrl_pybullet_envs/utils.py:66-68
+    normed_vec = 0
+    angle = 1
+
+
+class AntMazeBulletEnv(BatchedGymEnv):
+    def __init__(self, n_bins: int = 10, sensor_range: float = 5, sensor_span: float = 2 * np.pi, targets=_targets,
+                 target_encoding=0, sense_target=False, sense_walls=True, done_at_target=True,
+                 max_steps=-1, tol=1.5, inner_rew_weight=0, targ_dist_rew=False, seed=None, debug=0,
+                 num_envs=1, device='cuda:0'):
+        if isinstance(target_encoding, int):
+            target_encoding = PositionEncoding(target_encoding)  # ValueError on anything but 0/1, as in the reference
+        cfg = _lib.default_config(K.HRL_ANT_MAZE, n_bins=int(n_bins), sensor_range=float(sensor_range),
+                                  sensor_span=float(sensor_span), targets=[tuple(t) for t in targets],
+                                  target_encoding=int(target_encoding.value), sense_target=int(bool(sense_target)),
+                                  sense_walls=int(bool(sense_walls)), done_at_target=int(bool(done_at_target)),
+                                  max_steps=int(max_steps), tol=float(tol), inner_rew_weight=float(inner_rew_weight),
+                                  targ_dist_rew=int(bool(targ_dist_rew)))
+        self.n_bins, self.sensor_range, self.sensor_span = n_bins, float(sensor_range), sensor_span
+        self.targets, self.sense_walls, self.sense_target = targets, sense_walls, sense_target
+        self.done_at_target, self.max_steps, self.tol = done_at_target, max_steps, tol
+        self.inner_rew_weight, self.targ_dist_rew, self.target_encoding, self.debug = inner_rew_weight, targ_dist_rew, target_encoding, debug
+        self._finish_init(cfg, num_envs, device, seed)

@@ -1,0 +1,115 @@
+"""Host-side mirror of the reference's gym.Env interface on top of the batched HIP step.
+
+The reference's boundary is the old-gym (<= 0.21) class API (hrl_pybullet_envs/__init__.py:11-16, README.md:24-34):
+    reset() -> obs ;  step(a) -> (obs, rew, done, info) ;  seed(s) ;  observation_space / action_space
+`num_envs == 1` (default) behaves like the reference object: numpy in, numpy/float/bool out, `info` a dict of
+python numbers, and the gym TimeLimit of the registration (max_episode_steps=2000) applied inside.  `num_envs > 1`
+is the batched form: torch tensors resident on the GPU, `done` envs auto-reset (the returned obs is then the first
+observation of the next episode, as vector-env wrappers do).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _capi as K
+from .. import _lib
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is optional: used when it is not installed)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low = np.full(shape, low, dtype=dtype)
+        self.high = np.full(shape, high, dtype=dtype)
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def __repr__(self):
+        return f'Box{self.shape}'
+
+
+def _make_box(low, high, shape):
+    try:
+        from gym.spaces import Box as GymBox  # pragma: no cover - gym is absent in the build image
+        return GymBox(low, high, shape=shape, dtype=np.float32)
+    except Exception:
+        return Box(low, high, shape)
+
+
+class BatchedGymEnv:
+    """Common machinery; subclasses fill `self._cfg` (hrl_config) from their reference constructor kwargs."""
+
+    metadata = {'render.modes': []}
+    reward_range = (-float('inf'), float('inf'))
+    max_episode_steps = 2000  # hrl_pybullet_envs/__init__.py:15
+
+    def _finish_init(self, cfg, num_envs, device, seed):
+        if num_envs < 1:
+            raise ValueError('num_envs must be >= 1')
+        cfg.num_envs = int(num_envs)
+        cfg.max_episode_steps = self.max_episode_steps
+        cfg.auto_reset = 1 if num_envs > 1 else 0
+        cfg.seed = 0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._cfg, self._device, self.num_envs = cfg, device, int(num_envs)
+        L = _lib.lib()
+        od, ad = L.hrl_obs_dim(C.byref(cfg)), L.hrl_act_dim(C.byref(cfg))
+        self.observation_space = _make_box(-np.inf, np.inf, (od,))
+        self.action_space = _make_box(-1.0, 1.0, (ad,))
+        self._env = None
+
+    # lazily created so that constructing an env (e.g. to read its spaces) needs no GPU
+    def _backend(self):
+        if self._env is None:
+            from ..vec_env import BatchedEnv
+            self._env = BatchedEnv(self._cfg, self._device)
+        return self._env
+
+    def seed(self, seed=None):
+        """ant_gather_env.py:63-66 / ant_maze_bullet_env.py:99-102: reseeds the env's RNG streams."""
+        self._cfg.seed = 0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        if self._env is not None:
+            self._env.close()
+            self._env = None
+        return [seed]
+
+    def reset(self):
+        obs = self._backend().reset()
+        if self.num_envs == 1:
+            return obs[0].double().cpu().numpy()
+        return obs
+
+    def step(self, a):
+        import torch
+        env = self._backend()
+        if self.num_envs == 1:
+            act = torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(1, -1), device=env.device)
+            obs, rew, done, info = env.step(act)
+            row = env.info[0].cpu().numpy()
+            d = bool(done[0].item())
+            out = {'food_rew': float(row[0]), 'dead_rew': float(row[1])} if self._gather_info else {}
+            if d and env.aux[0, 0].item() >= self.max_episode_steps > 0:
+                out['TimeLimit.truncated'] = True
+            return obs[0].double().cpu().numpy(), float(rew[0].item()), d, out
+        return env.step(a)
+
+    def close(self):
+        if self._env is not None:
+            self._env.close()
+            self._env = None
+
+    def render(self, mode='human'):
+        raise NotImplementedError('rendering is out of scope (SURVEY.md section 2, row 15)')
+
+    _gather_info = False
+
+    @property
+    def unwrapped(self):
+        return self

@@ -16,8 +16,9 @@ class BatchedEnv:
     def __init__(self, cfg, device='cuda:0'):
         self.cfg = cfg
         self.device = torch.device(device)
-        if self.device.type != 'cuda':
-            raise _lib.HrlError('BatchedEnv needs a GPU device (no CPU path)')
+        if self.device.type != 'cuda' or not torch.cuda.is_available():
+            raise _lib.HrlError('BatchedEnv needs an MI355X (torch.cuda.is_available() is False or a CPU device was '
+                                'requested): the env step has no CPU path')
         L = _lib.lib()
         self.num_envs = cfg.num_envs
         self.obs_dim, self.act_dim = L.hrl_obs_dim(C.byref(cfg)), L.hrl_act_dim(C.byref(cfg))

@@ -1,7 +1,12 @@
 """GPU parity: HIP kernels (through the C-ABI) vs the fp32 CPU oracle on identical (state, items, action).
 
-Tolerance (single env step from identical inputs): |d| <= 2e-4 + 2e-5 * |x| on the packed state and observations,
-rewards / done / item positions exact except where a fp32 rounding difference flips a threshold (counted, bounded).
+Stated tolerance for one env step from identical inputs:
+  * packed state (qpos, qvel, episode return, potential), item positions, aux counters, reward, done: BIT-EXACT.
+    The algorithm pins every fp32 operation (no FMA contraction, specified sin/cos, IEEE divide/sqrt), so the device
+    and the host must produce the same bits.
+  * observations: |d| <= 2e-6.  They pass through library atan2f/asinf/sinf/cosf, which differ by an ulp or two
+    between the device math library and glibc; a sensor-bin edge can flip on such a difference (measure-zero event,
+    counted and bounded below).
 """
 import numpy as np
 import pytest
@@ -11,6 +16,8 @@ import orc
 from hrl_pybullet_envs_amd import _capi as K
 
 pytestmark = pytest.mark.gpu
+KINDS = [K.HRL_ANT_GATHER, K.HRL_ANT_FLAT, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER]
+OBS_ATOL = 2e-6
 
 
 def make(kind, n, seed=3, **kw):
@@ -22,63 +29,155 @@ def make(kind, n, seed=3, **kw):
     return BatchedEnv(cfg, 'cuda:0'), orc.OracleEnv(ocfg, np.float32)
 
 
-def close(a, b, atol=2e-4, rtol=2e-5):
-    return np.abs(a - b) <= atol + rtol * np.abs(b)
+def push(g, o):
+    g.state.copy_(torch.from_numpy(o.state)); g.items.copy_(torch.from_numpy(o.items)); g.aux.copy_(torch.from_numpy(o.aux))
 
 
-@pytest.mark.parametrize('kind', [K.HRL_ANT_GATHER, K.HRL_ANT_FLAT, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER])
+def obs_bad_rows(gobs, oobs):
+    return (np.abs(gobs - oobs) > OBS_ATOL).any(axis=1)
+
+
+@pytest.mark.parametrize('kind', KINDS)
 def test_reset_matches_oracle(kind):
-    g, o = make(kind, 256)
+    g, o = make(kind, 512)
     g.reset(); o.reset()
     torch.cuda.synchronize()
     assert np.array_equal(g.aux.cpu().numpy(), o.aux)
-    np.testing.assert_allclose(g.state.cpu().numpy(), o.state, atol=1e-6, rtol=1e-6)
-    np.testing.assert_allclose(g.items.cpu().numpy(), o.items, atol=1e-6)
-    np.testing.assert_allclose(g.obs.cpu().numpy(), o.obs, atol=2e-5, rtol=1e-5)
+    assert np.array_equal(g.state.cpu().numpy(), o.state)
+    assert np.array_equal(g.items.cpu().numpy(), o.items)
+    assert obs_bad_rows(g.obs.cpu().numpy(), o.obs).sum() == 0
+    mask = torch.zeros(512, dtype=torch.uint8); mask[::5] = 1
+    g.reset(mask.cuda()); o.reset(mask.numpy())
+    assert np.array_equal(g.state.cpu().numpy(), o.state) and np.array_equal(g.aux.cpu().numpy(), o.aux)
 
 
-@pytest.mark.parametrize('kind', [K.HRL_ANT_GATHER, K.HRL_ANT_FLAT, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER])
+@pytest.mark.parametrize('kind', KINDS)
 def test_single_step_parity_along_trajectory(kind):
-    n, T = 128, 60
-    g, o = make(kind, n)
+    """Identical inputs every step (the oracle's state is copied to the device), 80 steps of a random-action rollout
+    with auto-reset and a short time limit so that resets, pickups and deaths are all exercised."""
+    n, T = 256, 80
+    g, o = make(kind, n, max_episode_steps=37)
     g.reset(); o.reset()
     rng = np.random.RandomState(0)
-    bad_state = bad_obs = bad_flag = total = 0
+    obs_flips = 0
     for t in range(T):
         a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
-        # identical inputs: the oracle's state is copied to the device before every step
-        g.state.copy_(torch.from_numpy(o.state)); g.items.copy_(torch.from_numpy(o.items)); g.aux.copy_(torch.from_numpy(o.aux))
+        if kind == K.HRL_POINT_GATHER and t == 5:
+            a[3] = 0  # NaN force path (point_bot.py:29)
+        push(g, o)
         go, gr, gd, gi = g.step(torch.from_numpy(a).cuda())
         o.step(a)
         torch.cuda.synchronize()
-        flip = (gd.cpu().numpy() != o.done) | (gr.cpu().numpy() != o.rew)
-        ok_s = close(g.state.cpu().numpy(), o.state).all(axis=1)
-        ok_o = close(go.cpu().numpy(), o.obs).all(axis=1)
-        bad_flag += int(flip.sum()); bad_state += int((~ok_s & ~flip).sum()); bad_obs += int((~ok_o & ~flip).sum())
-        total += n
-        assert np.isfinite(g.state.cpu().numpy()).all() or kind == K.HRL_POINT_GATHER
-    # a threshold flip (contact activation, pickup radius, sensor bin edge) is a measure-zero event
-    assert bad_flag <= 2, (bad_flag, total)
-    assert bad_state <= max(2, total // 500), (bad_state, total)
-    assert bad_obs <= max(2, total // 500), (bad_obs, total)
+        assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True), t
+        assert np.array_equal(g.items.cpu().numpy(), o.items), t
+        assert np.array_equal(g.aux.cpu().numpy(), o.aux), t
+        assert np.array_equal(gd.cpu().numpy(), o.done), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew), t
+        assert np.array_equal(g.info.cpu().numpy(), o.info), t
+        gob = go.cpu().numpy()
+        fin = np.isfinite(o.obs).all(axis=1)
+        obs_flips += int(obs_bad_rows(gob[fin], o.obs[fin]).sum())
+    assert obs_flips <= 2, obs_flips  # sensor-bin edge flips only
+    assert o.aux[:, 2].min() >= 3     # every env was auto-reset at least twice
 
 
-def test_free_running_statistics_match():
-    """Trajectories are chaotic, so only statistics are compared when both run free for 300 steps."""
-    n = 512
+def test_free_running_stays_bit_exact():
+    """No state copying: device and oracle run 150 steps independently from the same seed and stay identical."""
+    n = 256
     g, o = make(K.HRL_ANT_GATHER, n)
     g.reset(); o.reset()
     rng = np.random.RandomState(1)
-    gsum = osum = 0.0
-    for t in range(300):
+    for t in range(150):
         a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
-        _, gr, _, _ = g.step(torch.from_numpy(a).cuda())
-        o.step(a)
-        gsum += float(gr.sum()); osum += float(o.rew.sum())
-    gs, os_ = g.state.cpu().numpy(), o.state
-    assert np.isfinite(gs).all()
-    assert abs(gs[:, 2].mean() - os_[:, 2].mean()) < 0.05          # mean torso height
-    assert abs(gsum - osum) <= 0.2 * max(20.0, abs(osum))           # pickups + deaths
+        g.step(torch.from_numpy(a).cuda()); o.step(a)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.state.cpu().numpy(), o.state) and np.array_equal(g.items.cpu().numpy(), o.items)
+
+
+def test_pickups_and_respawn_match():
+    n = 256
+    g, o = make(K.HRL_ANT_GATHER, n, seed=11)
+    g.reset(); o.reset()
+    rng = np.random.RandomState(5)
+    picked = 0
+    for t in range(20):
+        k = rng.randint(0, 16, n)
+        xy = o.items.reshape(n, 16, 2)[np.arange(n), k] + rng.uniform(-0.6, 0.6, (n, 2)).astype(np.float32)
+        o.state[:, 0:2] = xy
+        push(g, o)
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        _, gr, _, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        picked += int((o.info[:, 0] != 0).sum())
+        assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(gr.cpu().numpy(), o.rew)
+        assert np.array_equal(gi['food_rew'].cpu().numpy(), o.info[:, 0])
+    assert picked > 400
+
+
+@pytest.mark.parametrize('kind,n', [(K.HRL_ANT_GATHER, 4096), (K.HRL_ANT_FLAT, 4096), (K.HRL_ANT_MAZE, 8192)])
+def test_full_size_properties(kind, n):
+    """BASELINE.json sizes: size-independent properties + oracle parity on a sampled subset of rows."""
+    g, _ = make(kind, n, seed=21)
+    g.reset()
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    acts = torch.rand(60, n, 8, device='cuda', generator=gen) * 2 - 1
+    for t in range(59):
+        g.step(acts[t])
+    # sampled-row parity at full size: 256 random rows re-run on the oracle from the device's own state
+    rows = np.random.RandomState(3).choice(n, 256, replace=False)
+    st, it, au = g.state.cpu().numpy(), g.items.cpu().numpy(), g.aux.cpu().numpy()
+    obs, rew, done, _ = g.step(acts[59])
+    torch.cuda.synchronize()
+    a_np = acts[59].cpu().numpy()
+    for r in rows[:64]:  # the oracle keys RNG by global id: run each sampled row as its own 1-env shard
+        o = orc.OracleEnv(orc.default_config(kind, num_envs=1, seed=21, auto_reset=1, env_id_offset=int(r)), np.float32)
+        o.state[0] = st[r]; o.items[0] = it[r]; o.aux[0] = au[r]
+        o.step(a_np[r:r + 1])
+        assert np.array_equal(g.state[r].cpu().numpy(), o.state[0]), r
+        assert float(rew[r]) == float(o.rew[0]) and int(done[r]) == int(o.done[0])
+    s = g.state.cpu().numpy()
+    assert np.isfinite(s).all()
+    assert np.abs(np.linalg.norm(s[:, 3:7], axis=1) - 1).max() < 1e-5          # unit quaternions
+    assert np.all(np.abs(s[:, 21:29]) <= 100.0)                                 # joint-rate clamp
+    ob = obs.cpu().numpy()
+    assert np.isfinite(ob).all()
+    if kind == K.HRL_ANT_GATHER:
+        itf = g.items.cpu().numpy().reshape(n, 16, 2)
+        assert np.all(np.abs(itf) <= 7.0)                                       # gather_scene.py:52-62
+        assert np.all(ob[:, 26:] >= 0) and np.all(ob[:, 26:] <= 1)             # sensor intensities
+        assert np.all(np.abs(ob[:, :26]) <= 5)                                  # upstream clip
+        assert np.all(np.abs(s[:, 0:2]) < 7.6)                                  # walls hold the ant in the arena
+    if kind == K.HRL_ANT_MAZE:
+        assert np.all(ob[:, 28:] >= 0) and np.all(ob[:, 28:] <= 1)
+        assert np.allclose(np.linalg.norm(ob[:, 26:28], axis=1), 1, atol=1e-5)  # normed target vector
+        assert np.all(np.abs(s[:, 0]) < 5.1) and np.all(np.abs(s[:, 1]) < 9.1)
+
+
+def test_batch_composition_invariance():
+    """Env i's trajectory does not depend on which other envs share the launch (global-id RNG, no cross-env state)."""
+    big, _ = make(K.HRL_ANT_GATHER, 4096, seed=5)
+    small, _ = make(K.HRL_ANT_GATHER, 128, seed=5, env_id_offset=1000)
+    big.reset(); small.reset()
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    for t in range(40):
+        a = torch.rand(4096, 8, device='cuda', generator=gen) * 2 - 1
+        big.step(a); small.step(a[1000:1128].contiguous())
+    assert torch.equal(big.state[1000:1128], small.state) and torch.equal(big.items[1000:1128], small.items)
+
+
+def test_mixed_ant_point_shard():
+    """BASELINE config 5 shape on one GPU: first half AntGather, second half PointGather, two launches per step."""
+    n = 512
+    ant, oa = make(K.HRL_ANT_GATHER, n, seed=8)
+    pt, op = make(K.HRL_POINT_GATHER, n, seed=8, env_id_offset=n)
+    ant.reset(); pt.reset(); oa.reset(); op.reset()
+    rng = np.random.RandomState(2)
+    for t in range(30):
+        a8 = rng.uniform(-1, 1, (n, 8)).astype(np.float32); a2 = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        ant.step(torch.from_numpy(a8).cuda()); pt.step(torch.from_numpy(a2).cuda())
+        oa.step(a8); op.step(a2)
+    assert np.array_equal(ant.state.cpu().numpy(), oa.state) and np.array_equal(pt.state.cpu().numpy(), op.state)
+    returns = torch.cat([ant.info[:, 2], pt.info[:, 2]])
+    assert returns.shape == (2 * n,) and bool(torch.isfinite(returns).all())
 
 
 def test_get_set_state_roundtrip():
@@ -94,11 +193,11 @@ def test_get_set_state_roundtrip():
 def test_determinism_on_device():
     outs = []
     for rep in range(2):
-        g, _ = make(K.HRL_ANT_GATHER, 256, seed=9)
+        g, _ = make(K.HRL_ANT_GATHER, 1024, seed=9)
         g.reset()
         gen = torch.Generator(device='cuda').manual_seed(0)
         for t in range(50):
-            a = torch.rand(256, 8, device='cuda', generator=gen) * 2 - 1
+            a = torch.rand(1024, 8, device='cuda', generator=gen) * 2 - 1
             g.step(a)
         torch.cuda.synchronize()
         outs.append((g.state.clone(), g.items.clone(), g.obs.clone()))

@@ -1,0 +1,97 @@
+"""Host logic that needs no GPU: the C-ABI library loads and exports every symbol of include/hrl_envs.h, the ctypes
+mirror matches the C structs, the env classes mirror the reference's constructor API, sharding helpers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+from hrl_pybullet_envs_amd import _capi as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_library_exports_every_declared_symbol():
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.build import build
+    build()  # hipcc cross-compiles for gfx950 without a GPU
+    hdr = open(os.path.join(ROOT, 'include', 'hrl_envs.h')).read()
+    declared = set(re.findall(r'\b(hrl_[a-z_]+)\s*\(', hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for s in declared:
+        assert hasattr(L, s)
+    assert L.hrl_backend() == b'hip-gfx950'
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    from hrl_pybullet_envs_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    cfg = _lib.default_config(K.HRL_ANT_GATHER, num_envs=4)
+    h = C.c_void_p()
+    assert _lib.lib().hrl_create(C.byref(cfg), C.byref(h)) == K.HRL_ERR_NO_DEVICE
+    assert b'no HIP device' in _lib.lib().hrl_last_error()
+    import hrl_pybullet_envs_amd as H
+    with pytest.raises(_lib.HrlError):
+        H.make('AntGatherBulletEnv-v0').reset()
+
+
+def test_struct_layout_matches_header():
+    from hrl_pybullet_envs_amd import _lib
+    # sizes as the C compiler sees them (the oracle is compiled from the same header)
+    src = '#include "include/hrl_envs.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu", sizeof(hrl_config), sizeof(hrl_model), sizeof(hrl_buffers));return 0;}'
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(src)
+        subprocess.check_call(['gcc', '-I', ROOT, '-o', os.path.join(d, 't'), os.path.join(d, 't.c')], cwd=ROOT)
+        out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
+    assert [int(x) for x in out] == [C.sizeof(K.hrl_config), C.sizeof(K.hrl_model), C.sizeof(K.hrl_buffers)]
+    # product defaults == oracle defaults, byte for byte, for every kind
+    for kind in range(4):
+        assert bytes(_lib.default_config(kind)) == bytes(orc.default_config(kind))
+
+
+def test_bad_config_is_rejected_with_a_reason():
+    from hrl_pybullet_envs_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    for kw, frag in ((dict(n_food=12, n_poison=12), b'n_food'), (dict(num_envs=0), b'num_envs'),
+                     (dict(abi_version=99), b'abi_version'), (dict(use_sensor=0), b'use_sensor')):
+        cfg = _lib.default_config(K.HRL_ANT_GATHER, **kw)
+        assert L.hrl_create(C.byref(cfg), C.byref(h)) == K.HRL_ERR_BAD_ARG
+        assert frag in L.hrl_last_error()
+    assert L.hrl_step(None, None, None) == K.HRL_ERR_BAD_ARG
+
+
+def test_env_classes_mirror_reference_constructor_api():
+    import hrl_pybullet_envs_amd as H
+    e = H.AntGatherBulletEnv()
+    assert e.observation_space.shape == (46,) and e.action_space.shape == (8,)   # ant_gather_env.py:53-55
+    assert H.AntGatherBulletEnv(n_bins=6).observation_space.shape == (38,)
+    assert H.PointGatherBulletEnv().observation_space.shape == (18,)             # gather_base.py:54-55
+    assert H.PointGatherBulletEnv().action_space.shape == (2,)                   # point_bot.py:15
+    assert H.AntMazeBulletEnv().observation_space.shape == (38,)                 # ant_maze_bullet_env.py:54-57
+    assert H.AntMazeBulletEnv(sense_target=True, n_bins=8).observation_space.shape == (26 + 8 + 8,)
+    assert H.AntMazeBulletEnv(sense_walls=False).observation_space.shape == (28,)
+    assert H.AntMjEnv().observation_space.shape == (29,)                         # MjAnt.py:15
+    with pytest.raises(ValueError):
+        H.AntMazeBulletEnv(target_encoding=5)                                    # PositionEncoding(5), utils.py:66-68
+    assert isinstance(H.make('AntMazeBulletEnv-v0', tol=2.0), H.AntMazeBulletEnv)
+    with pytest.raises(KeyError):
+        H.make('AntMjBulletEnv-0')  # README.md:13 names an id that is never registered (SURVEY C-12)
+    c = H.AntGatherBulletEnv(n_food=4, n_poison=3, world_size=(9, 11), dying_cost=-3, seed=5)._cfg
+    assert (c.n_food, c.n_poison, c.world_size[0], c.world_size[1], c.dying_cost, c.seed) == (4, 3, 9.0, 11.0, -3.0, 5)
+    assert c.max_episode_steps == 2000 and c.auto_reset == 0                     # __init__.py:15
+
+
+def test_shard_range_partitions_all_envs():
+    from hrl_pybullet_envs_amd.dist import shard_range
+    for total, world in ((32768, 8), (4096, 3), (10, 4), (7, 8)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (o0, c0), (o1, _) in zip(spans, spans[1:]):
+            assert o0 + c0 == o1
