@@ -63,15 +63,17 @@ struct GpuExec {
     }
 };
 
-__global__ __launch_bounds__(64, 4) void k_step(DevBufs b, DevCfg c) {
+/* The ~0.5 KB of constants are read through a pointer (scalar loads on demand, scalar-cache resident) rather than
+ * passed by value: by-value kernel arguments were all preloaded into SGPRs and spilled (86 SGPR spills). */
+__global__ __launch_bounds__(64, 4) void k_step(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
     GpuExec x{L, {0.f, 0.f}, (int)threadIdx.x};
-    step_entry(x, b, c, (int)blockIdx.x);
+    step_entry(x, b, *cp, (int)blockIdx.x);
 }
-__global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, DevCfg c) {
+__global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
     GpuExec x{L, {0.f, 0.f}, (int)threadIdx.x};
-    reset_entry(x, b, c, (int)blockIdx.x);
+    reset_entry(x, b, *cp, (int)blockIdx.x);
 }
 /* packed record <-> split qpos[N][15], qvel[N][14] */
 __global__ void k_get_state(const float *state, float *qpos, float *qvel, int n) {
@@ -106,6 +108,8 @@ DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
 struct hrl_handle {
     hrl_config cfg;
     DevCfg dc;
+    DevCfg *d_dc; /* device copy of the constants (the only device memory the library owns) */
+    int device;
 };
 
 extern "C" {
@@ -128,10 +132,20 @@ int hrl_create(const hrl_config *cfg, hrl_handle **out) {
     hrl_handle *h = new hrl_handle;
     h->cfg = *cfg;
     build_devcfg(*cfg, h->dc);
+    h->d_dc = nullptr;
+    hipError_t e2 = hipGetDevice(&h->device);
+    if (e2 == hipSuccess) e2 = hipMalloc((void **)&h->d_dc, sizeof(DevCfg));
+    if (e2 == hipSuccess) e2 = hipMemcpy(h->d_dc, &h->dc, sizeof(DevCfg), hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) {
+        if (h->d_dc) (void)hipFree(h->d_dc);
+        delete h;
+        return hip_fail(e2, "hrl_create: device constants");
+    }
     *out = h;
     return HRL_OK;
 }
 int hrl_destroy(hrl_handle *h) {
+    if (h && h->d_dc) (void)hipFree(h->d_dc);
     delete h;
     return HRL_OK;
 }
@@ -140,7 +154,7 @@ int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *st
     if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_reset: null handle or buffer");
     const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
     if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: gather kinds need the items buffer");
-    hipLaunchKernelGGL(k_reset, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), h->dc);
+    hipLaunchKernelGGL(k_reset, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_reset launch");
 }
@@ -150,7 +164,7 @@ int hrl_step(hrl_handle *h, const hrl_buffers *b, void *stream) {
         return fail(HRL_ERR_BAD_ARG, "hrl_step: null handle or buffer");
     const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
     if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: gather kinds need the items buffer");
-    hipLaunchKernelGGL(k_step, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), h->dc);
+    hipLaunchKernelGGL(k_step, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_step launch");
 }

@@ -86,6 +86,11 @@ struct DevBufs {
 struct WaveLds {
     union {
         F2 JB[MAXR * JBS];       /* (J[r][d], B[r][d] = (M^-1 J^T)[d]) */
+        struct {                 /* phase K1 -> K2 hand-off (dead before the rows are built) */
+            float Iaf[4][24];    /* articulated inertia of the foot seen through the ankle (upper triangle) */
+            float paf[4][8];     /* its bias force */
+            float kleg[4][16];   /* e1[3], caux[3], vx[6]: aux axis, aux COM, aux spatial velocity */
+        };
         struct {
             float s28[32];       /* upstream 28-vector (WalkerBase.calc_state) */
             float obs[64];
@@ -211,37 +216,35 @@ HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
         t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
     }
 }
-/* explicit inverse of an SPD 6x6 (upper-triangle storage in, full 36 out) via Cholesky */
-HRL_DEV void spd6_inverse(float *Ainv, const float *A) {
-    float L[6][6], Li[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { L[i][j] = 0.f; Li[i][j] = 0.f; }
+/* explicit inverse of an SPD 6x6 via Cholesky, A = L L^T, Ainv = Linv^T Linv; all three in triangular storage
+ * (tri(i, j), i >= j) so that the whole computation stays in registers */
+HRL_DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+HRL_DEV void spd6_inverse(float *Ainv /* [21], si() layout */, const float *A /* [21], si() layout */) {
+    float Lm[21], Li[21];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         float s = A[si(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        for (int k = 0; k < j; ++k) s -= Lm[tri(j, k)] * Lm[tri(j, k)];
         float d = sqrtf(s), id = 1.f / d;
-        L[j][j] = d;
+        Lm[tri(j, j)] = d;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             float t = A[si(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
-            L[i][j] = t * id;
+            for (int k = 0; k < j; ++k) t -= Lm[tri(i, k)] * Lm[tri(j, k)];
+            Lm[tri(i, j)] = t * id;
         }
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        Li[j][j] = 1.f / L[j][j];
+        Li[tri(j, j)] = 1.f / Lm[tri(j, j)];
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             float t = 0.f;
 #pragma unroll
-            for (int k = j; k < i; ++k) t -= L[i][k] * Li[k][j];
-            Li[i][j] = t / L[i][i];
+            for (int k = j; k < i; ++k) t -= Lm[tri(i, k)] * Li[tri(k, j)];
+            Li[tri(i, j)] = t / Lm[tri(i, i)];
         }
     }
 #pragma unroll
@@ -250,8 +253,8 @@ HRL_DEV void spd6_inverse(float *Ainv, const float *A) {
         for (int j = 0; j <= i; ++j) {
             float t = 0.f;
 #pragma unroll
-            for (int k = i; k < 6; ++k) t += Li[k][i] * Li[k][j];
-            Ainv[i * 6 + j] = t; Ainv[j * 6 + i] = t;
+            for (int k = i; k < 6; ++k) t += Li[tri(k, i)] * Li[tri(k, j)];
+            Ainv[si(j, i)] = t;
         }
 }
 /* Philox4x32-10, keyed like the oracle: key = (seed_lo, seed_hi ^ env_hi), counter = (env_lo, index, w2, w3) */
@@ -271,8 +274,10 @@ HRL_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f
 
 /* ================================================================================================= ANT SUBSTEP */
 
-/* Phase K (leg map): kinematics of one leg, its two articulated-body joints (ankle, hip), results to LDS. */
-HRL_DEV void phase_kin_aba(const DevCfg &c, WaveLds &L, const float *q, int lane) {
+/* Phase K1 (leg map): kinematics of one leg and its ankle joint (foot -> aux), results to LDS.
+ * The two articulated-body joints of a leg are split over two phases so that only one 6x6 inertia is live in
+ * registers at a time (<= 128 VGPRs without scratch). */
+HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int lane) {
     const float is2 = 0.70710678118654752440f;
     const int l = (lane >> 4) & 3;
     float x = q[3], y = q[4], z = q[5], w = q[6];
@@ -300,6 +305,13 @@ HRL_DEV void phase_kin_aba(const DevCfg &c, WaveLds &L, const float *q, int lane
         caux[k] = ph[k] + (c.L1 * 0.5f) * e1[k];
         cfoot[k] = pa[k] + (c.L2 * 0.5f) * e2[k];
     }
+    const int jh = 2 * l, ja = jh + 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        L.ph[l][k] = ph[k]; L.pa[l][k] = pa[k]; L.tip[l][k] = tip[k];
+        L.XYZ[k] = X[k]; L.XYZ[3 + k] = Y[k]; L.XYZ[6 + k] = Z[k];
+        L.kleg[l][k] = e1[k]; L.kleg[l][3 + k] = caux[k];
+    }
     float Sh[6], Sa[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { Sh[k] = Z[k]; Sa[k] = axw[k]; }
@@ -312,65 +324,68 @@ HRL_DEV void phase_kin_aba(const DevCfg &c, WaveLds &L, const float *q, int lane
     for (int k = 0; k < 6; ++k) { vja[k] = Sa[k] * qda; vf[k] = vx[k] + vja[k]; }
     crm(cbh, v0, vjh);
     crm(cba, vx, vja);
-    float Ix[21], If[21], Iv[6], f[6], pAx[6], pAf[6], ng[3];
-    spatial_inertia(Ix, c.m1, c.a1, c.b1, e1, caux);
-    spatial_inertia(If, c.m2, c.a2, c.b2, e2, cfoot);
-    { /* bias forces: v x* (I v) - gravity wrench */
-        float fg[3] = {0.f, 0.f, -c.m1 * c.g};
-        sym6_matvec(Iv, Ix, vx); crf(f, vx, Iv); cross3(ng, caux, fg);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { pAx[k] = f[k] - ng[k]; pAx[3 + k] = f[3 + k] - fg[k]; }
+    for (int k = 0; k < 6; ++k) { L.S[jh][k] = Sh[k]; L.S[ja][k] = Sa[k]; L.cb[jh][k] = cbh[k]; L.cb[ja][k] = cba[k]; L.kleg[l][6 + k] = vx[k]; }
+    float If[21], Iv[6], f[6], pAf[6], ng[3];
+    spatial_inertia(If, c.m2, c.a2, c.b2, e2, cfoot);
+    { /* bias force of the foot: v x* (I v) - gravity wrench */
         float fg2[3] = {0.f, 0.f, -c.m2 * c.g};
         sym6_matvec(Iv, If, vf); crf(f, vf, Iv); cross3(ng, cfoot, fg2);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { pAf[k] = f[k] - ng[k]; pAf[3 + k] = f[3 + k] - fg2[k]; }
     }
-    /* ankle: foot -> aux */
     float Ua[6], Iac[6];
     sym6_matvec(Ua, If, Sa);
-    float invDa = 1.f / dot6(Sa, Ua);
-    float uta = L.tau[2 * l + 1] - dot6(Sa, pAf);
+    const float invDa = 1.f / dot6(Sa, Ua);
+    const float uta = L.tau[ja] - dot6(Sa, pAf);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = a; b < 6; ++b) If[si(a, b)] = If[si(a, b)] - (Ua[a] * invDa) * Ua[b];
     sym6_matvec(Iac, If, cba);
+    const float ud = uta * invDa;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { L.paf[l][a] = (pAf[a] + Iac[a]) + Ua[a] * ud; L.U[ja][a] = Ua[a]; }
+#pragma unroll
+    for (int k = 0; k < 21; ++k) L.Iaf[l][k] = If[k];
+    L.invD[ja] = invDa; L.uterm[ja] = uta;
+}
+
+/* Phase K2 (leg map): aux body + what the ankle handed over, then the hip joint (aux -> torso). */
+HRL_DEV void phase_hip(const DevCfg &c, WaveLds &L, int lane) {
+    const int l = (lane >> 4) & 3, jh = 2 * l;
+    float e1[3], caux[3], vx[6], Sh[6], cbh[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e1[k] = L.kleg[l][k]; caux[k] = L.kleg[l][3 + k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { vx[k] = L.kleg[l][6 + k]; Sh[k] = L.S[jh][k]; cbh[k] = L.cb[jh][k]; }
+    float Ix[21], Iv[6], f[6], pAx[6], ng[3];
+    spatial_inertia(Ix, c.m1, c.a1, c.b1, e1, caux);
     {
-        float ud = uta * invDa;
+        float fg[3] = {0.f, 0.f, -c.m1 * c.g};
+        sym6_matvec(Iv, Ix, vx); crf(f, vx, Iv); cross3(ng, caux, fg);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) pAx[a] += (pAf[a] + Iac[a]) + Ua[a] * ud;
-#pragma unroll
-        for (int k = 0; k < 21; ++k) Ix[k] += If[k];
+        for (int k = 0; k < 3; ++k) { pAx[k] = f[k] - ng[k]; pAx[3 + k] = f[3 + k] - fg[k]; }
     }
-    /* hip: aux -> torso */
-    float Uh[6], plg[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) pAx[a] += L.paf[l][a];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Ix[k] += L.Iaf[l][k];
+    float Uh[6], Iac[6];
     sym6_matvec(Uh, Ix, Sh);
-    float invDh = 1.f / dot6(Sh, Uh);
-    float uth = L.tau[2 * l] - dot6(Sh, pAx);
+    const float invDh = 1.f / dot6(Sh, Uh);
+    const float uth = L.tau[jh] - dot6(Sh, pAx);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = a; b < 6; ++b) Ix[si(a, b)] = Ix[si(a, b)] - (Uh[a] * invDh) * Uh[b];
     sym6_matvec(Iac, Ix, cbh);
-    {
-        float ud = uth * invDh;
+    const float ud = uth * invDh;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) plg[a] = (pAx[a] + Iac[a]) + Uh[a] * ud;
-    }
-    const int jh = 2 * l, ja = jh + 1;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        L.S[jh][k] = Sh[k]; L.S[ja][k] = Sa[k]; L.U[jh][k] = Uh[k]; L.U[ja][k] = Ua[k];
-        L.cb[jh][k] = cbh[k]; L.cb[ja][k] = cba[k]; L.legp[l][k] = plg[k];
-    }
-    L.invD[jh] = invDh; L.invD[ja] = invDa; L.uterm[jh] = uth; L.uterm[ja] = uta;
+    for (int a = 0; a < 6; ++a) { L.legp[l][a] = (pAx[a] + Iac[a]) + Uh[a] * ud; L.U[jh][a] = Uh[a]; }
 #pragma unroll
     for (int k = 0; k < 21; ++k) L.legI[l][k] = Ix[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        L.ph[l][k] = ph[k]; L.pa[l][k] = pa[k]; L.tip[l][k] = tip[k];
-        L.XYZ[k] = X[k]; L.XYZ[3 + k] = Y[k]; L.XYZ[6 + k] = Z[k];
-    }
+    L.invD[jh] = invDh; L.uterm[jh] = uth;
 }
 
 /* Phase B (uniform): torso + leg sums, inverse of the base articulated inertia, base acceleration. */
@@ -390,12 +405,15 @@ HRL_DEV void phase_base(const DevCfg &c, WaveLds &L, int lane) {
     for (int k = 0; k < 21; ++k) I0[k] += (L.legI[0][k] + L.legI[1][k]) + (L.legI[2][k] + L.legI[3][k]);
 #pragma unroll
     for (int k = 0; k < 6; ++k) p0[k] = p0[k] + ((L.legp[0][k] + L.legp[1][k]) + (L.legp[2][k] + L.legp[3][k]));
-    float Ainv[36];
+    float Ainv[21], a0[6];
     spd6_inverse(Ainv, I0);
+    sym6_matvec(a0, Ainv, p0);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) L.a0[a] = -dot6(Ainv + 6 * a, p0);
+    for (int a = 0; a < 6; ++a) L.a0[a] = -a0[a];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) L.I0inv[k] = Ainv[k];
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) L.I0inv[a * 6 + b] = Ainv[si(a, b)];
     (void)lane;
 }
 
@@ -638,7 +656,8 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
     WaveLds &L = x.lds();
     const float *q = L.q[qi];
     float *qn = L.q[qi ^ 1];
-    x.each([&](int lane) { phase_kin_aba(c, L, q, lane); });
+    x.each([&](int lane) { phase_kin_ankle(c, L, q, lane); });
+    x.each([&](int lane) { phase_hip(c, L, lane); });
     x.each([&](int lane) { phase_base(c, L, lane); });
     x.each([&](int lane) { x.reg(lane).ud = phase_forward_vel(c, L, lane); });
     /* contacts: surface-major, sphere-minor; at most MAXC kept */
@@ -839,7 +858,7 @@ HRL_DEV void maze_line(int l, float *a) {
 }
 
 /* Phase O1: upstream WalkerBase.calc_state (28-vector clipped to +-5) into L.s28, plus walk_target_dist, yaw and
- * joints_at_limit into L.scal.  `with_centroid` needs L.ph/pa/tip of the CURRENT qpos (phase_kin_aba on L.st). */
+ * joints_at_limit into L.scal.  `with_centroid` needs L.ph/pa/tip of the CURRENT qpos (phase_kin_ankle on L.st). */
 HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_feet, bool with_centroid) {
     const float *qp = L.st, *qv = L.st + 15;
     float rpy[3];
@@ -1029,14 +1048,15 @@ HRL_DEV void phase_point_state(const DevCfg &c, WaveLds &L, int lane) {
 template <class X>
 HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
     WaveLds &L = x.lds();
+    const bool centroid = (c.kind == 0 || c.kind == 2);
+    if (centroid) { /* link positions of the final pose for the parts centroid; its LDS hand-off area overlays the
+                       task scratch, so it runs before anything below is written */
+        x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
+        x.each([&](int lane) { phase_kin_ankle(c, L, L.q[0], lane); });
+    }
     x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
     if (c.kind == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
     else {
-        const bool centroid = (c.kind == 0 || c.kind == 2);
-        if (centroid) { /* link positions of the final pose for the parts centroid */
-            x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
-            x.each([&](int lane) { phase_kin_aba(c, L, L.q[0], lane); });
-        }
         const bool feet = step_mode && c.kind == 2; /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
         x.each([&](int lane) { phase_calc_state(c, L, lane, feet, centroid); });
     }
