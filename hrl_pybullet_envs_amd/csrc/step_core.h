@@ -131,13 +131,16 @@ struct WaveLds {
 struct LaneRegs { float ud, jby; };
 
 /* ------------------------------------------------------------------------------------------------ small math */
+/* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
+ * rounding of every operation is part of the algorithm's definition: DESIGN.md 3.7. */
+HRL_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 HRL_DEV void cross3(float *o, const float *a, const float *b) {
-    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    float x = fma_(a[1], b[2], -(a[2] * b[1])), y = fma_(a[2], b[0], -(a[0] * b[2])), z = fma_(a[0], b[1], -(a[1] * b[0]));
     o[0] = x; o[1] = y; o[2] = z;
 }
-HRL_DEV float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+HRL_DEV float dot3(const float *a, const float *b) { return fma_(a[2], b[2], fma_(a[1], b[1], a[0] * b[0])); }
 HRL_DEV float dot6(const float *a, const float *b) {
-    return ((((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]) + a[4] * b[4]) + a[5] * b[5];
+    return fma_(a[5], b[5], fma_(a[4], b[4], fma_(a[3], b[3], fma_(a[2], b[2], fma_(a[1], b[1], a[0] * b[0])))));
 }
 /* sin and cos for the dynamics (joint rotations, quaternion increment), specified operation by operation so that
  * every fp32 implementation of the step produces the same bits: quadrant k = rint(x * 2/pi), three-term
@@ -145,20 +148,26 @@ HRL_DEV float dot6(const float *a, const float *b) {
  * Accurate to ~1.5 ulp for |x| < 100; the library sinf/cosf are only used for observations. */
 HRL_DEV void sincos_spec(float x, float *sn, float *cs) {
     const float k = rintf(x * 0.636619772367581343f);
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188216e-8f;
+    float r = fma_(-k, 1.5703125f, x);
+    r = fma_(-k, 4.837512969970703125e-4f, r);
+    r = fma_(-k, 7.54978995489188216e-8f, r);
     const float z = r * r;
-    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
-    ps = ps * z + -1.6666654611e-1f;
-    const float sr = (ps * z) * r + r;
-    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    const float cr = ((pc * z) * z - 0.5f * z) + 1.0f;
+    float ps = fma_(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fma_(ps, z, -1.6666654611e-1f);
+    const float sr = fma_(ps * z, r, r);
+    float pc = fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fma_(pc, z, 4.166664568298827e-2f);
+    const float cr = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
     const int q = ((int)k) & 3;
     const float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
     *sn = (q & 2) ? -s1 : s1;
     *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+/* columns of the rotation matrix of the unit quaternion (x, y, z, w) */
+HRL_DEV void quat_axes(float x, float y, float z, float w, float *X, float *Y, float *Z) {
+    X[0] = fma_(-2.f, fma_(y, y, z * z), 1.f); X[1] = 2.f * fma_(x, y, w * z); X[2] = 2.f * fma_(x, z, -(w * y));
+    Y[0] = 2.f * fma_(x, y, -(w * z)); Y[1] = fma_(-2.f, fma_(x, x, z * z), 1.f); Y[2] = 2.f * fma_(y, z, w * x);
+    Z[0] = 2.f * fma_(x, z, w * y); Z[1] = 2.f * fma_(y, z, -(w * x)); Z[2] = fma_(-2.f, fma_(x, x, y * y), 1.f);
 }
 HRL_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 /* symmetric 6x6 stored as the upper triangle, row-major (21 floats) */
@@ -166,7 +175,7 @@ HRL_DEV constexpr int si(int a, int b) { return a <= b ? a * 6 - (a * (a - 1)) /
 HRL_DEV void sym6_matvec(float *o, const float *A, const float *x) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-        o[i] = ((((A[si(i, 0)] * x[0] + A[si(i, 1)] * x[1]) + A[si(i, 2)] * x[2]) + A[si(i, 3)] * x[3]) + A[si(i, 4)] * x[4]) + A[si(i, 5)] * x[5];
+        o[i] = fma_(A[si(i, 5)], x[5], fma_(A[si(i, 4)], x[4], fma_(A[si(i, 3)], x[3], fma_(A[si(i, 2)], x[2], fma_(A[si(i, 1)], x[1], A[si(i, 0)] * x[0])))));
 }
 /* spatial inertia about O of a body with mass m, central inertia alpha*1 + beta*e e^T, COM offset c */
 HRL_DEV void spatial_inertia(float *I, float m, float alpha, float beta, const float *e, const float *c) {
@@ -176,7 +185,7 @@ HRL_DEV void spatial_inertia(float *I, float m, float alpha, float beta, const f
 #pragma unroll
         for (int j = i; j < 3; ++j) {
             float d = (i == j) ? 1.f : 0.f;
-            I[si(i, j)] = (alpha * d + beta * e[i] * e[j]) + m * (cc * d - c[i] * c[j]);
+            I[si(i, j)] = fma_(m, fma_(-c[i], c[j], cc * d), fma_(beta * e[i], e[j], alpha * d));
             I[si(3 + i, 3 + j)] = m * d;
         }
     /* top-right block = m [c]x */
@@ -207,11 +216,11 @@ HRL_DEV float tree16(const float *x) {
 }
 HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
     if (fabsf(n[2]) > 0.70710678118654752440f) {
-        float a = n[1] * n[1] + n[2] * n[2], k = 1.f / sqrtf(a);
+        float a = fma_(n[1], n[1], n[2] * n[2]), k = 1.f / sqrtf(a);
         t1[0] = 0.f; t1[1] = -n[2] * k; t1[2] = n[1] * k;
         t2[0] = a * k; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
     } else {
-        float a = n[0] * n[0] + n[1] * n[1], k = 1.f / sqrtf(a);
+        float a = fma_(n[0], n[0], n[1] * n[1]), k = 1.f / sqrtf(a);
         t1[0] = -n[1] * k; t1[1] = n[0] * k; t1[2] = 0.f;
         t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
     }
@@ -225,26 +234,25 @@ HRL_DEV void spd6_inverse(float *Ainv /* [21], si() layout */, const float *A /*
     for (int j = 0; j < 6; ++j) {
         float s = A[si(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= Lm[tri(j, k)] * Lm[tri(j, k)];
+        for (int k = 0; k < j; ++k) s = fma_(-Lm[tri(j, k)], Lm[tri(j, k)], s);
         float d = sqrtf(s), id = 1.f / d;
-        Lm[tri(j, j)] = d;
+        Lm[tri(j, j)] = d; Li[tri(j, j)] = id;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             float t = A[si(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= Lm[tri(i, k)] * Lm[tri(j, k)];
+            for (int k = 0; k < j; ++k) t = fma_(-Lm[tri(i, k)], Lm[tri(j, k)], t);
             Lm[tri(i, j)] = t * id;
         }
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        Li[tri(j, j)] = 1.f / Lm[tri(j, j)];
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             float t = 0.f;
 #pragma unroll
-            for (int k = j; k < i; ++k) t -= Lm[tri(i, k)] * Li[tri(k, j)];
-            Li[tri(i, j)] = t / Lm[tri(i, i)];
+            for (int k = j; k < i; ++k) t = fma_(-Lm[tri(i, k)], Li[tri(k, j)], t);
+            Li[tri(i, j)] = t * Li[tri(i, i)];
         }
     }
 #pragma unroll
@@ -253,7 +261,7 @@ HRL_DEV void spd6_inverse(float *Ainv /* [21], si() layout */, const float *A /*
         for (int j = 0; j <= i; ++j) {
             float t = 0.f;
 #pragma unroll
-            for (int k = i; k < 6; ++k) t += Li[tri(k, i)] * Li[tri(k, j)];
+            for (int k = i; k < 6; ++k) t = fma_(Li[tri(k, i)], Li[tri(k, j)], t);
             Ainv[si(j, i)] = t;
         }
 }
@@ -281,9 +289,8 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
     const float is2 = 0.70710678118654752440f;
     const int l = (lane >> 4) & 3;
     float x = q[3], y = q[4], z = q[5], w = q[6];
-    float X[3] = {1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)};
-    float Y[3] = {2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)};
-    float Z[3] = {2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)};
+    float X[3], Y[3], Z[3];
+    quat_axes(x, y, z, w, X, Y, Z);
     float qh = q[7 + 2 * l], qa = q[8 + 2 * l], qdh = L.u[6 + 2 * l], qda = L.u[7 + 2 * l];
     float ch, sh, ca, sa;
     sincos_spec(qh, &sh, &ch);
@@ -291,19 +298,19 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
     /* leg direction signs, ankle axes and sigma = (ankle axis) x (leg dir) . z : assets/ant.xml:15-58 */
     float sx = (l == 0 || l == 3) ? 1.f : -1.f, sy = (l < 2) ? 1.f : -1.f;
     float ax = (l & 1) ? 1.f : -1.f, ay = 1.f, sg = (l == 1 || l == 2) ? 1.f : -1.f;
-    float e1x = (sx * ch - sy * sh) * is2, e1y = (sx * sh + sy * ch) * is2;
-    float axx = (ax * ch - ay * sh) * is2, axy = (ax * sh + ay * ch) * is2;
+    float e1x = fma_(sx, ch, -(sy * sh)) * is2, e1y = fma_(sx, sh, sy * ch) * is2;
+    float axx = fma_(ax, ch, -(ay * sh)) * is2, axy = fma_(ax, sh, ay * ch) * is2;
     float e1[3], axw[3], e2[3], ph[3], pa[3], tip[3], caux[3], cfoot[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        e1[k] = e1x * X[k] + e1y * Y[k];
-        axw[k] = axx * X[k] + axy * Y[k];
-        e2[k] = ca * e1[k] + (sg * sa) * Z[k];
-        ph[k] = 0.2f * (sx * X[k] + sy * Y[k]);
-        pa[k] = ph[k] + c.L1 * e1[k];
-        tip[k] = pa[k] + c.L2 * e2[k];
-        caux[k] = ph[k] + (c.L1 * 0.5f) * e1[k];
-        cfoot[k] = pa[k] + (c.L2 * 0.5f) * e2[k];
+        e1[k] = fma_(e1y, Y[k], e1x * X[k]);
+        axw[k] = fma_(axy, Y[k], axx * X[k]);
+        e2[k] = fma_(sg * sa, Z[k], ca * e1[k]);
+        ph[k] = 0.2f * fma_(sy, Y[k], sx * X[k]);
+        pa[k] = fma_(c.L1, e1[k], ph[k]);
+        tip[k] = fma_(c.L2, e2[k], pa[k]);
+        caux[k] = fma_(c.L1 * 0.5f, e1[k], ph[k]);
+        cfoot[k] = fma_(c.L2 * 0.5f, e2[k], pa[k]);
     }
     const int jh = 2 * l, ja = jh + 1;
 #pragma unroll
@@ -341,11 +348,11 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = a; b < 6; ++b) If[si(a, b)] = If[si(a, b)] - (Ua[a] * invDa) * Ua[b];
+        for (int b = a; b < 6; ++b) If[si(a, b)] = fma_(-(Ua[a] * invDa), Ua[b], If[si(a, b)]);
     sym6_matvec(Iac, If, cba);
     const float ud = uta * invDa;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) { L.paf[l][a] = (pAf[a] + Iac[a]) + Ua[a] * ud; L.U[ja][a] = Ua[a]; }
+    for (int a = 0; a < 6; ++a) { L.paf[l][a] = fma_(Ua[a], ud, pAf[a] + Iac[a]); L.U[ja][a] = Ua[a]; }
 #pragma unroll
     for (int k = 0; k < 21; ++k) L.Iaf[l][k] = If[k];
     L.invD[ja] = invDa; L.uterm[ja] = uta;
@@ -378,11 +385,11 @@ HRL_DEV void phase_hip(const DevCfg &c, WaveLds &L, int lane) {
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = a; b < 6; ++b) Ix[si(a, b)] = Ix[si(a, b)] - (Uh[a] * invDh) * Uh[b];
+        for (int b = a; b < 6; ++b) Ix[si(a, b)] = fma_(-(Uh[a] * invDh), Uh[b], Ix[si(a, b)]);
     sym6_matvec(Iac, Ix, cbh);
     const float ud = uth * invDh;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) { L.legp[l][a] = (pAx[a] + Iac[a]) + Uh[a] * ud; L.U[jh][a] = Uh[a]; }
+    for (int a = 0; a < 6; ++a) { L.legp[l][a] = fma_(Uh[a], ud, pAx[a] + Iac[a]); L.U[jh][a] = Uh[a]; }
 #pragma unroll
     for (int k = 0; k < 21; ++k) L.legI[l][k] = Ix[k];
     L.invD[jh] = invDh; L.uterm[jh] = uth;
@@ -423,11 +430,11 @@ HRL_DEV float phase_forward_vel(const DevCfg &c, const WaveLds &L, int lane) {
     float a0[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) a0[k] = L.a0[k];
-    if (d < 3) return L.u[d] + c.h * a0[d];
+    if (d < 3) return fma_(c.h, a0[d], L.u[d]);
     if (d < 6) {
         float wxv[3];
         cross3(wxv, L.u, L.u + 3);
-        return L.u[d] + c.h * (a0[d] + wxv[d - 3]);
+        return fma_(c.h, a0[d] + wxv[d - 3], L.u[d]);
     }
     if (d >= 14) return 0.f;
     const int j = d - 6, jh = j & ~1, ja = jh + 1;
@@ -435,11 +442,11 @@ HRL_DEV float phase_forward_vel(const DevCfg &c, const WaveLds &L, int lane) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) ap[k] = a0[k] + L.cb[jh][k];
     float qddh = (L.uterm[jh] - dot6(L.U[jh], ap)) * L.invD[jh];
-    if (j == jh) return L.u[d] + c.h * qddh;
+    if (j == jh) return fma_(c.h, qddh, L.u[d]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ax_[k] = (ap[k] + L.S[jh][k] * qddh) + L.cb[ja][k];
+    for (int k = 0; k < 6; ++k) ax_[k] = fma_(L.S[jh][k], qddh, ap[k]) + L.cb[ja][k];
     float qdda = (L.uterm[ja] - dot6(L.U[ja], ax_)) * L.invD[ja];
-    return L.u[d] + c.h * qdda;
+    return fma_(c.h, qdda, L.u[d]);
 }
 
 /* velocity response du = M^-1 (generalized impulse) through the articulated-body quantities in LDS */
@@ -454,7 +461,7 @@ HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, fl
     {
         float s = ua * L.invD[ja];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p[k] = p[k] + L.U[ja][k] * s;
+        for (int k = 0; k < 6; ++k) p[k] = fma_(L.U[ja][k], s, p[k]);
     }
     if (level == 1) {
 #pragma unroll
@@ -464,7 +471,7 @@ HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, fl
     {
         float s = uh * L.invD[jh];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p[k] = p[k] + L.U[jh][k] * s;
+        for (int k = 0; k < 6; ++k) p[k] = fma_(L.U[jh][k], s, p[k]);
     }
     if (level == 0) {
 #pragma unroll
@@ -481,7 +488,7 @@ HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, fl
         float uhl = (l == leg) ? uh : 0.f, ual = (l == leg) ? ua : 0.f, dvx[6];
         float dqh = (uhl - dot6(L.U[h_], dv0)) * L.invD[h_];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dvx[k] = dv0[k] + L.S[h_][k] * dqh;
+        for (int k = 0; k < 6; ++k) dvx[k] = fma_(L.S[h_][k], dqh, dv0[k]);
         float dqa = (ual - dot6(L.U[a_], dvx)) * L.invD[a_];
         du[6 + h_] = dqh; du[6 + a_] = dqa;
     }
@@ -513,7 +520,7 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
     } else {
         float d[3], d2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { float cp = clampf(p[k], c.box_lo[k], c.box_hi[k]); d[k] = p[k] - cp; d2 += d[k] * d[k]; }
+        for (int k = 0; k < 3; ++k) { float cp = clampf(p[k], c.box_lo[k], c.box_hi[k]); d[k] = p[k] - cp; d2 = fma_(d[k], d[k], d2); }
         if (d2 > 0.f) {
             float len = sqrtf(d2);
             h.n[0] = d[0] / len; h.n[1] = d[1] / len; h.n[2] = d[2] / len;
@@ -601,17 +608,17 @@ HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float 
     if (th > 1e-6f) { float sh_, ch_; sincos_spec(0.5f * th, &sh_, &ch_); float s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
     else { float s = 0.5f * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1.f; }
     float x = q[3], y = q[4], z = q[5], w = q[6];
-    float nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
-    float ny = dq[3] * y - dq[0] * z + dq[1] * w + dq[2] * x;
-    float nz = dq[3] * z + dq[0] * y - dq[1] * x + dq[2] * w;
-    float nw = dq[3] * w - dq[0] * x - dq[1] * y - dq[2] * z;
-    float inv = 1.f / sqrtf((nx * nx + ny * ny) + (nz * nz + nw * nw));
+    float nx = fma_(-dq[2], y, fma_(dq[1], z, fma_(dq[0], w, dq[3] * x)));
+    float ny = fma_(dq[2], x, fma_(dq[1], w, fma_(-dq[0], z, dq[3] * y)));
+    float nz = fma_(dq[2], w, fma_(-dq[1], x, fma_(dq[0], y, dq[3] * z)));
+    float nw = fma_(-dq[2], z, fma_(-dq[1], y, fma_(-dq[0], x, dq[3] * w)));
+    float inv = 1.f / sqrtf(fma_(nx, nx, ny * ny) + fma_(nz, nz, nw * nw));
     float nq[16];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) nq[k] = q[k] + h * u[3 + k];
+    for (int k = 0; k < 3; ++k) nq[k] = fma_(h, u[3 + k], q[k]);
     nq[3] = nx * inv; nq[4] = ny * inv; nq[5] = nz * inv; nq[6] = nw * inv;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) nq[7 + j] = q[7 + j] + h * u[6 + j];
+    for (int j = 0; j < NJ; ++j) nq[7 + j] = fma_(h, u[6 + j], q[7 + j]);
     nq[15] = 0.f;
     /* every lane holds the same 16 values; lane k < 16 stores element k */
     float mine = nq[0];
@@ -641,9 +648,9 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nR) {
                     float lo = rp.z, hi = rp.w;
                     const int fn = L.frn[r];
                     if (fn >= 0) { hi = c.mu * L.lam[nxt][fn]; lo = -hi; }
-                    const float ln = clampf(lam - (wv + rp.x) * rp.y, lo, hi);
+                    const float ln = clampf(fma_(-(wv + rp.x), rp.y, lam), lo, hi);
                     const float dl = ln - lam;
-                    x.reg(lane).ud = x.reg(lane).ud + x.reg(lane).jby * dl;
+                    x.reg(lane).ud = fma_(x.reg(lane).jby, dl, x.reg(lane).ud);
                     L.lam[nxt][r] = ln;
                 });
         }
@@ -671,7 +678,7 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
                 const int i = base + rank;
                 if (i < MAXC) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { L.cn[i][k] = h.n[k]; L.cr[i][k] = h.c[k] - h.rad * h.n[k]; }
+                    for (int k = 0; k < 3; ++k) { L.cn[i][k] = h.n[k]; L.cr[i][k] = fma_(-h.rad, h.n[k], h.c[k]); }
                     L.cdist_[i] = h.dist; L.clink[i] = h.link;
                 }
             },
@@ -718,14 +725,14 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
     x.each([&](int lane) {
         const int d = lane & 15;
         float v = L.u[d];
-        if (d == 3) v = L.u[3] + c.h * (L.tau[0] / m);
-        if (d == 4) v = L.u[4] + c.h * (L.tau[1] / m);
-        if (d == 5) v = L.u[5] + c.h * (L.tau[2] / m - c.g);
+        if (d == 3) v = fma_(c.h, L.tau[0] / m, L.u[3]);
+        if (d == 4) v = fma_(c.h, L.tau[1] / m, L.u[4]);
+        if (d == 5) v = fma_(c.h, L.tau[2] / m - c.g, L.u[5]);
         x.reg(lane).ud = d < 6 ? v : 0.f;
-        float qx = q[3], qy = q[4], qz = q[5], qw = q[6];
-        L.XYZ[0] = 1 - 2 * (qy * qy + qz * qz); L.XYZ[1] = 2 * (qx * qy + qw * qz); L.XYZ[2] = 2 * (qx * qz - qw * qy);
-        L.XYZ[3] = 2 * (qx * qy - qw * qz); L.XYZ[4] = 1 - 2 * (qx * qx + qz * qz); L.XYZ[5] = 2 * (qy * qz + qw * qx);
-        L.XYZ[6] = 2 * (qx * qz + qw * qy); L.XYZ[7] = 2 * (qy * qz - qw * qx); L.XYZ[8] = 1 - 2 * (qx * qx + qy * qy);
+        float ax_[3], ay_[3], az_[3];
+        quat_axes(q[3], q[4], q[5], q[6], ax_, ay_, az_);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { L.XYZ[k] = ax_[k]; L.XYZ[3 + k] = ay_[k]; L.XYZ[6 + k] = az_[k]; }
     });
     int nC = 0;
     for (int f = 0; f < 1 + c.n_planes; ++f) {
@@ -736,7 +743,7 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
                 if (lane < 8) {
                     float sx = (lane & 1) ? he : -he, sy = (lane & 2) ? he : -he, sz = (lane & 4) ? he : -he;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) h.c[k] = (sx * L.XYZ[k] + sy * L.XYZ[3 + k]) + sz * L.XYZ[6 + k];
+                    for (int k = 0; k < 3; ++k) h.c[k] = fma_(sz, L.XYZ[6 + k], fma_(sy, L.XYZ[3 + k], sx * L.XYZ[k]));
                     if (f == 0) h.dist = (q[2] + h.c[2]) - c.ground_z;
                     else {
                         float p[3] = {q[0] + h.c[0], q[1] + h.c[1], q[2] + h.c[2]};

@@ -20,16 +20,23 @@
 #define FN(name) CAT(name, SUF)
 
 #define R_(x) ((REAL)(x))
+/* Fused multiply-adds are explicit (and the file is compiled with -ffp-contract=off): the rounding of every
+ * operation of the rigid-body step is part of its specification. */
+#if REAL_IS_FLOAT
+#define FMA_(a, b, c) __builtin_fmaf(a, b, c)
+#else
+#define FMA_(a, b, c) __builtin_fma(a, b, c)
+#endif
 
 /* ---------------------------------------------------------------------------------------------- small vector helpers */
 static inline void FN(v3set)(REAL *o, REAL x, REAL y, REAL z) { o[0] = x; o[1] = y; o[2] = z; }
 static inline void FN(v3cross)(REAL *o, const REAL *a, const REAL *b) {
-    REAL x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    REAL x = FMA_(a[1], b[2], -(a[2] * b[1])), y = FMA_(a[2], b[0], -(a[0] * b[2])), z = FMA_(a[0], b[1], -(a[1] * b[0]));
     o[0] = x; o[1] = y; o[2] = z;
 }
-static inline REAL FN(v3dot)(const REAL *a, const REAL *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline REAL FN(v3dot)(const REAL *a, const REAL *b) { return FMA_(a[2], b[2], FMA_(a[1], b[1], a[0] * b[0])); }
 static inline REAL FN(dot6)(const REAL *a, const REAL *b) {
-    return ((((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]) + a[4] * b[4]) + a[5] * b[5];
+    return FMA_(a[5], b[5], FMA_(a[4], b[4], FMA_(a[3], b[3], FMA_(a[2], b[2], FMA_(a[1], b[1], a[0] * b[0])))));
 }
 /* balanced butterfly over 16 slots: pairs (i,i+8), then +4, +2, +1 -- the order a 16-lane rotate-add tree produces */
 static inline REAL FN(sum16_tree)(const REAL *x) {
@@ -61,16 +68,16 @@ static inline REAL FN(sum16_tree)(const REAL *x) {
 static inline void FN(dyn_sincos)(REAL x, REAL *sn, REAL *cs) {
 #if REAL_IS_FLOAT
     float k = rintf(x * 0.636619772367581343f);
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188216e-8f;
+    float r = FMA_(-k, 1.5703125f, x);
+    r = FMA_(-k, 4.837512969970703125e-4f, r);
+    r = FMA_(-k, 7.54978995489188216e-8f, r);
     float z = r * r;
-    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
-    ps = ps * z + -1.6666654611e-1f;
-    float sr = (ps * z) * r + r;
-    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    float cr = ((pc * z) * z - 0.5f * z) + 1.0f;
+    float ps = FMA_(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = FMA_(ps, z, -1.6666654611e-1f);
+    float sr = FMA_(ps * z, r, r);
+    float pc = FMA_(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = FMA_(pc, z, 4.166664568298827e-2f);
+    float cr = FMA_(pc * z, z, FMA_(-0.5f, z, 1.0f));
     int q = ((int)k) & 3;
     float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
     *sn = (q & 2) ? -s1 : s1;
@@ -464,12 +471,18 @@ typedef struct FN(orc_dyn) {
     REAL a0[6], qdd[NJ];
 } FN(orc_dyn);
 
+/* columns of the rotation matrix of the unit quaternion (x, y, z, w) */
+static void FN(quat_axes)(REAL x, REAL y, REAL z, REAL w, REAL *X, REAL *Y, REAL *Z) {
+    X[0] = FMA_(R_(-2), FMA_(y, y, z * z), R_(1)); X[1] = R_(2) * FMA_(x, y, w * z); X[2] = R_(2) * FMA_(x, z, -(w * y));
+    Y[0] = R_(2) * FMA_(x, y, -(w * z)); Y[1] = FMA_(R_(-2), FMA_(x, x, z * z), R_(1)); Y[2] = R_(2) * FMA_(y, z, w * x);
+    Z[0] = R_(2) * FMA_(x, z, w * y); Z[1] = R_(2) * FMA_(y, z, -(w * x)); Z[2] = FMA_(R_(-2), FMA_(x, x, y * y), R_(1));
+}
 static void FN(spatial_inertia)(REAL I[6][6], REAL m, REAL alpha, REAL beta, const REAL *e, const REAL *c) {
     REAL cc = FN(v3dot)(c, c);
     for (int i = 0; i < 3; ++i)
         for (int j = i; j < 3; ++j) { /* upper triangle, mirrored: the matrix is exactly symmetric */
             REAL d = (i == j) ? R_(1) : R_(0);
-            I[i][j] = I[j][i] = (alpha * d + beta * e[i] * e[j]) + m * (cc * d - c[i] * c[j]);
+            I[i][j] = I[j][i] = FMA_(m, FMA_(-c[i], c[j], cc * d), FMA_(beta * e[i], e[j], alpha * d));
             I[3 + i][3 + j] = I[3 + j][3 + i] = m * d;
         }
     /* top-right = m [c]x ; bottom-left = its transpose */
@@ -497,27 +510,25 @@ static void FN(spd6_inverse)(REAL Ainv[6][6], REAL A[6][6]) {
     memset(L, 0, sizeof(L)); memset(Li, 0, sizeof(Li));
     for (int j = 0; j < 6; ++j) {
         REAL s = A[j][j];
-        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        for (int k = 0; k < j; ++k) s = FMA_(-L[j][k], L[j][k], s);
         REAL d = RSQRT(s), id = R_(1) / d;
-        L[j][j] = d;
+        L[j][j] = d; Li[j][j] = id;
         for (int i = j + 1; i < 6; ++i) {
             REAL t = A[i][j];
-            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            for (int k = 0; k < j; ++k) t = FMA_(-L[i][k], L[j][k], t);
             L[i][j] = t * id;
         }
     }
-    for (int j = 0; j < 6; ++j) { /* Li = L^-1 (lower), column by column */
-        Li[j][j] = R_(1) / L[j][j];
+    for (int j = 0; j < 6; ++j) /* Li = L^-1 (lower), column by column; its diagonal is the 1/d computed above */
         for (int i = j + 1; i < 6; ++i) {
             REAL t = 0;
-            for (int k = j; k < i; ++k) t -= L[i][k] * Li[k][j];
-            Li[i][j] = t / L[i][i];
+            for (int k = j; k < i; ++k) t = FMA_(-L[i][k], Li[k][j], t);
+            Li[i][j] = t * Li[i][i];
         }
-    }
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j <= i; ++j) {
             REAL t = 0;
-            for (int k = i; k < 6; ++k) t += Li[k][i] * Li[k][j];
+            for (int k = i; k < 6; ++k) t = FMA_(Li[k][i], Li[k][j], t);
             Ainv[i][j] = t; Ainv[j][i] = t;
         }
 }
@@ -528,9 +539,7 @@ static void FN(spd6_inverse)(REAL Ainv[6][6], REAL A[6][6]) {
 void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, const REAL *tau, FN(orc_dyn) * D) {
     const REAL is2 = R_(0.70710678118654752440);
     REAL x = q[3], y = q[4], z = q[5], w = q[6];
-    FN(v3set)(D->X, 1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y));
-    FN(v3set)(D->Y, 2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x));
-    FN(v3set)(D->Z, 2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y));
+    FN(quat_axes)(x, y, z, w, D->X, D->Y, D->Z);
     REAL IA[NBODY][6][6], pA[NBODY][6], v[NBODY][6];
     REAL zero3[3] = {0, 0, 0};
     FN(spatial_inertia)(IA[0], K->m0, K->a0, K->b0, D->Z, zero3);
@@ -543,18 +552,18 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
         FN(dyn_sincos)(qh, &sh, &ch);
         FN(dyn_sincos)(qa, &sa, &ca);
         REAL sx = R_(LEG_SX[l]), sy = R_(LEG_SY[l]), ax = R_(ANK_AX[l]), ay = R_(ANK_AY[l]), sg = R_(LEG_SIGMA[l]);
-        REAL e1x = (sx * ch - sy * sh) * is2, e1y = (sx * sh + sy * ch) * is2; /* Rz(qh) * leg direction, torso frame */
-        REAL axx = (ax * ch - ay * sh) * is2, axy = (ax * sh + ay * ch) * is2; /* Rz(qh) * ankle axis            */
+        REAL e1x = FMA_(sx, ch, -(sy * sh)) * is2, e1y = FMA_(sx, sh, sy * ch) * is2; /* Rz(qh) * leg direction, torso frame */
+        REAL axx = FMA_(ax, ch, -(ay * sh)) * is2, axy = FMA_(ax, sh, ay * ch) * is2; /* Rz(qh) * ankle axis            */
         REAL e1[3], axw[3], e2[3], caux[3], cfoot[3];
         for (int k = 0; k < 3; ++k) {
-            e1[k] = e1x * D->X[k] + e1y * D->Y[k];
-            axw[k] = axx * D->X[k] + axy * D->Y[k];
-            e2[k] = ca * e1[k] + (sg * sa) * D->Z[k];
-            D->ph[l][k] = R_(0.2) * (sx * D->X[k] + sy * D->Y[k]);
-            D->pa[l][k] = D->ph[l][k] + K->L1 * e1[k];
-            D->tip[l][k] = D->pa[l][k] + K->L2 * e2[k];
-            caux[k] = D->ph[l][k] + (K->L1 * R_(0.5)) * e1[k];
-            cfoot[k] = D->pa[l][k] + (K->L2 * R_(0.5)) * e2[k];
+            e1[k] = FMA_(e1y, D->Y[k], e1x * D->X[k]);
+            axw[k] = FMA_(axy, D->Y[k], axx * D->X[k]);
+            e2[k] = FMA_(sg * sa, D->Z[k], ca * e1[k]);
+            D->ph[l][k] = R_(0.2) * FMA_(sy, D->Y[k], sx * D->X[k]);
+            D->pa[l][k] = FMA_(K->L1, e1[k], D->ph[l][k]);
+            D->tip[l][k] = FMA_(K->L2, e2[k], D->pa[l][k]);
+            caux[k] = FMA_(K->L1 * R_(0.5), e1[k], D->ph[l][k]);
+            cfoot[k] = FMA_(K->L2 * R_(0.5), e2[k], D->pa[l][k]);
         }
         int jh = 2 * l, ja = 2 * l + 1, bx = 1 + 2 * l, bf = 2 + 2 * l;
         for (int k = 0; k < 3; ++k) { D->S[jh][k] = D->Z[k]; D->S[ja][k] = axw[k]; }
@@ -588,10 +597,10 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
             D->uterm[j] = (tau ? tau[j] : R_(0)) - FN(dot6)(D->S[j], pA[child]);
             REAL Ia[6][6], pa_[6], Iac[6];
             for (int a = 0; a < 6; ++a) /* symmetric rank-1 downdate, upper triangle mirrored */
-                for (int b = a; b < 6; ++b) { Ia[a][b] = IA[child][a][b] - (D->U[j][a] * D->invD[j]) * D->U[j][b]; Ia[b][a] = Ia[a][b]; }
+                for (int b = a; b < 6; ++b) { Ia[a][b] = FMA_(-(D->U[j][a] * D->invD[j]), D->U[j][b], IA[child][a][b]); Ia[b][a] = Ia[a][b]; }
             FN(matvec6)(Iac, Ia, D->cb[j]);
             REAL ud = D->uterm[j] * D->invD[j];
-            for (int a = 0; a < 6; ++a) pa_[a] = (pA[child][a] + Iac[a]) + D->U[j][a] * ud;
+            for (int a = 0; a < 6; ++a) pa_[a] = FMA_(D->U[j][a], ud, pA[child][a] + Iac[a]);
             if (s == 1) { /* ankle -> accumulate into aux body */
                 int par = 1 + 2 * l;
                 for (int a = 0; a < 6; ++a) { for (int b = 0; b < 6; ++b) IA[par][a][b] += Ia[a][b]; pA[par][a] += pa_[a]; }
@@ -612,7 +621,7 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
         int jh = 2 * l, ja = jh + 1;
         for (int k = 0; k < 6; ++k) ap[k] = D->a0[k] + D->cb[jh][k];
         D->qdd[jh] = (D->uterm[jh] - FN(dot6)(D->U[jh], ap)) * D->invD[jh];
-        for (int k = 0; k < 6; ++k) ax_[k] = (ap[k] + D->S[jh][k] * D->qdd[jh]) + D->cb[ja][k];
+        for (int k = 0; k < 6; ++k) ax_[k] = FMA_(D->S[jh][k], D->qdd[jh], ap[k]) + D->cb[ja][k];
         D->qdd[ja] = (D->uterm[ja] - FN(dot6)(D->U[ja], ax_)) * D->invD[ja];
     }
 }
@@ -626,10 +635,10 @@ static void FN(orc_response)(const FN(orc_dyn) * D, const REAL *phi, int level, 
         for (int k = 0; k < 6; ++k) p[k] = -phi[k];
         ua = ta - FN(dot6)(D->S[ja], p);
     }
-    { REAL s = ua * D->invD[ja]; for (int k = 0; k < 6; ++k) p[k] = p[k] + D->U[ja][k] * s; }
+    { REAL s = ua * D->invD[ja]; for (int k = 0; k < 6; ++k) p[k] = FMA_(D->U[ja][k], s, p[k]); }
     if (level == 1) for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
     uh = th - FN(dot6)(D->S[jh], p);
-    { REAL s = uh * D->invD[jh]; for (int k = 0; k < 6; ++k) p[k] = p[k] + D->U[jh][k] * s; }
+    { REAL s = uh * D->invD[jh]; for (int k = 0; k < 6; ++k) p[k] = FMA_(D->U[jh][k], s, p[k]); }
     if (level == 0) for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
     REAL dv0[6];
     for (int a = 0; a < 6; ++a) dv0[a] = -FN(dot6)(D->I0inv[a], p);
@@ -638,7 +647,7 @@ static void FN(orc_response)(const FN(orc_dyn) * D, const REAL *phi, int level, 
         int h_ = 2 * l, a_ = h_ + 1;
         REAL uhl = (l == leg) ? uh : R_(0), ual = (l == leg) ? ua : R_(0), dvx[6];
         REAL dqh = (uhl - FN(dot6)(D->U[h_], dv0)) * D->invD[h_];
-        for (int k = 0; k < 6; ++k) dvx[k] = dv0[k] + D->S[h_][k] * dqh;
+        for (int k = 0; k < 6; ++k) dvx[k] = FMA_(D->S[h_][k], dqh, dv0[k]);
         REAL dqa = (ual - FN(dot6)(D->U[a_], dvx)) * D->invD[a_];
         du[6 + h_] = dqh; du[6 + a_] = dqa;
     }
@@ -647,11 +656,11 @@ static void FN(orc_response)(const FN(orc_dyn) * D, const REAL *phi, int level, 
 /* btPlaneSpace1-style tangent basis for a unit normal */
 static void FN(tangent_basis)(const REAL *n, REAL *t1, REAL *t2) {
     if (RFABS(n[2]) > R_(0.70710678118654752440)) {
-        REAL a = n[1] * n[1] + n[2] * n[2], k = R_(1) / RSQRT(a);
+        REAL a = FMA_(n[1], n[1], n[2] * n[2]), k = R_(1) / RSQRT(a);
         FN(v3set)(t1, 0, -n[2] * k, n[1] * k);
         FN(v3set)(t2, a * k, -n[0] * t1[2], n[0] * t1[1]);
     } else {
-        REAL a = n[0] * n[0] + n[1] * n[1], k = R_(1) / RSQRT(a);
+        REAL a = FMA_(n[0], n[0], n[1] * n[1]), k = R_(1) / RSQRT(a);
         FN(v3set)(t1, -n[1] * k, n[0] * k, 0);
         FN(v3set)(t2, -n[2] * t1[1], n[2] * t1[0], a * k);
     }
@@ -687,7 +696,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
             } else {
                 const REAL *lo = W->box_lo[f - 1 - W->n_planes], *hi = W->box_hi[f - 1 - W->n_planes];
                 REAL d[3], d2 = 0;
-                for (int k = 0; k < 3; ++k) { REAL cp = FN(clampr)(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 += d[k] * d[k]; }
+                for (int k = 0; k < 3; ++k) { REAL cp = FN(clampr)(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 = FMA_(d[k], d[k], d2); }
                 if (d2 > 0) { REAL len = RSQRT(d2); for (int k = 0; k < 3; ++k) n[k] = d[k] / len; dist = len - rad; }
                 else { /* centre inside the box: exit through the nearest face */
                     int best = 0; REAL bd = R_(1e30), sgn = 1;
@@ -704,7 +713,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                 if (nc < MAXC) {
                     FN(orc_contact) *cc = &C[nc++];
                     cc->level = level; cc->leg = leg; cc->sphere = s; cc->dist = dist;
-                    for (int k = 0; k < 3; ++k) { cc->n[k] = n[k]; cc->r[k] = c[k] - rad * n[k]; }
+                    for (int k = 0; k < 3; ++k) { cc->n[k] = n[k]; cc->r[k] = FMA_(-rad, n[k], c[k]); }
                 }
             }
         }
@@ -723,8 +732,8 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
     REAL wxv[3];
     FN(v3cross)(wxv, u, u + 3);
     REAL un[16];
-    for (int k = 0; k < 3; ++k) { un[k] = u[k] + h * D.a0[k]; un[3 + k] = u[3 + k] + h * (D.a0[3 + k] + wxv[k]); }
-    for (int j = 0; j < NJ; ++j) un[6 + j] = u[6 + j] + h * D.qdd[j];
+    for (int k = 0; k < 3; ++k) { un[k] = FMA_(h, D.a0[k], u[k]); un[3 + k] = FMA_(h, D.a0[3 + k] + wxv[k], u[3 + k]); }
+    for (int j = 0; j < NJ; ++j) un[6 + j] = FMA_(h, D.qdd[j], u[6 + j]);
     un[14] = un[15] = 0;
     /* (2) constraint rows: joint limits, contact normals, friction pairs */
     REAL J[MAXR][16], B[MAXR][16], bias[MAXR], invd[MAXR], lo[MAXR], hi[MAXR], lam[MAXR];
@@ -780,28 +789,28 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
             if (fr_normal[r] >= 0) { l_hi = K->mu * lam[fr_normal[r]]; l_lo = -l_hi; }
             for (int k = 0; k < 16; ++k) prod[k] = J[r][k] * un[k];
             REAL wv = FN(sum16_tree)(prod);
-            REAL ln = FN(clampr)(lam[r] - (wv + bias[r]) * invd[r], l_lo, l_hi);
+            REAL ln = FN(clampr)(FMA_(-(wv + bias[r]), invd[r], lam[r]), l_lo, l_hi);
             REAL dl = ln - lam[r];
             lam[r] = ln;
-            for (int k = 0; k < 16; ++k) un[k] = un[k] + B[r][k] * dl;
+            for (int k = 0; k < 16; ++k) un[k] = FMA_(B[r][k], dl, un[k]);
         }
     /* (4) joint-rate clamp and position integration (semi-implicit Euler, exponential map for the quaternion) */
     for (int j = 0; j < NJ; ++j) un[6 + j] = FN(clampr)(un[6 + j], -K->vmax, K->vmax);
     for (int k = 0; k < NDOF; ++k) u[k] = un[k];
-    for (int k = 0; k < 3; ++k) q[k] = q[k] + h * u[3 + k];
+    for (int k = 0; k < 3; ++k) q[k] = FMA_(h, u[3 + k], q[k]);
     {
         REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
         if (th > R_(1e-6)) { REAL sh_, ch_; FN(dyn_sincos)(R_(0.5) * th, &sh_, &ch_); REAL s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
         else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
         REAL x = q[3], y = q[4], z = q[5], w = q[6]; /* q <- dq (x) q */
-        REAL nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
-        REAL ny = dq[3] * y - dq[0] * z + dq[1] * w + dq[2] * x;
-        REAL nz = dq[3] * z + dq[0] * y - dq[1] * x + dq[2] * w;
-        REAL nw = dq[3] * w - dq[0] * x - dq[1] * y - dq[2] * z;
-        REAL inv = R_(1) / RSQRT((nx * nx + ny * ny) + (nz * nz + nw * nw));
+        REAL nx = FMA_(-dq[2], y, FMA_(dq[1], z, FMA_(dq[0], w, dq[3] * x)));
+        REAL ny = FMA_(dq[2], x, FMA_(dq[1], w, FMA_(-dq[0], z, dq[3] * y)));
+        REAL nz = FMA_(dq[2], w, FMA_(-dq[1], x, FMA_(dq[0], y, dq[3] * z)));
+        REAL nw = FMA_(-dq[2], z, FMA_(-dq[1], y, FMA_(-dq[0], x, dq[3] * w)));
+        REAL inv = R_(1) / RSQRT(FMA_(nx, nx, ny * ny) + FMA_(nz, nz, nw * nw));
         q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
     }
-    for (int j = 0; j < NJ; ++j) q[7 + j] = q[7 + j] + h * u[6 + j];
+    for (int j = 0; j < NJ; ++j) q[7 + j] = FMA_(h, u[6 + j], q[7 + j]);
     if (dbg) { dbg->n_rows = nr; dbg->n_limits = nl; dbg->n_contacts = nc; for (int r = 0; r < nr; ++r) dbg->lambda[r] = lam[r]; }
 }
 
@@ -811,12 +820,10 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
 void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL *q, REAL *u, const REAL *force) {
     const REAL m = 10, he = R_(0.35), I = m * (R_(0.7) * R_(0.7)) / 6, h = K->h;
     REAL x = q[3], y = q[4], z = q[5], w = q[6], X[3], Y[3], Z[3];
-    FN(v3set)(X, 1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y));
-    FN(v3set)(Y, 2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x));
-    FN(v3set)(Z, 2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y));
+    FN(quat_axes)(x, y, z, w, X, Y, Z);
     REAL un[6];
     for (int k = 0; k < 3; ++k) un[k] = u[k];
-    un[3] = u[3] + h * (force[0] / m); un[4] = u[4] + h * (force[1] / m); un[5] = u[5] + h * (force[2] / m - K->g);
+    un[3] = FMA_(h, force[0] / m, u[3]); un[4] = FMA_(h, force[1] / m, u[4]); un[5] = FMA_(h, force[2] / m - K->g, u[5]);
     /* contacts: 8 corners vs ground + lateral planes, surface-major order, at most MAXC */
     REAL Jr[3 * MAXC][6], Br[3 * MAXC][6], bias[3 * MAXC], invd[3 * MAXC], lam[3 * MAXC];
     int frn[3 * MAXC], nc = 0;
@@ -825,7 +832,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
         for (int s = 0; s < 8; ++s) {
             REAL c[3], n[3], dist;
             REAL sx = (s & 1) ? he : -he, sy = (s & 2) ? he : -he, sz = (s & 4) ? he : -he;
-            for (int k = 0; k < 3; ++k) c[k] = (sx * X[k] + sy * Y[k]) + sz * Z[k];
+            for (int k = 0; k < 3; ++k) c[k] = FMA_(sz, Z[k], FMA_(sy, Y[k], sx * X[k]));
             if (f == 0) { FN(v3set)(n, 0, 0, 1); dist = (q[2] + c[2]) - K->ground_z; }
             else {
                 const REAL *pn = W->plane_n[f - 1];
@@ -858,21 +865,21 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
             REAL prod[16] = {0};
             for (int k = 0; k < 6; ++k) prod[k] = Jr[r][k] * un[k];
             REAL wv = FN(sum16_tree)(prod);
-            REAL ln = FN(clampr)(lam[r] - (wv + bias[r]) * invd[r], l_lo, l_hi), dl = ln - lam[r];
+            REAL ln = FN(clampr)(FMA_(-(wv + bias[r]), invd[r], lam[r]), l_lo, l_hi), dl = ln - lam[r];
             lam[r] = ln;
-            for (int k = 0; k < 6; ++k) un[k] = un[k] + Br[r][k] * dl;
+            for (int k = 0; k < 6; ++k) un[k] = FMA_(Br[r][k], dl, un[k]);
         }
     for (int k = 0; k < 6; ++k) u[k] = un[k];
-    for (int k = 0; k < 3; ++k) q[k] = q[k] + h * u[3 + k];
+    for (int k = 0; k < 3; ++k) q[k] = FMA_(h, u[3 + k], q[k]);
     {
         REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
         if (th > R_(1e-6)) { REAL sh_, ch_; FN(dyn_sincos)(R_(0.5) * th, &sh_, &ch_); REAL s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
         else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
-        REAL nx = dq[3] * x + dq[0] * w + dq[1] * z - dq[2] * y;
-        REAL ny = dq[3] * y - dq[0] * z + dq[1] * w + dq[2] * x;
-        REAL nz = dq[3] * z + dq[0] * y - dq[1] * x + dq[2] * w;
-        REAL nw = dq[3] * w - dq[0] * x - dq[1] * y - dq[2] * z;
-        REAL inv = R_(1) / RSQRT((nx * nx + ny * ny) + (nz * nz + nw * nw));
+        REAL nx = FMA_(-dq[2], y, FMA_(dq[1], z, FMA_(dq[0], w, dq[3] * x)));
+        REAL ny = FMA_(dq[2], x, FMA_(dq[1], w, FMA_(-dq[0], z, dq[3] * y)));
+        REAL nz = FMA_(dq[2], w, FMA_(-dq[1], x, FMA_(dq[0], y, dq[3] * z)));
+        REAL nw = FMA_(-dq[2], z, FMA_(-dq[1], y, FMA_(-dq[0], x, dq[3] * w)));
+        REAL inv = R_(1) / RSQRT(FMA_(nx, nx, ny * ny) + FMA_(nz, nz, nw * nw));
         q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
     }
 }
@@ -1237,6 +1244,7 @@ void FN(orc_ant_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *t
 #undef MAXC
 #undef MAXR
 #undef RSQRT
+#undef FMA_
 #undef RSIN
 #undef RCOS
 #undef RATAN2
