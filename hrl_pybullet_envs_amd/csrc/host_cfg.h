@@ -115,7 +115,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.walk_tx = c.walk_target[0]; d.walk_ty = c.walk_target[1];
     d.span_is_2pi = c.sensor_span == 6.28318530717958647692f; /* sizeable_enclosed_scene.py:68 `s_span == 2*pi` */
     const hrl_model &m = c.model;
-    d.h = m.timestep; d.g = m.gravity; d.erp_c = m.contact_erp; d.erp_l = m.limit_erp;
+    d.h = m.timestep; d.inv_h = 1.0f / m.timestep; d.g = m.gravity; d.erp_c = m.contact_erp; d.erp_l = m.limit_erp;
     d.mu = m.friction_ground * m.friction_robot; d.cdist = m.contact_dist; d.lmargin = m.limit_margin;
     d.vmax = m.max_joint_vel; d.limp_max = m.limit_max_impulse; d.ground_z = m.ground_z;
     d.torque_scale = m.torque_scale; d.point_force = m.point_force;

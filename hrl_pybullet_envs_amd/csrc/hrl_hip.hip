@@ -41,6 +41,10 @@ struct GpuExec {
     __device__ __forceinline__ WaveLds &lds() { return L; }
     __device__ __forceinline__ LaneRegs &reg(int) { return r; }
     __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    /* accumulated impulse of solver row `src` (held by lane `src`), broadcast to the wave: v_readlane_b32 */
+    __device__ __forceinline__ float lane_lam(int which, int src) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(which ? r.lam1 : r.lam0), src));
+    }
     template <class F>
     __device__ __forceinline__ void each(F f) {
         f(lane);
@@ -67,12 +71,12 @@ struct GpuExec {
  * passed by value: by-value kernel arguments were all preloaded into SGPRs and spilled (86 SGPR spills). */
 __global__ __launch_bounds__(64, 4) void k_step(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
-    GpuExec x{L, {0.f, 0.f}, (int)threadIdx.x};
+    GpuExec x{L, LaneRegs{}, (int)threadIdx.x};
     step_entry(x, b, *cp, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
-    GpuExec x{L, {0.f, 0.f}, (int)threadIdx.x};
+    GpuExec x{L, LaneRegs{}, (int)threadIdx.x};
     reset_entry(x, b, *cp, (int)blockIdx.x);
 }
 /* packed record <-> split qpos[N][15], qvel[N][14] */

@@ -30,8 +30,13 @@
 
 #ifdef HRL_EMU
 #define HRL_DEV inline
+#define HRL_PIN_VGPR(x) ((void)0)
 #else
 #define HRL_DEV __device__ __forceinline__
+/* Materialise a wave-uniform value in a VGPR here.  Used before the solver loop: a constant that is still an
+ * outstanding scalar load inside the loop makes hipcc wait on lgkmcnt(0) there, which also drains the loop's LDS
+ * prefetches (scalar loads and LDS share that counter). */
+#define HRL_PIN_VGPR(x) asm volatile("" : "+v"(x))
 #endif
 
 namespace hrl {
@@ -58,7 +63,7 @@ struct DevCfg {
     int centroid_n_static;
     float centroid_sx, centroid_sy, walk_tx, walk_ty;
     int span_is_2pi;
-    float h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z, torque_scale, point_force, dt;
+    float h, inv_h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z, torque_scale, point_force, dt;
     int iters, nsub;
     float m0, a0, b0, m1, a1, b1, m2, a2, b2, L1, L2, r_torso, r_caps;
     float jlo[NJ], jhi[NJ];
@@ -106,7 +111,6 @@ struct WaveLds {
         F4 rowp[MAXR];           /* bias, 1/diag, lo, hi */
         struct { float legI[4][24], legp[4][8]; };
     };
-    float lam[2][MAXR];  /* accumulated impulses, ping-pong by iteration parity */
     int frn[MAXR];       /* friction rows: index of their normal row, else -1 */
     float st[32];        /* packed state record as stored in HBM */
     float items[32];
@@ -128,7 +132,11 @@ struct WaveLds {
     int gtouch[16];
 };
 
-struct LaneRegs { float ud, jby; };
+/* Per-lane registers that live across phases (the solver's working set):
+ *   ud       dof map: the lane's velocity component
+ *   lam0/1   row map: accumulated impulse of row `lane`, ping-pong by sweep parity
+ *   jb,rp,fn the NEXT row's (J,B)[dof], parameters and friction link, prefetched one row ahead */
+struct LaneRegs { float ud, lam0, lam1; F2 jb; F4 rp; int fn; };
 
 /* ------------------------------------------------------------------------------------------------ small math */
 /* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
@@ -497,12 +505,13 @@ HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, fl
 
 struct Hit { bool ok; float dist, n[3], c[3], rad; int link; };
 
-/* Phase C helper (lane = sphere): signed distance of sphere `lane` to surface f (0 ground, planes, boxes) */
+/* Phase C helper: signed distance of contact sphere `lane` (0 torso, 1+3l hip, 2+3l ankle, 3+3l tip; -1 = idle lane)
+ * to surface f (0 ground, 1..n_planes lateral half-spaces, then boxes) */
 HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q, int lane, int f) {
     Hit h;
     h.ok = false; h.dist = 0.f; h.rad = 0.f; h.link = 0;
     h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f;
-    if (lane >= 13) return h;
+    if (lane < 0 || lane >= 13) return h;
     int level = 0, leg = 0;
     h.rad = c.r_torso;
     if (lane > 0) {
@@ -558,7 +567,7 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, int lane, int nL, int 
 #pragma unroll
         for (int k = 0; k < NJ; ++k) J[6 + k] = (k == j) ? sgn : 0.f;
         response(L, zero6, 0, j >> 1, (j & 1) ? 0.f : sgn, (j & 1) ? sgn : 0.f, B);
-        bias = (dist > 0.f ? dist : c.erp_l * dist) / c.h;
+        bias = (dist > 0.f ? dist : c.erp_l * dist) * c.inv_h;
         hi = c.limp_max;
     } else {
         const int row = lane - nL;
@@ -584,7 +593,7 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, int lane, int nL, int 
         response(L, phi, level, leg, 0.f, 0.f, B);
         if (which == 0) {
             const float dist = L.cdist_[ci];
-            bias = (dist > 0.f ? dist : c.erp_c * dist) / c.h;
+            bias = (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h;
             hi = 1e30f;
         } else { bias = 0.f; frn = nL + ci; }
     }
@@ -595,7 +604,7 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, int lane, int nL, int 
 #pragma unroll
     for (int k = 0; k < 16; ++k) { F2 jb; jb.x = J[k]; jb.y = B[k]; L.JB[lane * JBS + k] = jb; }
     F4 rp; rp.x = bias; rp.y = invd; rp.z = lo; rp.w = hi;
-    L.rowp[lane] = rp; L.frn[lane] = frn; L.lam[0][lane] = 0.f;
+    L.rowp[lane] = rp; L.frn[lane] = frn;
 }
 
 /* Phase I (uniform): clamp joint rates was done in the dof map; integrate positions */
@@ -627,33 +636,52 @@ HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float 
     if (lane < 16) qn[lane] = mine;
 }
 
-/* Projected Gauss-Seidel in the dof map: every row update is one LDS read of (J,B)[r][dof], one 16-lane
- * rotate-add reduction for J.u, a handful of wave-uniform scalar ops and one FMA on the lane's velocity register.
- * Rows run in order (limits, normals, friction pairs); friction bounds use the normal impulse of this sweep. */
+/* Projected Gauss-Seidel in the dof map.  Every row update is a 16-lane rotate-add reduction for J.u, a handful of
+ * wave-uniform scalar ops and one FMA on the lane's velocity register.  Rows run in order (limits, normals, friction
+ * pairs); friction bounds use the normal impulse of this sweep.  The solver is a long dependent chain, so nothing
+ * on it waits for LDS: accumulated impulses live in lane registers (row r in lane r, read with a lane broadcast) and
+ * the next row's (J,B) and parameters are prefetched while the current row is reduced. */
+template <int CUR, class X>
+HRL_DEV void pgs_sweep(X &x, float mu, int nR) {
+    WaveLds &L = x.lds();
+    for (int r = 0; r < nR; ++r) {
+        x.each_reduce16(
+            [&](int lane) { return x.reg(lane).jb.x * x.reg(lane).ud; },
+            [&](int lane, float wv) {
+                LaneRegs &g = x.reg(lane);
+                const F4 rp = g.rp;
+                const int fn = g.fn;
+                const float jby = g.jb.y;
+                const int rn = (r + 1 < nR) ? r + 1 : 0; /* same rows every sweep: wrap around */
+                g.jb = L.JB[rn * JBS + (lane & 15)];
+                g.rp = L.rowp[rn];
+                g.fn = L.frn[rn];
+                const float lam = x.lane_lam(CUR, r);
+                const float lam_n = x.lane_lam(CUR ^ 1, fn < 0 ? 0 : fn);
+                const float hi = fn >= 0 ? mu * lam_n : rp.w;
+                const float lo = fn >= 0 ? -hi : rp.z;
+                const float ln = clampf(fma_(-(wv + rp.x), rp.y, lam), lo, hi);
+                const float dl = ln - lam;
+                g.ud = fma_(jby, dl, g.ud);
+                if (lane == r) { if (CUR) g.lam0 = ln; else g.lam1 = ln; }
+            });
+    }
+}
 template <class X>
 HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nR) {
     WaveLds &L = x.lds();
-    for (int it = 0; it < c.iters; ++it) {
-        const int cur = it & 1, nxt = cur ^ 1;
-        for (int r = 0; r < nR; ++r) {
-            x.each_reduce16(
-                [&](int lane) {
-                    const F2 jb = L.JB[r * JBS + (lane & 15)];
-                    x.reg(lane).jby = jb.y;
-                    return jb.x * x.reg(lane).ud;
-                },
-                [&](int lane, float wv) {
-                    const F4 rp = L.rowp[r];
-                    const float lam = L.lam[cur][r];
-                    float lo = rp.z, hi = rp.w;
-                    const int fn = L.frn[r];
-                    if (fn >= 0) { hi = c.mu * L.lam[nxt][fn]; lo = -hi; }
-                    const float ln = clampf(fma_(-(wv + rp.x), rp.y, lam), lo, hi);
-                    const float dl = ln - lam;
-                    x.reg(lane).ud = fma_(x.reg(lane).jby, dl, x.reg(lane).ud);
-                    L.lam[nxt][r] = ln;
-                });
-        }
+    if (nR <= 0) return;
+    x.each([&](int lane) {
+        LaneRegs &g = x.reg(lane);
+        g.lam0 = 0.f; g.lam1 = 0.f;
+        g.jb = L.JB[lane & 15]; g.rp = L.rowp[0]; g.fn = L.frn[0];
+    });
+    float mu = c.mu;
+    const int iters = c.iters;
+    HRL_PIN_VGPR(mu);
+    for (int it = 0; it < iters; it += 2) {
+        pgs_sweep<0>(x, mu, nR);
+        if (it + 1 < iters) pgs_sweep<1>(x, mu, nR);
     }
 }
 
@@ -667,13 +695,19 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
     x.each([&](int lane) { phase_hip(c, L, lane); });
     x.each([&](int lane) { phase_base(c, L, lane); });
     x.each([&](int lane) { x.reg(lane).ud = phase_forward_vel(c, L, lane); });
-    /* contacts: surface-major, sphere-minor; at most MAXC kept */
+    /* contacts in surface-major, sphere-minor order (ballot ranks follow lane order), at most MAXC kept:
+     * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = boxes */
     int nC = 0;
-    const int nsurf = 1 + c.n_planes + c.n_boxes;
-    for (int f = 0; f < nsurf; ++f) {
+    for (int pass = 0; pass < 3; ++pass) {
+        const int nsurf = pass == 0 ? 1 : (pass == 1 ? c.n_planes : c.n_boxes);
+        if (nsurf == 0) continue;
+        const int f0 = pass == 0 ? 0 : (pass == 1 ? 1 : 1 + c.n_planes);
         const int base = nC;
         int cnt = x.each_compact(
-            [&](int lane) { return sphere_vs_surface(c, L, q, lane, f); },
+            [&](int lane) {
+                const int fi = lane / 13, sph = lane - 13 * fi;
+                return sphere_vs_surface(c, L, q, fi < nsurf ? sph : -1, f0 + fi);
+            },
             [&](int lane, int rank, const Hit &h) {
                 const int i = base + rank;
                 if (i < MAXC) {
@@ -682,7 +716,7 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
                     L.cdist_[i] = h.dist; L.clink[i] = h.link;
                 }
             },
-            [&](int lane, const Hit &h) { if (f == 0 && lane < 16) L.gtouch[lane] = h.ok ? 1 : 0; });
+            [&](int lane, const Hit &h) { if (pass == 0 && lane < 16) L.gtouch[lane] = h.ok ? 1 : 0; });
         nC += cnt;
         if (nC > MAXC) nC = MAXC;
     }
@@ -782,10 +816,10 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) prod[k] = J[k] * B[k];
         const float dist = L.cdist_[ci];
-        F4 rp; rp.x = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) / c.h : 0.f; rp.y = 1.f / tree16(prod); rp.z = 0.f; rp.w = which == 0 ? 1e30f : 0.f;
+        F4 rp; rp.x = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h : 0.f; rp.y = 1.f / tree16(prod); rp.z = 0.f; rp.w = which == 0 ? 1e30f : 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { F2 jb; jb.x = J[k]; jb.y = B[k]; L.JB[lane * JBS + k] = jb; }
-        L.rowp[lane] = rp; L.frn[lane] = which == 0 ? -1 : ci; L.lam[0][lane] = 0.f;
+        L.rowp[lane] = rp; L.frn[lane] = which == 0 ? -1 : ci;
     });
     pgs_solve(x, c, 3 * nC);
     x.each([&](int lane) { if (lane < 16) L.u[lane] = x.reg(lane).ud; });

@@ -394,7 +394,7 @@ void FN(orc_antmj_reward)(const REAL *state29, REAL potential_old, REAL potentia
 #define MAXR 44
 
 typedef struct FN(orc_consts) {
-    REAL h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z;
+    REAL h, inv_h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z;
     REAL r_torso, r_caps, L1, L2;
     REAL m0, a0, b0;      /* composite torso: mass, inertia alpha*1 + beta*Z Z^T                         */
     REAL m1, a1, b1;      /* aux (short) capsule about its own COM: alpha*1 + beta*e e^T, e = capsule axis */
@@ -435,7 +435,7 @@ void FN(orc_consts_init)(const hrl_model *M, FN(orc_consts) * K) {
     K->m1 = R_(m[0]); K->a1 = R_(It[0]); K->b1 = R_(Ia[0] - It[0]);
     K->m2 = R_(m[1]); K->a2 = R_(It[1]); K->b2 = R_(Ia[1] - It[1]);
     K->r_torso = R_(rt); K->r_caps = R_(rc); K->L1 = R_(L1); K->L2 = R_(L2);
-    K->h = R_(M->timestep); K->g = R_(M->gravity); K->erp_c = R_(M->contact_erp); K->erp_l = R_(M->limit_erp);
+    K->h = R_(M->timestep); K->inv_h = R_(1) / K->h; K->g = R_(M->gravity); K->erp_c = R_(M->contact_erp); K->erp_l = R_(M->limit_erp);
     K->mu = R_(M->friction_ground * M->friction_robot); K->cdist = R_(M->contact_dist); K->lmargin = R_(M->limit_margin);
     K->vmax = R_(M->max_joint_vel); K->limp_max = R_(M->limit_max_impulse); K->ground_z = R_(M->ground_z);
     K->iters = M->solver_iters; K->nsub = M->frame_skip;
@@ -750,7 +750,7 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         J[nr][6 + j] = sgn;
         FN(orc_response)(&D, zero6, 0, j / 2, (j & 1) ? R_(0) : sgn, (j & 1) ? sgn : R_(0), B[nr]);
         B[nr][14] = B[nr][15] = 0;
-        bias[nr] = (dist > 0 ? dist : K->erp_l * dist) / h;
+        bias[nr] = (dist > 0 ? dist : K->erp_l * dist) * K->inv_h;
         lo[nr] = 0; hi[nr] = K->limp_max; fr_normal[nr] = -1;
         ++nr; ++nl;
     }
@@ -771,7 +771,7 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         FN(orc_response)(&D, phi, C[c].level, C[c].leg, 0, 0, B[nr]);
         B[nr][14] = B[nr][15] = 0;
         if (which == 0) {
-            bias[nr] = (C[c].dist > 0 ? C[c].dist : K->erp_c * C[c].dist) / h;
+            bias[nr] = (C[c].dist > 0 ? C[c].dist : K->erp_c * C[c].dist) * K->inv_h;
             lo[nr] = 0; hi[nr] = R_(1e30); fr_normal[nr] = -1;
         } else { bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fr_normal[nr] = nl + c; }
         ++nr;
@@ -854,7 +854,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
         FN(v3cross)(Jr[nr], cr[c], d);
         for (int k = 0; k < 3; ++k) { Jr[nr][3 + k] = d[k]; Br[nr][k] = Jr[nr][k] / I; Br[nr][3 + k] = d[k] / m; }
         { REAL prod[16] = {0}; for (int k = 0; k < 6; ++k) prod[k] = Jr[nr][k] * Br[nr][k]; invd[nr] = R_(1) / FN(sum16_tree)(prod); }
-        bias[nr] = which == 0 ? (cd[c] > 0 ? cd[c] : K->erp_c * cd[c]) / h : R_(0);
+        bias[nr] = which == 0 ? (cd[c] > 0 ? cd[c] : K->erp_c * cd[c]) * K->inv_h : R_(0);
         frn[nr] = which == 0 ? -1 : c;
         lam[nr] = 0; ++nr;
     }

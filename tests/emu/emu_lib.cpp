@@ -20,6 +20,7 @@ struct CpuExec {
     WaveLds &lds() { return L; }
     LaneRegs &reg(int lane) { return regs[lane]; }
     int uniform(int v) { return v; }
+    float lane_lam(int which, int src) { return which ? regs[src].lam1 : regs[src].lam0; }
     template <class F> void each(F f) {
         if (!reverse) for (int lane = 0; lane < 64; ++lane) f(lane);
         else for (int lane = 63; lane >= 0; --lane) f(lane);
