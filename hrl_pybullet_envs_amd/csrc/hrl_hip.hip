@@ -41,10 +41,10 @@ struct GpuExec {
     __device__ __forceinline__ WaveLds &lds() { return L; }
     __device__ __forceinline__ LaneRegs &reg(int) { return r; }
     __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-    /* accumulated impulse of solver row `src` (held by lane `src`), broadcast to the wave: v_readlane_b32 */
-    __device__ __forceinline__ float lane_lam(int which, int src) {
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(which ? r.lam1 : r.lam0), src));
-    }
+    /* Makes the lane id (and the friction links) opaque to the optimizer at this point.  Without it every
+     * lane-derived value of the unrolled solver (44 `lane == r` masks, LDS addresses, ...) is loop-invariant, gets
+     * hoisted to the top of the kernel and is spilled to scratch for the whole substep loop. */
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(lane), "+v"(r.fn)); }
     template <class F>
     __device__ __forceinline__ void each(F f) {
         f(lane);
@@ -65,19 +65,49 @@ struct GpuExec {
         const float v = row16_sum(produce(lane));
         consume(lane, v);
     }
+    /* every lane produces a pair, lane `src`'s pair is broadcast to the wave (two v_readlane_b32) */
+    template <class P, class C>
+    __device__ __forceinline__ void each_bcast(int src, P produce, C consume) {
+        const F2b v = produce(lane);
+        F2b b;
+        b.ln = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.ln), src));
+        b.dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.dl), src));
+        consume(lane, b);
+    }
 };
 
 /* The ~0.5 KB of constants are read through a pointer (scalar loads on demand, scalar-cache resident) rather than
- * passed by value: by-value kernel arguments were all preloaded into SGPRs and spilled (86 SGPR spills). */
+ * passed by value: by-value kernel arguments were all preloaded into SGPRs and spilled.
+ * One kernel per env kind: each contains only its own env's code, which keeps the instruction footprint small
+ * (all waves of a CU share one instruction cache). */
+template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_step(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
     GpuExec x{L, LaneRegs{}, (int)threadIdx.x};
-    step_entry(x, b, *cp, (int)blockIdx.x);
+    step_entry<KIND>(x, b, *cp, (int)blockIdx.x);
 }
+template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
     GpuExec x{L, LaneRegs{}, (int)threadIdx.x};
-    reset_entry(x, b, *cp, (int)blockIdx.x);
+    reset_entry<KIND>(x, b, *cp, (int)blockIdx.x);
+}
+using kernel_fn = void (*)(DevBufs, const DevCfg *);
+kernel_fn step_kernel(int kind) {
+    switch (kind) {
+        case HRL_ANT_FLAT: return k_step<HRL_ANT_FLAT>;
+        case HRL_ANT_GATHER: return k_step<HRL_ANT_GATHER>;
+        case HRL_ANT_MAZE: return k_step<HRL_ANT_MAZE>;
+        default: return k_step<HRL_POINT_GATHER>;
+    }
+}
+kernel_fn reset_kernel(int kind) {
+    switch (kind) {
+        case HRL_ANT_FLAT: return k_reset<HRL_ANT_FLAT>;
+        case HRL_ANT_GATHER: return k_reset<HRL_ANT_GATHER>;
+        case HRL_ANT_MAZE: return k_reset<HRL_ANT_MAZE>;
+        default: return k_reset<HRL_POINT_GATHER>;
+    }
 }
 /* packed record <-> split qpos[N][15], qvel[N][14] */
 __global__ void k_get_state(const float *state, float *qpos, float *qvel, int n) {
@@ -158,7 +188,7 @@ int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *st
     if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_reset: null handle or buffer");
     const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
     if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: gather kinds need the items buffer");
-    hipLaunchKernelGGL(k_reset, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc);
+    hipLaunchKernelGGL(reset_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_reset launch");
 }
@@ -168,7 +198,7 @@ int hrl_step(hrl_handle *h, const hrl_buffers *b, void *stream) {
         return fail(HRL_ERR_BAD_ARG, "hrl_step: null handle or buffer");
     const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
     if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: gather kinds need the items buffer");
-    hipLaunchKernelGGL(k_step, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
+    hipLaunchKernelGGL(step_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_step launch");
 }

@@ -28,15 +28,23 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <utility>
+
 #ifdef HRL_EMU
 #define HRL_DEV inline
 #define HRL_PIN_VGPR(x) ((void)0)
+#define HRL_PIN_INT(x) ((void)0)
+#define HRL_SCHED_FENCE() ((void)0)
 #else
+/* keep the instruction scheduler from moving code across this point (used between the unrolled rows of the
+ * A build: without it all 44 rows' LDS loads are hoisted to the front and spill) */
+#define HRL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define HRL_DEV __device__ __forceinline__
 /* Materialise a wave-uniform value in a VGPR here.  Used before the solver loop: a constant that is still an
  * outstanding scalar load inside the loop makes hipcc wait on lgkmcnt(0) there, which also drains the loop's LDS
  * prefetches (scalar loads and LDS share that counter). */
 #define HRL_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#define HRL_PIN_INT(x) asm volatile("" : "+s"(x))
 #endif
 
 namespace hrl {
@@ -44,7 +52,6 @@ namespace hrl {
 constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (assets/ant.xml:18-54) */
 constexpr int MAXC = 12;  /* contacts kept per substep */
 constexpr int MAXR = 44;  /* constraint rows per substep: 8 limits + 12 * (normal + 2 friction) */
-constexpr int JBS = 17;   /* row stride of the J/B table in float2 units (16 dofs + 1 pad: spreads rows over LDS banks) */
 
 struct F2 { float x, y; };
 struct alignas(16) F4 { float x, y, z, w; };
@@ -90,7 +97,7 @@ struct DevBufs {
  * (written later, in phase R). */
 struct WaveLds {
     union {
-        F2 JB[MAXR * JBS];       /* (J[r][d], B[r][d] = (M^-1 J^T)[d]) */
+        float Bt[MAXR][16];      /* B[r][d] = (M^-1 J_r^T)[d]: velocity response of every solver row */
         struct {                 /* phase K1 -> K2 hand-off (dead before the rows are built) */
             float Iaf[4][24];    /* articulated inertia of the foot seen through the ankle (upper triangle) */
             float paf[4][8];     /* its bias force */
@@ -107,11 +114,9 @@ struct WaveLds {
             float scal[8];       /* 0: reward, 1: food_rew, 2: dead_rew, 3: walk_target_dist, 4: yaw, 5: joints_at_limit */
         };
     };
-    union {
-        F4 rowp[MAXR];           /* bias, 1/diag, lo, hi */
-        struct { float legI[4][24], legp[4][8]; };
-    };
-    int frn[MAXR];       /* friction rows: index of their normal row, else -1 */
+    float legI[4][24], legp[4][8]; /* per-leg articulated inertia / bias force handed to the base */
+    float lamf[MAXR];    /* final impulses, for the velocity reconstruction */
+    float ustar[16];     /* unconstrained velocity (dof order) */
     float st[32];        /* packed state record as stored in HBM */
     float items[32];
     float act[8];
@@ -133,10 +138,14 @@ struct WaveLds {
 };
 
 /* Per-lane registers that live across phases (the solver's working set):
- *   ud       dof map: the lane's velocity component
- *   lam0/1   row map: accumulated impulse of row `lane`, ping-pong by sweep parity
- *   jb,rp,fn the NEXT row's (J,B)[dof], parameters and friction link, prefetched one row ahead */
-struct LaneRegs { float ud, lam0, lam1; F2 jb; F4 rp; int fn; };
+ * (the solver's working set; on the GPU these are VGPRs, the row-space solver never touches LDS in its sweeps) */
+struct LaneRegs {
+    float ud;                        /* dof map: the lane's velocity component */
+    float J[16], A[MAXR];            /* row map: the row's Jacobian and its row of A = J M^-1 J^T */
+    float w, lam, bias, invd, lo, hi; /* row map: constraint velocity, impulse, bias, 1/A_ii, bounds */
+    int fn;                          /* row map: friction rows: index of their normal row, else -1 */
+};
+struct F2b { float ln, dl; };
 
 /* ------------------------------------------------------------------------------------------------ small math */
 /* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
@@ -552,11 +561,12 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
 
 struct LimitHit { bool ok; float sgn, dist; };
 
-/* Phase R (row map): Jacobian row, its response B = M^-1 J^T, diagonal, bias and bounds -> LDS */
-HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, int lane, int nL, int nC) {
+/* Phase R1 (row map): Jacobian row and its velocity response B = M^-1 J^T.  J, bias and bounds stay in the lane's
+ * registers, B goes to LDS (every row needs every B to build its row of A). */
+HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane, int nL, int nC) {
     const int nR = nL + 3 * nC;
     if (lane >= nR) return;
-    float J[16], B[16], bias, lo = 0.f, hi = 0.f;
+    float J[16], B[16], bias, hi = 0.f;
     int frn = -1;
 #pragma unroll
     for (int k = 0; k < 16; ++k) J[k] = 0.f;
@@ -597,14 +607,38 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, int lane, int nL, int 
             hi = 1e30f;
         } else { bias = 0.f; frn = nL + ci; }
     }
-    float prod[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) prod[k] = J[k] * B[k];
-    const float invd = 1.f / tree16(prod);
+    for (int k = 0; k < 16; ++k) { g.J[k] = J[k]; L.Bt[lane][k] = B[k]; }
+    g.bias = bias; g.fn = frn; g.lam = 0.f; g.lo = 0.f; g.hi = frn >= 0 ? 0.f : hi;
+}
+
+/* Phase R2 (row map): the row's line of A = J M^-1 J^T (A[i][r] = J_i . B_r), 1/A_ii and the initial constraint
+ * velocity w_i = J_i . u*.  Sequential fma chains over the 16 dof slots; B_r and u* are LDS broadcast reads.
+ * The row index is a template parameter (pack expansion over 0..MAXR-1) so that A[] is statically indexed: a runtime
+ * index would push the array out of registers into scratch memory. */
+template <int R>
+HRL_DEV void build_A_row(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag) {
+    if (R < nR) { /* wave-uniform test; the rows form a flat sequence (no nesting) */
+        float a = g.J[0] * L.Bt[R][0];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { F2 jb; jb.x = J[k]; jb.y = B[k]; L.JB[lane * JBS + k] = jb; }
-    F4 rp; rp.x = bias; rp.y = invd; rp.z = lo; rp.w = hi;
-    L.rowp[lane] = rp; L.frn[lane] = frn;
+        for (int d = 1; d < 16; ++d) a = fma_(g.J[d], L.Bt[R][d], a);
+        g.A[R] = a;
+        diag = (R == lane) ? a : diag;
+    }
+}
+template <int... Rs>
+HRL_DEV void build_A_rows(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag, std::integer_sequence<int, Rs...>) {
+    (build_A_row<Rs>(L, g, lane, nR, diag), ...);
+}
+HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nR) {
+    if (lane >= nR) return;
+    float diag = 1.f;
+    build_A_rows(L, g, lane, nR, diag, std::make_integer_sequence<int, MAXR>{});
+    g.invd = 1.f / diag;
+    float wi = g.J[0] * L.ustar[0];
+#pragma unroll
+    for (int d = 1; d < 16; ++d) wi = fma_(g.J[d], L.ustar[d], wi);
+    g.w = wi;
 }
 
 /* Phase I (uniform): clamp joint rates was done in the dof map; integrate positions */
@@ -636,53 +670,54 @@ HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float 
     if (lane < 16) qn[lane] = mine;
 }
 
-/* Projected Gauss-Seidel in the dof map.  Every row update is a 16-lane rotate-add reduction for J.u, a handful of
- * wave-uniform scalar ops and one FMA on the lane's velocity register.  Rows run in order (limits, normals, friction
- * pairs); friction bounds use the normal impulse of this sweep.  The solver is a long dependent chain, so nothing
- * on it waits for LDS: accumulated impulses live in lane registers (row r in lane r, read with a lane broadcast) and
- * the next row's (J,B) and parameters are prefetched while the current row is reduced. */
-template <int CUR, class X>
-HRL_DEV void pgs_sweep(X &x, float mu, int nR) {
-    WaveLds &L = x.lds();
-    for (int r = 0; r < nR; ++r) {
-        x.each_reduce16(
-            [&](int lane) { return x.reg(lane).jb.x * x.reg(lane).ud; },
-            [&](int lane, float wv) {
+/* Projected Gauss-Seidel in ROW SPACE: lane i owns solver row i -- its constraint velocity w_i,
+ * impulse, bounds and its row of A -- all in registers.  Updating row r: lane r's candidate impulse is broadcast with a
+ * lane read, every lane applies w_i += A[i][r] * dl, and the friction rows of a just-updated normal row refresh
+ * their bounds.  No LDS and no cross-lane reduction on the solver's dependent chain.  Rows run in order (limits,
+ * normals, friction pairs), c.iters sweeps; the velocity is reconstructed once at the end from the impulses. */
+template <int R, class X>
+HRL_DEV void pgs_row(X &x, float mu, int nR) { /* update of solver row R (compile-time index: A[R] is a register) */
+    if (R < nR) {
+        x.each_bcast(
+            R,
+            [&](int lane) {
+                const LaneRegs &g = x.reg(lane);
+                F2b o;
+                o.ln = clampf(fma_(-(g.w + g.bias), g.invd, g.lam), g.lo, g.hi);
+                o.dl = o.ln - g.lam;
+                return o;
+            },
+            [&](int lane, const F2b &b) {
                 LaneRegs &g = x.reg(lane);
-                const F4 rp = g.rp;
-                const int fn = g.fn;
-                const float jby = g.jb.y;
-                const int rn = (r + 1 < nR) ? r + 1 : 0; /* same rows every sweep: wrap around */
-                g.jb = L.JB[rn * JBS + (lane & 15)];
-                g.rp = L.rowp[rn];
-                g.fn = L.frn[rn];
-                const float lam = x.lane_lam(CUR, r);
-                const float lam_n = x.lane_lam(CUR ^ 1, fn < 0 ? 0 : fn);
-                const float hi = fn >= 0 ? mu * lam_n : rp.w;
-                const float lo = fn >= 0 ? -hi : rp.z;
-                const float ln = clampf(fma_(-(wv + rp.x), rp.y, lam), lo, hi);
-                const float dl = ln - lam;
-                g.ud = fma_(jby, dl, g.ud);
-                if (lane == r) { if (CUR) g.lam0 = ln; else g.lam1 = ln; }
+                g.w = fma_(g.A[R], b.dl, g.w);
+                if (lane == R) g.lam = b.ln;
+                if (g.fn == R) { g.hi = mu * b.ln; g.lo = -g.hi; }
             });
     }
 }
+template <class X, int... Rs>
+HRL_DEV void pgs_sweep(X &x, float mu, int nR, std::integer_sequence<int, Rs...>) { /* rows in order, flat sequence */
+    (pgs_row<Rs>(x, mu, nR), ...);
+}
 template <class X>
-HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nR) {
+HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
     WaveLds &L = x.lds();
+    const int nR = ant ? nL + 3 * nC : 3 * nC;
     if (nR <= 0) return;
-    x.each([&](int lane) {
-        LaneRegs &g = x.reg(lane);
-        g.lam0 = 0.f; g.lam1 = 0.f;
-        g.jb = L.JB[lane & 15]; g.rp = L.rowp[0]; g.fn = L.frn[0];
-    });
+    x.each([&](int lane) { phase_build_A(L, x.reg(lane), lane, nR); });
     float mu = c.mu;
     const int iters = c.iters;
     HRL_PIN_VGPR(mu);
-    for (int it = 0; it < iters; it += 2) {
-        pgs_sweep<0>(x, mu, nR);
-        if (it + 1 < iters) pgs_sweep<1>(x, mu, nR);
+    for (int it = 0; it < iters; ++it) {
+        x.refresh();
+        pgs_sweep(x, mu, nR, std::make_integer_sequence<int, MAXR>{});
     }
+    x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });
+    x.each([&](int lane) { /* dof map: u = u* + sum_r B_r * lambda_r */
+        float v = L.ustar[lane & 15];
+        for (int r = 0; r < nR; ++r) v = fma_(L.Bt[r][lane & 15], L.lamf[r], v);
+        x.reg(lane).ud = v;
+    });
 }
 
 /* One physics substep.  On entry L.q[qi] / L.u / L.tau hold the state; on exit L.q[qi ^ 1] / L.u are advanced by h. */
@@ -691,10 +726,11 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
     WaveLds &L = x.lds();
     const float *q = L.q[qi];
     float *qn = L.q[qi ^ 1];
+    x.refresh(); /* keep lane-derived values local to the substep (see GpuExec::refresh) */
     x.each([&](int lane) { phase_kin_ankle(c, L, q, lane); });
     x.each([&](int lane) { phase_hip(c, L, lane); });
     x.each([&](int lane) { phase_base(c, L, lane); });
-    x.each([&](int lane) { x.reg(lane).ud = phase_forward_vel(c, L, lane); });
+    x.each([&](int lane) { const float v = phase_forward_vel(c, L, lane); x.reg(lane).ud = v; if (lane < 16) L.ustar[lane] = v; });
     /* contacts in surface-major, sphere-minor order (ballot ranks follow lane order), at most MAXC kept:
      * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = boxes */
     int nC = 0;
@@ -733,8 +769,8 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
         },
         [&](int lane, int rank, const LimitHit &r) { L.ljoint[rank] = lane; L.lsign[rank] = r.sgn; L.ldist[rank] = r.dist; },
         [&](int, const LimitHit &) {});
-    x.each([&](int lane) { phase_build_row(c, L, lane, nL, nC); });
-    pgs_solve(x, c, nL + 3 * nC);
+    x.each([&](int lane) { phase_build_row(c, L, x.reg(lane), lane, nL, nC); });
+    pgs_solve(x, c, nL, nC, true);
     x.each([&](int lane) {
         const int d = lane & 15;
         float v = x.reg(lane).ud;
@@ -756,6 +792,7 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
     const float *q = L.q[qi];
     float *qn = L.q[qi ^ 1];
     const float m = 10.f, he = 0.35f, I = m * (0.7f * 0.7f) / 6.f;
+    x.refresh();
     x.each([&](int lane) {
         const int d = lane & 15;
         float v = L.u[d];
@@ -763,6 +800,7 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
         if (d == 4) v = fma_(c.h, L.tau[1] / m, L.u[4]);
         if (d == 5) v = fma_(c.h, L.tau[2] / m - c.g, L.u[5]);
         x.reg(lane).ud = d < 6 ? v : 0.f;
+        if (lane < 16) L.ustar[lane] = d < 6 ? v : 0.f;
         float ax_[3], ay_[3], az_[3];
         quat_axes(q[3], q[4], q[5], q[6], ax_, ay_, az_);
 #pragma unroll
@@ -802,9 +840,10 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
     }
     x.each([&](int lane) { /* row map */
         if (lane >= 3 * nC) return;
+        LaneRegs &g = x.reg(lane);
         const int ci = lane < nC ? lane : (lane - nC) >> 1, which = lane < nC ? 0 : 1 + ((lane - nC) & 1);
         float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
-        float t1[3], t2[3], d[3], J[16], B[16], prod[16];
+        float t1[3], t2[3], d[3], J[16], B[16];
         tangent_basis(n, t1, t2);
 #pragma unroll
         for (int k = 0; k < 3; ++k) d[k] = which == 0 ? n[k] : (which == 1 ? t1[k] : t2[k]);
@@ -813,15 +852,13 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
         cross3(J, r, d);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { J[3 + k] = d[k]; B[k] = J[k] / I; B[3 + k] = d[k] / m; }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) prod[k] = J[k] * B[k];
         const float dist = L.cdist_[ci];
-        F4 rp; rp.x = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h : 0.f; rp.y = 1.f / tree16(prod); rp.z = 0.f; rp.w = which == 0 ? 1e30f : 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { F2 jb; jb.x = J[k]; jb.y = B[k]; L.JB[lane * JBS + k] = jb; }
-        L.rowp[lane] = rp; L.frn[lane] = which == 0 ? -1 : ci;
+        for (int k = 0; k < 16; ++k) { g.J[k] = J[k]; L.Bt[lane][k] = B[k]; }
+        g.bias = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h : 0.f;
+        g.fn = which == 0 ? -1 : ci; g.lam = 0.f; g.lo = 0.f; g.hi = which == 0 ? 1e30f : 0.f;
     });
-    pgs_solve(x, c, 3 * nC);
+    pgs_solve(x, c, 0, nC, false);
     x.each([&](int lane) { if (lane < 16) L.u[lane] = x.reg(lane).ud; });
     x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });
 }
@@ -900,12 +937,13 @@ HRL_DEV void maze_line(int l, float *a) {
 
 /* Phase O1: upstream WalkerBase.calc_state (28-vector clipped to +-5) into L.s28, plus walk_target_dist, yaw and
  * joints_at_limit into L.scal.  `with_centroid` needs L.ph/pa/tip of the CURRENT qpos (phase_kin_ankle on L.st). */
+template <int KIND>
 HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_feet, bool with_centroid) {
     const float *qp = L.st, *qv = L.st + 15;
     float rpy[3];
     quat_to_rpy(qp + 3, rpy);
     float tx = c.walk_tx, ty = c.walk_ty;
-    if (c.kind == 2) { /* maze: the episode's target */
+    if (KIND == 2) { /* maze: the episode's target */
         const int ti = L.aux[3];
         tx = c.targets[0][0]; ty = c.targets[0][1];
 #pragma unroll
@@ -996,15 +1034,16 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
 }
 
 /* Phase O3: final observation vector into L.obs, non-finite flag into L.flags[0] */
+template <int KIND>
 HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
     if (lane >= c.obs_dim) return;
     float v = 0.f;
-    if (c.kind == 0) v = L.st[lane];                       /* MjAnt.py:17-25: qpos | qvel */
-    else if (c.kind == 3) {                                /* point: calc_state(8) | food | poison */
+    if (KIND == 0) v = L.st[lane];                       /* MjAnt.py:17-25: qpos | qvel */
+    else if (KIND == 3) {                                /* point: calc_state(8) | food | poison */
         if (lane < 8) v = L.s28[lane];
     } else if (lane < 26) v = L.s28[lane == 0 ? 0 : lane + 2]; /* ant_gather_env.py:81, ant_maze_bullet_env.py:75 */
-    const int nb = (c.kind == 3) ? 8 : 26;
-    if ((c.kind == 1 || c.kind == 3) && lane >= nb) { /* ant_gather_env.py:128-177: nearest in-range item per bin and type */
+    const int nb = (KIND == 3) ? 8 : 26;
+    if ((KIND == 1 || KIND == 3) && lane >= nb) { /* ant_gather_env.py:128-177: nearest in-range item per bin and type */
         const int b = lane - nb, type = b / c.n_bins, bin = b - type * c.n_bins;
         const int k0 = type ? c.n_food : 0, k1 = type ? c.n_food + c.n_poison : c.n_food;
         float best = 0.f;
@@ -1012,7 +1051,7 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
             if (L.ibin[k] == (float)bin && L.iint[k] > best) best = L.iint[k];
         v = best;
     }
-    if (c.kind == 2 && lane >= 26) {
+    if (KIND == 2 && lane >= 26) {
         const float rx = L.st[0], ry = L.st[1], yaw = L.scal[4];
         const int ti = L.aux[3];
         float tx = c.targets[0][0], ty = c.targets[0][1];
@@ -1086,29 +1125,29 @@ HRL_DEV void phase_point_state(const DevCfg &c, WaveLds &L, int lane) {
 }
 
 /* Observation of the state in L.st / L.items / L.aux into L.obs (and L.scal).  Used by step and by reset. */
-template <class X>
+template <int KIND, class X>
 HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
     WaveLds &L = x.lds();
-    const bool centroid = (c.kind == 0 || c.kind == 2);
+    const bool centroid = (KIND == 0 || KIND == 2);
     if (centroid) { /* link positions of the final pose for the parts centroid; its LDS hand-off area overlays the
                        task scratch, so it runs before anything below is written */
         x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
         x.each([&](int lane) { phase_kin_ankle(c, L, L.q[0], lane); });
     }
     x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
-    if (c.kind == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
+    if (KIND == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
     else {
-        const bool feet = step_mode && c.kind == 2; /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
-        x.each([&](int lane) { phase_calc_state(c, L, lane, feet, centroid); });
+        const bool feet = step_mode && KIND == 2; /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
+        x.each([&](int lane) { phase_calc_state<KIND>(c, L, lane, feet, centroid); });
     }
-    if (c.kind == 1 || c.kind == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode); });
-    x.each([&](int lane) { phase_pack_obs(c, L, lane); });
+    if (KIND == 1 || KIND == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode); });
+    x.each([&](int lane) { phase_pack_obs<KIND>(c, L, lane); });
 }
 
 /* ================================================================================================= RESET / STEP */
 
 /* Env.reset(): ant_gather_env.py:68-74, gather_scene.py:38-50, ant_maze_bullet_env.py:104-121, point_bot.py:12,25-26 */
-template <class X>
+template <int KIND, class X>
 HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
     WaveLds &L = x.lds();
     x.each([&](int lane) {
@@ -1116,10 +1155,10 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
         if (lane < 32) {
             float v = 0.f;
             if (lane == 6) v = 1.f;
-            if (c.kind == 3) { if (lane == 2) v = 0.5f; if (lane == 30) v = 1.f; }
+            if (KIND == 3) { if (lane == 2) v = 0.5f; if (lane == 30) v = 1.f; }
             else {
                 float z0 = 0.75f;
-                if (c.kind == 2) { z0 = c.start_pos[2]; if (lane == 0) v = c.start_pos[0]; if (lane == 1) v = c.start_pos[1]; }
+                if (KIND == 2) { z0 = c.start_pos[2]; if (lane == 0) v = c.start_pos[0]; if (lane == 1) v = c.start_pos[1]; }
                 if (lane == 2 || lane == 30) v = z0;
                 if (lane >= 7 && lane < 15) {
                     const int j = lane - 7;
@@ -1130,7 +1169,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
                 }
             }
             L.st[lane] = v;
-        } else if (c.kind == 1 || c.kind == 3) {
+        } else if (KIND == 1 || KIND == 3) {
             const int i = lane - 32; /* lanes 32..47: item i */
             if (i < 16) {
                 float px = 0.f, py = 0.f;
@@ -1140,15 +1179,15 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
         }
         if (lane < 16) L.u[lane] = 0.f;
         if (lane < 8) L.tau[lane] = 0.f;
-        if (lane == 63 && c.kind == 2) {
+        if (lane == 63 && KIND == 2) {
             uint32_t r[4];
             philox4x32(c, env, ep, (3u << 16), 0u, r);
             L.aux[3] = (int)(r[0] % (uint32_t)c.n_targets);
         }
     });
     x.each([&](int lane) { if (lane == 0) L.aux[0] = 0; if (lane == 2) L.aux[2] = L.aux[2] + 1; });
-    compute_obs(x, c, env, false);
-    x.each([&](int lane) { if (lane == 31) L.st[31] = (c.kind == 0 || c.kind == 2) ? -L.scal[3] / c.dt : 0.f; }); /* upstream calc_potential */
+    compute_obs<KIND>(x, c, env, false);
+    x.each([&](int lane) { if (lane == 31) L.st[31] = (KIND == 0 || KIND == 2) ? -L.scal[3] / c.dt : 0.f; }); /* upstream calc_potential */
 }
 
 template <class X>
@@ -1173,16 +1212,16 @@ HRL_DEV void store_env(X &x, const DevBufs &b, const DevCfg &c, int e) {
 }
 
 /* hrl_reset for one env (one wave) */
-template <class X>
+template <int KIND, class X>
 HRL_DEV void reset_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     if (b.mask && !b.mask[e]) return;
     load_env(x, b, c, e, false);
-    reset_env(x, c, c.env_id_offset + e);
+    reset_env<KIND>(x, c, c.env_id_offset + e);
     store_env(x, b, c, e);
 }
 
 /* hrl_step for one env (one wave) */
-template <class X>
+template <int KIND, class X>
 HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     WaveLds &L = x.lds();
     const long long env = c.env_id_offset + e;
@@ -1196,16 +1235,19 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         }
         if (lane >= 16 && lane < 24) {
             const int j = lane - 16;
-            if (c.kind == 3) { /* point_bot.py:28-31: a / |a| * 500 N in the world xy plane */
+            if (KIND == 3) { /* point_bot.py:28-31: a / |a| * 500 N in the world xy plane */
                 const float n = sqrtf(L.act[0] * L.act[0] + L.act[1] * L.act[1]);
                 L.tau[j] = j < 2 ? L.act[j] / n * c.point_force : 0.f;
             } else L.tau[j] = c.torque_scale * clampf(L.act[j], -1.f, 1.f);
         }
     });
     int qi = 0;
-    for (int s = 0; s < c.nsub; ++s) {
-        if (c.kind == 3) point_substep(x, c, qi); else ant_substep(x, c, qi);
+    HRL_PIN_INT(qi);
+#pragma unroll 1
+    for (int s = 0; s < c.nsub; ++s) { /* one copy of the substep body: it is the kernel's instruction-cache footprint */
+        if constexpr (KIND == 3) point_substep(x, c, qi); else ant_substep(x, c, qi);
         qi ^= 1;
+        HRL_PIN_INT(qi); /* keep the ping-pong index a run-time value so the body is not cloned per parity */
     }
     x.each([&](int lane) { /* back to the packed record */
         if (lane < 15) L.st[lane] = L.q[qi][lane];
@@ -1214,19 +1256,19 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             L.st[15 + k] = k < 3 ? L.u[3 + k] : (k < 6 ? L.u[k - 3] : L.u[k]);
         }
     });
-    compute_obs(x, c, env, true);
+    compute_obs<KIND>(x, c, env, true);
     /* reward / done (uniform values, every lane computes them; lane-selected stores) */
     x.each([&](int lane) {
         float rew = 0.f, food = 0.f, dead = 0.f;
         int done = 0;
-        if (c.kind == 1 || c.kind == 3) { /* ant_gather_env.py:99-119 */
+        if (KIND == 1 || KIND == 3) { /* ant_gather_env.py:99-119 */
             for (int k = 0; k < c.n_food + c.n_poison; ++k) food += L.irew[k];
             float alive = 1.f;
-            if (c.kind == 1) alive = (L.obs[0] + L.st[30] > 0.26f) ? 1.f : -1.f;
+            if (KIND == 1) alive = (L.obs[0] + L.st[30] > 0.26f) ? 1.f : -1.f;
             done = (alive < 0.f) || L.flags[0];
             dead = alive < 0.f ? c.dying_cost : 0.f;
             rew = food + dead;
-        } else if (c.kind == 0) { /* MjAnt.py:36-97 */
+        } else if (KIND == 0) { /* MjAnt.py:36-97 */
             const float alive = L.st[2] > 0.26f ? 1.f : -1.f;
             done = (alive < 0.f) || L.flags[0];
             const float pot = -L.scal[3] / c.dt, progress = pot - L.st[31];
@@ -1257,15 +1299,35 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     x.each([&](int lane) { /* each LDS word below is read and written by one lane only */
         if (lane == 0) { L.aux[0] = L.aux[0] + 1; b.reward[e] = L.scal[0]; b.done[e] = (uint8_t)L.flags[1]; }
         if (lane == 1) L.aux[1] = L.aux[1] + 1;
-        if (lane == 2 && (c.kind == 0 || c.kind == 2)) L.st[31] = L.red[0];
+        if (lane == 2 && (KIND == 0 || KIND == 2)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
         if (lane >= 4 && lane < 8) {
             const int k = lane - 4;
             b.info[(size_t)e * 4 + k] = k == 0 ? L.scal[1] : (k == 1 ? L.scal[2] : (k == 2 ? L.red[1] : L.red[2]));
         }
     });
-    if (x.uniform(L.flags[1]) && c.auto_reset) reset_env(x, c, env);
+    if (x.uniform(L.flags[1]) && c.auto_reset) reset_env<KIND>(x, c, env);
     store_env(x, b, c, e);
+}
+
+/* run-time kind -> compile-time KIND (each instantiation only contains its own env's code) */
+template <class X>
+HRL_DEV void step_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
+    switch (c.kind) {
+        case 0: step_entry<0>(x, b, c, e); break;
+        case 1: step_entry<1>(x, b, c, e); break;
+        case 2: step_entry<2>(x, b, c, e); break;
+        default: step_entry<3>(x, b, c, e); break;
+    }
+}
+template <class X>
+HRL_DEV void reset_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
+    switch (c.kind) {
+        case 0: reset_entry<0>(x, b, c, e); break;
+        case 1: reset_entry<1>(x, b, c, e); break;
+        case 2: reset_entry<2>(x, b, c, e); break;
+        default: reset_entry<3>(x, b, c, e); break;
+    }
 }
 
 }  // namespace hrl

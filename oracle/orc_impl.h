@@ -666,6 +666,41 @@ static void FN(tangent_basis)(const REAL *n, REAL *t1, REAL *t2) {
     }
 }
 
+/* Projected Gauss-Seidel in ROW SPACE.  With A = J M^-1 J^T (row i of A is computed from row i's own
+ * Jacobian: A[i][r] = J_i . B_r, a sequential fma chain over the 16 dof slots) every row keeps its constraint
+ * velocity w_i = J_i . u; updating row r by dl changes every w_i by A[i][r] * dl.  Rows are visited in order
+ * (limits, normals, friction pairs) `iters` times; a friction row's bounds are +-mu * (current impulse of its normal
+ * row).  The generalized velocity is reconstructed once at the end: u += sum_r B_r * lambda_r. */
+#define ORC_MAXROWS 44
+static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, const REAL *hic, const int *frn, REAL mu,
+                        int iters, REAL *un, REAL *lam) {
+    static _Thread_local REAL A[ORC_MAXROWS][ORC_MAXROWS];
+    REAL w[ORC_MAXROWS], invd[ORC_MAXROWS], lo[ORC_MAXROWS], hi[ORC_MAXROWS];
+    for (int i = 0; i < nr; ++i) {
+        for (int r = 0; r < nr; ++r) {
+            REAL a = J[i][0] * B[r][0];
+            for (int d = 1; d < 16; ++d) a = FMA_(J[i][d], B[r][d], a);
+            A[i][r] = a;
+        }
+        invd[i] = R_(1) / A[i][i];
+        REAL wi = J[i][0] * un[0];
+        for (int d = 1; d < 16; ++d) wi = FMA_(J[i][d], un[d], wi);
+        w[i] = wi; lam[i] = 0; lo[i] = 0; hi[i] = frn[i] >= 0 ? R_(0) : hic[i];
+    }
+    for (int it = 0; it < iters; ++it)
+        for (int r = 0; r < nr; ++r) {
+            REAL ln = FN(clampr)(FMA_(-(w[r] + bias[r]), invd[r], lam[r]), lo[r], hi[r]);
+            REAL dl = ln - lam[r];
+            lam[r] = ln;
+            for (int i = 0; i < nr; ++i) {
+                w[i] = FMA_(A[i][r], dl, w[i]);
+                if (frn[i] == r) { hi[i] = mu * ln; lo[i] = -hi[i]; }
+            }
+        }
+    for (int d = 0; d < 16; ++d)
+        for (int r = 0; r < nr; ++r) un[d] = FMA_(B[r][d], lam[r], un[d]);
+}
+
 typedef struct FN(orc_contact) { int level, leg, sphere; REAL r[3], n[3], dist; } FN(orc_contact);
 
 /* sphere `s` (0 torso, 1+3l hip, 2+3l ankle, 3+3l tip): centre relative to O, radius, owning body */
@@ -736,7 +771,7 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
     for (int j = 0; j < NJ; ++j) un[6 + j] = FMA_(h, D.qdd[j], u[6 + j]);
     un[14] = un[15] = 0;
     /* (2) constraint rows: joint limits, contact normals, friction pairs */
-    REAL J[MAXR][16], B[MAXR][16], bias[MAXR], invd[MAXR], lo[MAXR], hi[MAXR], lam[MAXR];
+    REAL J[MAXR][16], B[MAXR][16], bias[MAXR], hi[MAXR], lam[MAXR]; /* hi: bound of non-friction rows */
     int fr_normal[MAXR];
     int nr = 0, nl = 0;
     REAL zero6[6] = {0, 0, 0, 0, 0, 0};
@@ -751,7 +786,7 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         FN(orc_response)(&D, zero6, 0, j / 2, (j & 1) ? R_(0) : sgn, (j & 1) ? sgn : R_(0), B[nr]);
         B[nr][14] = B[nr][15] = 0;
         bias[nr] = (dist > 0 ? dist : K->erp_l * dist) * K->inv_h;
-        lo[nr] = 0; hi[nr] = K->limp_max; fr_normal[nr] = -1;
+        hi[nr] = K->limp_max; fr_normal[nr] = -1;
         ++nr; ++nl;
     }
     FN(orc_contact) C[MAXC];
@@ -772,28 +807,12 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         B[nr][14] = B[nr][15] = 0;
         if (which == 0) {
             bias[nr] = (C[c].dist > 0 ? C[c].dist : K->erp_c * C[c].dist) * K->inv_h;
-            lo[nr] = 0; hi[nr] = R_(1e30); fr_normal[nr] = -1;
-        } else { bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fr_normal[nr] = nl + c; }
+            hi[nr] = R_(1e30); fr_normal[nr] = -1;
+        } else { bias[nr] = 0; hi[nr] = 0; fr_normal[nr] = nl + c; }
         ++nr;
     }
-    for (int r = 0; r < nr; ++r) {
-        REAL prod[16];
-        for (int k = 0; k < 16; ++k) prod[k] = J[r][k] * B[r][k];
-        invd[r] = R_(1) / FN(sum16_tree)(prod);
-        lam[r] = 0;
-    }
-    /* (3) projected Gauss-Seidel, rows in order, friction bounds from the current normal impulse */
-    for (int it = 0; it < K->iters; ++it)
-        for (int r = 0; r < nr; ++r) {
-            REAL prod[16], l_lo = lo[r], l_hi = hi[r];
-            if (fr_normal[r] >= 0) { l_hi = K->mu * lam[fr_normal[r]]; l_lo = -l_hi; }
-            for (int k = 0; k < 16; ++k) prod[k] = J[r][k] * un[k];
-            REAL wv = FN(sum16_tree)(prod);
-            REAL ln = FN(clampr)(FMA_(-(wv + bias[r]), invd[r], lam[r]), l_lo, l_hi);
-            REAL dl = ln - lam[r];
-            lam[r] = ln;
-            for (int k = 0; k < 16; ++k) un[k] = FMA_(B[r][k], dl, un[k]);
-        }
+    /* (3) projected Gauss-Seidel in row space */
+    FN(orc_pgs)(nr, J, B, bias, hi, fr_normal, K->mu, K->iters, un, lam);
     /* (4) joint-rate clamp and position integration (semi-implicit Euler, exponential map for the quaternion) */
     for (int j = 0; j < NJ; ++j) un[6 + j] = FN(clampr)(un[6 + j], -K->vmax, K->vmax);
     for (int k = 0; k < NDOF; ++k) u[k] = un[k];
@@ -825,7 +844,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
     for (int k = 0; k < 3; ++k) un[k] = u[k];
     un[3] = FMA_(h, force[0] / m, u[3]); un[4] = FMA_(h, force[1] / m, u[4]); un[5] = FMA_(h, force[2] / m - K->g, u[5]);
     /* contacts: 8 corners vs ground + lateral planes, surface-major order, at most MAXC */
-    REAL Jr[3 * MAXC][6], Br[3 * MAXC][6], bias[3 * MAXC], invd[3 * MAXC], lam[3 * MAXC];
+    REAL Jr[3 * MAXC][16], Br[3 * MAXC][16], bias[3 * MAXC], hic[3 * MAXC], lam[3 * MAXC];
     int frn[3 * MAXC], nc = 0;
     REAL cr[MAXC][3], cn[MAXC][3], cd[MAXC];
     for (int f = 0; f < 1 + W->n_planes; ++f)
@@ -851,24 +870,18 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
         REAL t1[3], t2[3];
         FN(tangent_basis)(cn[c], t1, t2);
         const REAL *d = which == 0 ? cn[c] : (which == 1 ? t1 : t2);
+        memset(Jr[nr], 0, sizeof(Jr[nr])); memset(Br[nr], 0, sizeof(Br[nr]));
         FN(v3cross)(Jr[nr], cr[c], d);
         for (int k = 0; k < 3; ++k) { Jr[nr][3 + k] = d[k]; Br[nr][k] = Jr[nr][k] / I; Br[nr][3 + k] = d[k] / m; }
-        { REAL prod[16] = {0}; for (int k = 0; k < 6; ++k) prod[k] = Jr[nr][k] * Br[nr][k]; invd[nr] = R_(1) / FN(sum16_tree)(prod); }
         bias[nr] = which == 0 ? (cd[c] > 0 ? cd[c] : K->erp_c * cd[c]) * K->inv_h : R_(0);
+        hic[nr] = which == 0 ? R_(1e30) : R_(0);
         frn[nr] = which == 0 ? -1 : c;
-        lam[nr] = 0; ++nr;
+        ++nr;
     }
-    for (int it = 0; it < K->iters; ++it)
-        for (int r = 0; r < nr; ++r) {
-            REAL l_lo = 0, l_hi = R_(1e30);
-            if (frn[r] >= 0) { l_hi = K->mu * lam[frn[r]]; l_lo = -l_hi; }
-            REAL prod[16] = {0};
-            for (int k = 0; k < 6; ++k) prod[k] = Jr[r][k] * un[k];
-            REAL wv = FN(sum16_tree)(prod);
-            REAL ln = FN(clampr)(FMA_(-(wv + bias[r]), invd[r], lam[r]), l_lo, l_hi), dl = ln - lam[r];
-            lam[r] = ln;
-            for (int k = 0; k < 6; ++k) un[k] = FMA_(Br[r][k], dl, un[k]);
-        }
+    REAL un16[16] = {0};
+    for (int k = 0; k < 6; ++k) un16[k] = un[k];
+    FN(orc_pgs)(nr, Jr, Br, bias, hic, frn, K->mu, K->iters, un16, lam);
+    for (int k = 0; k < 6; ++k) un[k] = un16[k];
     for (int k = 0; k < 6; ++k) u[k] = un[k];
     for (int k = 0; k < 3; ++k) q[k] = FMA_(h, u[3 + k], q[k]);
     {

@@ -20,7 +20,7 @@ struct CpuExec {
     WaveLds &lds() { return L; }
     LaneRegs &reg(int lane) { return regs[lane]; }
     int uniform(int v) { return v; }
-    float lane_lam(int which, int src) { return which ? regs[src].lam1 : regs[src].lam0; }
+    void refresh() {}
     template <class F> void each(F f) {
         if (!reverse) for (int lane = 0; lane < 64; ++lane) f(lane);
         else for (int lane = 63; lane >= 0; --lane) f(lane);
@@ -34,6 +34,13 @@ struct CpuExec {
         if (!reverse) { for (int lane = 0; lane < 64; ++lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane]); } }
         else { for (int lane = 63; lane >= 0; --lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane]); } }
         return n;
+    }
+    template <class P, class C> void each_bcast(int src, P produce, C consume) {
+        F2b v[64];
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) v[lane] = produce(lane);
+        else for (int lane = 63; lane >= 0; --lane) v[lane] = produce(lane);
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, v[src]);
+        else for (int lane = 63; lane >= 0; --lane) consume(lane, v[src]);
     }
     template <class P, class C> void each_reduce16(P produce, C consume) {
         float v[64];
@@ -62,14 +69,14 @@ int emu_reset(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, 
     if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, mask);
-    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; reset_entry(x, d, c, e); }
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; reset_dispatch(x, d, c, e); }
     return HRL_OK;
 }
 int emu_step(const hrl_config *cfg, const hrl_buffers *b, int reverse) {
     if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, nullptr);
-    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; step_entry(x, d, c, e); }
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; step_dispatch(x, d, c, e); }
     return HRL_OK;
 }
 int emu_lds_bytes(void) { return (int)sizeof(WaveLds); }
