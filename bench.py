@@ -51,7 +51,11 @@ def cpu_baseline(kind, seconds_budget=15.0):
     out = {'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
            'sample': f'CPU oracle (oracle/liborc.so, fp32), {NAMES[kind]}, 1 env x {steps} random-action steps, '
                      f'1 thread, {dt:.1f} s'}
-    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = max(1, min(ncpu, 16))  # the GPU box gives one GPU's job a 16-core share
     cfg_n = orc.default_config(KINDS[kind], num_envs=4096, seed=0, auto_reset=1)
     dtn = L.orc_bench_f32(C.byref(cfg_n), 4, ncpu, C.byref(cs))
     nsteps = max(4, int(4 / dtn * 5.0))
@@ -59,6 +63,18 @@ def cpu_baseline(kind, seconds_budget=15.0):
     out['all_cores'] = {'value': 4096 * nsteps / dtn, 'cores': ncpu,
                         'sample': f'same oracle, 4096 envs x {nsteps} steps, OpenMP over {ncpu} threads, {dtn:.1f} s'}
     return out
+
+
+def profiled_traffic(kind, n):
+    """HBM bytes per launch of k_step from the committed rocprofv3 PMC summary (profiles/), scaled to n envs.
+    bench.py cannot collect counters itself; None when no summary for this kernel is committed."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)[kind]
+        return (d['fetch_bytes_per_env'] + d['write_bytes_per_env']) * n
+    except Exception:
+        return None
 
 
 def main():
@@ -126,7 +142,7 @@ def main():
                        'substeps_per_step': 4, 'parallelism': f'env-sharded x{world}, no data-path collective; '
                                                               f'RCCL all-gather of episode returns every {args.gather_every} steps'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'k_step', 'kernel_avg_us': launch_s * 1e6,
+                         'traffic': profiled_traffic(args.kind, n), 'kernel': 'k_step', 'kernel_avg_us': launch_s * 1e6,
                          'algorithmic_bytes_per_launch': ALG_BYTES[args.kind] * n,
                          'note': 'latency/VALU-bound by construction (~1.4e5 flop per env-step, ~240 flop/B): see DESIGN.md 5'},
         }

@@ -83,13 +83,15 @@ struct GpuExec {
 template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_step(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
-    GpuExec x{L, LaneRegs{}, (int)threadIdx.x};
+    LaneRegs regs; /* deliberately uninitialised: every field is defined by the phase that produces it */
+    GpuExec x{L, regs, (int)threadIdx.x};
     step_entry<KIND>(x, b, *cp, (int)blockIdx.x);
 }
 template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L;
-    GpuExec x{L, LaneRegs{}, (int)threadIdx.x};
+    LaneRegs regs;
+    GpuExec x{L, regs, (int)threadIdx.x};
     reset_entry<KIND>(x, b, *cp, (int)blockIdx.x);
 }
 using kernel_fn = void (*)(DevBufs, const DevCfg *);

@@ -565,14 +565,24 @@ struct LimitHit { bool ok; float sgn, dist; };
  * registers, B goes to LDS (every row needs every B to build its row of A). */
 HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane, int nL, int nC) {
     const int nR = nL + 3 * nC;
-    if (lane >= nR) return;
+    /* Lanes beyond the last row recompute row 0 and discard it: every lane then (re)defines all of its solver
+     * registers each substep, so none of them stays live around the substep loop (a partially written register
+     * would, and the 60 of them would be spilled in the register-hungry leg phases). */
+    const bool active = lane < nR;
+    const int row_id = active ? lane : 0;
     float J[16], B[16], bias, hi = 0.f;
     int frn = -1;
 #pragma unroll
     for (int k = 0; k < 16; ++k) J[k] = 0.f;
-    if (lane < nL) {
-        const int j = L.ljoint[lane];
-        const float sgn = L.lsign[lane], dist = L.ldist[lane];
+    if (nR == 0) { /* no rows this substep (wave-uniform): still define every register */
+#pragma unroll
+        for (int k = 0; k < 16; ++k) g.J[k] = 0.f;
+        g.bias = 0.f; g.fn = -1; g.lam = 0.f; g.lo = 0.f; g.hi = 0.f;
+        return;
+    }
+    if (row_id < nL) {
+        const int j = L.ljoint[row_id];
+        const float sgn = L.lsign[row_id], dist = L.ldist[row_id];
         float zero6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NJ; ++k) J[6 + k] = (k == j) ? sgn : 0.f;
@@ -580,7 +590,7 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
         bias = (dist > 0.f ? dist : c.erp_l * dist) * c.inv_h;
         hi = c.limp_max;
     } else {
-        const int row = lane - nL;
+        const int row = row_id - nL;
         const int ci = row < nC ? row : (row - nC) >> 1, which = row < nC ? 0 : 1 + ((row - nC) & 1);
         float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
         float t1[3], t2[3], phi[6];
@@ -608,8 +618,12 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
         } else { bias = 0.f; frn = nL + ci; }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { g.J[k] = J[k]; L.Bt[lane][k] = B[k]; }
-    g.bias = bias; g.fn = frn; g.lam = 0.f; g.lo = 0.f; g.hi = frn >= 0 ? 0.f : hi;
+    for (int k = 0; k < 16; ++k) g.J[k] = J[k];
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) L.Bt[lane][k] = B[k];
+    }
+    g.bias = bias; g.fn = active ? frn : -1; g.lam = 0.f; g.lo = 0.f; g.hi = frn >= 0 ? 0.f : hi;
 }
 
 /* Phase R2 (row map): the row's line of A = J M^-1 J^T (A[i][r] = J_i . B_r), 1/A_ii and the initial constraint
@@ -618,20 +632,20 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
  * index would push the array out of registers into scratch memory. */
 template <int R>
 HRL_DEV void build_A_row(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag) {
+    float a = 0.f;
     if (R < nR) { /* wave-uniform test; the rows form a flat sequence (no nesting) */
-        float a = g.J[0] * L.Bt[R][0];
+        a = g.J[0] * L.Bt[R][0];
 #pragma unroll
         for (int d = 1; d < 16; ++d) a = fma_(g.J[d], L.Bt[R][d], a);
-        g.A[R] = a;
         diag = (R == lane) ? a : diag;
     }
+    g.A[R] = a; /* unconditional: the register is fully redefined every substep */
 }
 template <int... Rs>
 HRL_DEV void build_A_rows(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag, std::integer_sequence<int, Rs...>) {
     (build_A_row<Rs>(L, g, lane, nR, diag), ...);
 }
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nR) {
-    if (lane >= nR) return;
     float diag = 1.f;
     build_A_rows(L, g, lane, nR, diag, std::make_integer_sequence<int, MAXR>{});
     g.invd = 1.f / diag;

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/<dir>) into the small files committed under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/prof_r1c r1_final gather
+writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and updates profiles/pmc_summary.json[kind].
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    src, tag, kind = sys.argv[1], sys.argv[2], sys.argv[3]
+    n_envs = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+    out_dir = os.path.join(ROOT, 'profiles')
+    os.makedirs(out_dir, exist_ok=True)
+    stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        with open(os.path.join(out_dir, f'{tag}_kernel_stats.csv'), 'w') as f:
+            w = csv.writer(f)
+            w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
+            for r in rows:
+                name = r['Name'] if len(r['Name']) <= 120 else r['Name'][:117] + '...'
+                w.writerow([name, r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs'], r['StdDev']])
+    counters = {}
+    for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
+        for f in glob.glob(os.path.join(d, '*', '*_counter_collection.csv')):
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if 'k_step' in r['Kernel_Name']:
+                    acc[r['Counter_Name']].append(float(r['Counter_Value']))
+            for k, v in acc.items():
+                counters[k] = {'launches': len(v), 'mean_per_launch': sum(v) / len(v), 'mean_per_wave': sum(v) / len(v) / n_envs}
+    meta = {'source': src, 'kernel': f'k_step<{kind}>', 'envs_per_launch': n_envs,
+            'command': 'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline',
+            'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (rocprofv3); on gfx950 FETCH_SIZE is calibrated (x2) only for 16-B/lane '
+                     'streams (MI355X_MICROARCH.md, HBM): the dword-per-lane scratch traffic and 4-B/lane record loads here are '
+                     'reported uncorrected; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles',
+            'counters': counters}
+    json.dump(meta, open(os.path.join(out_dir, f'{tag}_pmc.json'), 'w'), indent=1)
+    if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
+        path = os.path.join(out_dir, 'pmc_summary.json')
+        summ = json.load(open(path)) if os.path.exists(path) else {}
+        summ[kind] = {'tag': tag, 'fetch_bytes_per_env': counters['FETCH_SIZE']['mean_per_launch'] * 1024 / n_envs,
+                      'write_bytes_per_env': counters['WRITE_SIZE']['mean_per_launch'] * 1024 / n_envs}
+        json.dump(summ, open(path, 'w'), indent=1)
+    print(json.dumps({k: round(v['mean_per_wave'], 1) for k, v in counters.items()}))
+
+
+if __name__ == '__main__':
+    main()
