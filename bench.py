@@ -86,9 +86,12 @@ def main():
     ap.add_argument('--kind', default='gather', choices=sorted(KINDS))
     ap.add_argument('--gather-every', type=int, default=100, help='all-gather episode returns every K steps (N>1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo only to rehearse N>1 on a box with fewer GPUs')
     args = ap.parse_args()
 
-    rank, world, local_rank = init_distributed(args.gpus)
+    rank, world, local_rank = init_distributed(args.gpus, backend=args.backend)
+    if args.backend == 'gloo':
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     n = args.envs
@@ -122,7 +125,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tt = torch.tensor([wall], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         wall = float(tt.item())
     assert bool(torch.isfinite(env.state).all()), 'non-finite state after the timed region'

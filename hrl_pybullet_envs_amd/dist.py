@@ -46,6 +46,12 @@ def all_gather_returns(local, world, out=None):
         return local.clone() if out is None else out.copy_(local)
     if out is None:
         out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend() != 'nccl':
+        # rehearsal path (gloo with device tensors): stage through the host; RCCL gathers device-to-device
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.detach().cpu().contiguous())
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, local.contiguous())
     return out
 
