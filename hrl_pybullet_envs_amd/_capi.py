@@ -2,7 +2,7 @@
 import ctypes as C
 
 HRL_ABI_VERSION = 1
-HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER = 0, 1, 2, 3
+HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER, HRL_ANT_MAZE_MJ = 0, 1, 2, 3, 4
 HRL_STATE_STRIDE = 32
 HRL_QPOS_OFF, HRL_QVEL_OFF, HRL_EPRET_OFF, HRL_INITZ_OFF, HRL_POTENTIAL_OFF = 0, 15, 29, 30, 31
 HRL_ITEMS_STRIDE = 32

@@ -17,7 +17,7 @@ namespace hrl {
 /* reference constructor defaults: ant_gather_env.py:16-29, point_gather_env.py:8-21,
  * ant_maze_bullet_env.py:13-27, MjAnt.py:31-34; scene constants ant_gather_env.py:58 */
 inline int default_config(int32_t kind, hrl_config *c) {
-    if (!c || kind < HRL_ANT_FLAT || kind > HRL_POINT_GATHER) return HRL_ERR_BAD_ARG;
+    if (!c || kind < HRL_ANT_FLAT || kind > HRL_ANT_MAZE_MJ) return HRL_ERR_BAD_ARG;
     memset(c, 0, sizeof(*c));
     c->abi_version = HRL_ABI_VERSION;
     c->env_kind = kind;
@@ -48,6 +48,14 @@ inline int default_config(int32_t kind, hrl_config *c) {
         c->start_pos[0] = -2.f; c->start_pos[1] = -5.f; c->start_pos[2] = 0.25f; /* :27 */
         c->centroid_n_static = 3; c->centroid_static_sum[0] = -7.f; /* floor + wall (-5,0) + obstacle (-2,0) */
     }
+    if (kind == HRL_ANT_MAZE_MJ) { /* ant_maze_mj_env.py:13-27 */
+        static const float t[5][2] = {{2, -4}, {2, 0}, {2, 4}, {0, 4}, {-2, 4}};
+        c->sensor_range = 5.f; c->sensor_span = 6.28318530717958647692f; c->n_targets = 5;
+        for (int i = 0; i < 5; ++i) { c->targets[i][0] = t[i][0]; c->targets[i][1] = t[i][1]; }
+        c->sense_walls = 1; c->done_at_target = 1; c->max_steps = -1; c->tol = 1.5f;
+        c->start_pos[0] = -2.f; c->start_pos[1] = -5.f; c->start_pos[2] = 0.25f;
+        c->centroid_n_static = 3; c->centroid_static_sum[0] = -7.f;
+    }
     if (kind == HRL_ANT_FLAT) {
         c->walk_target[0] = 1000.f; c->centroid_n_static = 0; c->centroid_static_sum[0] = 0.f; m.ground_z = 0.f;
     }
@@ -62,6 +70,7 @@ inline int obs_dim(const hrl_config *c) {
         case HRL_ANT_GATHER: return 28 - 2 + nfo;    /* ant_gather_env.py:53-55 */
         case HRL_POINT_GATHER: return 8 + nfo;       /* gather_base.py:53-55, point_bot.py:16 */
         case HRL_ANT_MAZE: return 28 - 2 + (c->sense_walls ? c->n_bins : 0) + (c->sense_target ? c->n_bins : 2); /* ant_maze_bullet_env.py:54-57 */
+        case HRL_ANT_MAZE_MJ: return 29 + 3 * c->n_bins + 1; /* ant_maze_mj_env.py:50 */
     }
     return -1;
 }
@@ -72,18 +81,17 @@ inline std::string validate(const hrl_config *c) {
     char buf[256];
     if (!c) return "null config";
     if (c->abi_version != HRL_ABI_VERSION) return "abi_version mismatch";
-    if (c->env_kind < HRL_ANT_FLAT || c->env_kind > HRL_POINT_GATHER) return "unknown env_kind";
+    if (c->env_kind < HRL_ANT_FLAT || c->env_kind > HRL_ANT_MAZE_MJ) return "unknown env_kind";
     if (c->num_envs <= 0) return "num_envs must be positive";
     const bool gather = c->env_kind == HRL_ANT_GATHER || c->env_kind == HRL_POINT_GATHER;
     if (gather) {
         if (c->n_food < 0 || c->n_poison < 0 || c->n_food + c->n_poison > HRL_MAX_ITEMS) return "n_food + n_poison must be within 0..16";
         if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
-        if (!c->use_sensor) return "use_sensor=False (absolute item positions, ant_gather_env.py:179-196) is not implemented on the device path";
         if (!(c->robot_coll_dist > 0)) return "robot_coll_dist <= 0 (contact based pickup, ant_gather_env.py:113-116) is not implemented";
         if (!(c->world_size[0] > 1 && c->world_size[1] > 1 && c->world_size[0] < 50 && c->world_size[1] < 50)) return "world_size must be within (1, 50)";
         if (!(c->sensor_range > 0) || !(c->sensor_span > 0)) return "sensor_range and sensor_span must be positive";
     }
-    if (c->env_kind == HRL_ANT_MAZE) {
+    if (c->env_kind == HRL_ANT_MAZE || c->env_kind == HRL_ANT_MAZE_MJ) {
         if (c->n_targets < 1 || c->n_targets > HRL_MAX_TARGETS) return "n_targets must be within 1..8";
         if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
         if (c->target_encoding != 0 && c->target_encoding != 1) return "target_encoding must be 0 (normed_vec) or 1 (angle)"; /* utils.py:66-68 */
@@ -143,14 +151,15 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     /* static world: walls 0.1 thick centred on +-size/2 (sizeable_enclosed_scene.py:46-57, wall.xml:19); maze box (box.xml:19) */
     float hx = 0.f, hy = 0.f;
     if (c.env_kind == HRL_ANT_GATHER || c.env_kind == HRL_POINT_GATHER) { hx = c.world_size[0] / 2; hy = c.world_size[1] / 2; }
-    if (c.env_kind == HRL_ANT_MAZE) { hx = 5.f; hy = 9.f; } /* maze_scene.py:10 */
+    const bool maze_world = c.env_kind == HRL_ANT_MAZE || c.env_kind == HRL_ANT_MAZE_MJ;
+    if (maze_world) { hx = 5.f; hy = 9.f; } /* maze_scene.py:10 */
     if (hx > 0.f) {
         const float t = 0.05f, n[4][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}};
         const float dd[4] = {-(hx - t), -(hx - t), -(hy - t), -(hy - t)};
         d.n_planes = 4;
         for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) d.plane_n[i][k] = n[i][k]; d.plane_d[i] = dd[i]; }
     }
-    if (c.env_kind == HRL_ANT_MAZE) { d.n_boxes = 1; d.box_lo[0] = -5; d.box_lo[1] = -2; d.box_lo[2] = 0; d.box_hi[0] = 1; d.box_hi[1] = 2; d.box_hi[2] = 2; }
+    if (maze_world) { d.n_boxes = 1; d.box_lo[0] = -5; d.box_lo[1] = -2; d.box_lo[2] = 0; d.box_hi[0] = 1; d.box_hi[1] = 2; d.box_hi[2] = 2; }
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
 }
 

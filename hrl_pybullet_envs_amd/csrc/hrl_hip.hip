@@ -100,6 +100,7 @@ kernel_fn step_kernel(int kind) {
         case HRL_ANT_FLAT: return k_step<HRL_ANT_FLAT>;
         case HRL_ANT_GATHER: return k_step<HRL_ANT_GATHER>;
         case HRL_ANT_MAZE: return k_step<HRL_ANT_MAZE>;
+        case HRL_ANT_MAZE_MJ: return k_step<HRL_ANT_MAZE_MJ>;
         default: return k_step<HRL_POINT_GATHER>;
     }
 }
@@ -108,6 +109,7 @@ kernel_fn reset_kernel(int kind) {
         case HRL_ANT_FLAT: return k_reset<HRL_ANT_FLAT>;
         case HRL_ANT_GATHER: return k_reset<HRL_ANT_GATHER>;
         case HRL_ANT_MAZE: return k_reset<HRL_ANT_MAZE>;
+        case HRL_ANT_MAZE_MJ: return k_reset<HRL_ANT_MAZE_MJ>;
         default: return k_reset<HRL_POINT_GATHER>;
     }
 }

@@ -949,6 +949,29 @@ HRL_DEV void maze_line(int l, float *a) {
     }
 }
 
+/* sizeable_enclosed_scene.py:63-97 `sense_walls`, one bin: the ray and all 7 maze lines are INFINITE lines
+ * (intersection_utils.py:74-90), filtered by range and quadrant */
+HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, int i) {
+    const float half_pi = 1.5707963267948966f;
+    float phi;
+    if (c.span_is_2pi) phi = half_pi + yaw + ((float)(i + 1) / (float)c.n_bins) * c.sensor_span;
+    else phi = half_pi + yaw + ((float)i / (float)(c.n_bins - 1)) * c.sensor_span;
+    const float svx = rx + c.sensor_range * cosf(phi), svy = ry + c.sensor_range * sinf(phi);
+    const int sq = quadrant(svx - rx, svy - ry);
+    float best = 0.f;
+    for (int l = 0; l < 7; ++l) {
+        float a[4], px, py;
+        maze_line(l, a);
+        if (!inf_intersection(rx, ry, svx, svy, a[0], a[1], a[2], a[3], &px, &py)) continue;
+        const float ddx = rx - px, ddy = ry - py, dist = sqrtf(ddx * ddx + ddy * ddy);
+        if (dist > c.sensor_range) continue;
+        if (sq != quadrant(px - rx, py - ry)) continue;
+        const float val = 1.f - dist / c.sensor_range;
+        if (val > best) best = val;
+    }
+    return best;
+}
+
 /* Phase O1: upstream WalkerBase.calc_state (28-vector clipped to +-5) into L.s28, plus walk_target_dist, yaw and
  * joints_at_limit into L.scal.  `with_centroid` needs L.ph/pa/tip of the CURRENT qpos (phase_kin_ankle on L.st). */
 template <int KIND>
@@ -957,7 +980,7 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
     float rpy[3];
     quat_to_rpy(qp + 3, rpy);
     float tx = c.walk_tx, ty = c.walk_ty;
-    if (KIND == 2) { /* maze: the episode's target */
+    if (KIND == 2 || KIND == 4) { /* maze kinds: the episode's target */
         const int ti = L.aux[3];
         tx = c.targets[0][0]; ty = c.targets[0][1];
 #pragma unroll
@@ -1034,7 +1057,8 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
             L.items[2 * lane] = ix; L.items[2 * lane + 1] = iy;
             dx = ix - rx; dy = iy - ry; d2 = dx * dx + dy * dy;
         }
-        if (!(d2 > c.sensor_range)) {
+        if (!c.use_sensor) inten = d2; /* get_abs_pos (ant_gather_env.py:179-196) sorts by squared distance */
+        else if (!(d2 > c.sensor_range)) {
             const float half_span = c.sensor_span * 0.5f, bin_res = c.sensor_span / (float)c.n_bins;
             const float angle = wrap_angle(atan2f(iy - ry, ix - rx) - yaw);
             if (fabsf(angle) <= half_span) {
@@ -1053,17 +1077,32 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
     if (lane >= c.obs_dim) return;
     float v = 0.f;
     if (KIND == 0) v = L.st[lane];                       /* MjAnt.py:17-25: qpos | qvel */
+    else if (KIND == 4) { /* ant_maze_mj_env.py:57-64: state29 | walls | pit zeros | moveable zeros | t * 0.001 */
+        if (lane < 29) v = L.st[lane];
+        else if (lane < 29 + c.n_bins) v = wall_sensor_bin(c, L.st[0], L.st[1], L.scal[4], lane - 29);
+        else if (lane == 29 + 3 * c.n_bins) v = (float)L.aux[0] * 0.001f;
+    }
     else if (KIND == 3) {                                /* point: calc_state(8) | food | poison */
         if (lane < 8) v = L.s28[lane];
     } else if (lane < 26) v = L.s28[lane == 0 ? 0 : lane + 2]; /* ant_gather_env.py:81, ant_maze_bullet_env.py:75 */
     const int nb = (KIND == 3) ? 8 : 26;
-    if ((KIND == 1 || KIND == 3) && lane >= nb) { /* ant_gather_env.py:128-177: nearest in-range item per bin and type */
+    if ((KIND == 1 || KIND == 3) && lane >= nb && c.use_sensor) { /* ant_gather_env.py:128-177: nearest in-range item per bin and type */
         const int b = lane - nb, type = b / c.n_bins, bin = b - type * c.n_bins;
         const int k0 = type ? c.n_food : 0, k1 = type ? c.n_food + c.n_poison : c.n_food;
         float best = 0.f;
         for (int k = k0; k < k1; ++k)
             if (L.ibin[k] == (float)bin && L.iint[k] > best) best = L.iint[k];
         v = best;
+    }
+    if ((KIND == 1 || KIND == 3) && lane >= nb && !c.use_sensor) { /* ant_gather_env.py:179-196: xy of the nearest items, stable ascending by d2 */
+        const int mf = c.n_food < c.n_bins ? c.n_food : c.n_bins;
+        const int b = lane - nb, type = b >= 2 * mf, bb = type ? b - 2 * mf : b, want = bb >> 1, comp = bb & 1;
+        const int k0 = type ? c.n_food : 0, k1 = type ? c.n_food + c.n_poison : c.n_food;
+        for (int i = k0; i < k1; ++i) {
+            int rank = 0;
+            for (int j = k0; j < k1; ++j) rank += (L.iint[j] < L.iint[i] || (L.iint[j] == L.iint[i] && j < i)) ? 1 : 0;
+            if (rank == want) v = L.items[2 * i + comp];
+        }
     }
     if (KIND == 2 && lane >= 26) {
         const float rx = L.st[0], ry = L.st[1], yaw = L.scal[4];
@@ -1091,27 +1130,7 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
                     }
                 }
             }
-        } else { /* sizeable_enclosed_scene.py:63-97 wall sensor, lane = bin */
-            const int i = lane - 26 - ntar;
-            const float half_pi = 1.5707963267948966f;
-            float phi;
-            if (c.span_is_2pi) phi = half_pi + yaw + ((float)(i + 1) / (float)c.n_bins) * c.sensor_span;
-            else phi = half_pi + yaw + ((float)i / (float)(c.n_bins - 1)) * c.sensor_span;
-            const float svx = rx + c.sensor_range * cosf(phi), svy = ry + c.sensor_range * sinf(phi);
-            const int sq = quadrant(svx - rx, svy - ry);
-            float best = 0.f;
-            for (int l = 0; l < 7; ++l) {
-                float a[4], px, py;
-                maze_line(l, a);
-                if (!inf_intersection(rx, ry, svx, svy, a[0], a[1], a[2], a[3], &px, &py)) continue;
-                const float ddx = rx - px, ddy = ry - py, dist = sqrtf(ddx * ddx + ddy * ddy);
-                if (dist > c.sensor_range) continue;
-                if (sq != quadrant(px - rx, py - ry)) continue;
-                const float val = 1.f - dist / c.sensor_range;
-                if (val > best) best = val;
-            }
-            v = best;
-        }
+        } else v = wall_sensor_bin(c, rx, ry, yaw, lane - 26 - ntar); /* lane = bin */
     }
     L.obs[lane] = v;
     if (!isfinite(v)) L.flags[0] = 1;
@@ -1142,7 +1161,7 @@ HRL_DEV void phase_point_state(const DevCfg &c, WaveLds &L, int lane) {
 template <int KIND, class X>
 HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
     WaveLds &L = x.lds();
-    const bool centroid = (KIND == 0 || KIND == 2);
+    const bool centroid = (KIND == 0 || KIND == 2 || KIND == 4);
     if (centroid) { /* link positions of the final pose for the parts centroid; its LDS hand-off area overlays the
                        task scratch, so it runs before anything below is written */
         x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
@@ -1172,7 +1191,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
             if (KIND == 3) { if (lane == 2) v = 0.5f; if (lane == 30) v = 1.f; }
             else {
                 float z0 = 0.75f;
-                if (KIND == 2) { z0 = c.start_pos[2]; if (lane == 0) v = c.start_pos[0]; if (lane == 1) v = c.start_pos[1]; }
+                if (KIND == 2 || KIND == 4) { z0 = c.start_pos[2]; if (lane == 0) v = c.start_pos[0]; if (lane == 1) v = c.start_pos[1]; }
                 if (lane == 2 || lane == 30) v = z0;
                 if (lane >= 7 && lane < 15) {
                     const int j = lane - 7;
@@ -1193,7 +1212,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
         }
         if (lane < 16) L.u[lane] = 0.f;
         if (lane < 8) L.tau[lane] = 0.f;
-        if (lane == 63 && KIND == 2) {
+        if (lane == 63 && (KIND == 2 || KIND == 4)) {
             uint32_t r[4];
             philox4x32(c, env, ep, (3u << 16), 0u, r);
             L.aux[3] = (int)(r[0] % (uint32_t)c.n_targets);
@@ -1201,7 +1220,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
     });
     x.each([&](int lane) { if (lane == 0) L.aux[0] = 0; if (lane == 2) L.aux[2] = L.aux[2] + 1; });
     compute_obs<KIND>(x, c, env, false);
-    x.each([&](int lane) { if (lane == 31) L.st[31] = (KIND == 0 || KIND == 2) ? -L.scal[3] / c.dt : 0.f; }); /* upstream calc_potential */
+    x.each([&](int lane) { if (lane == 31) L.st[31] = (KIND == 0 || KIND == 2 || KIND == 4) ? -L.scal[3] / c.dt : 0.f; }); /* upstream calc_potential */
 }
 
 template <class X>
@@ -1288,6 +1307,16 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             const float pot = -L.scal[3] / c.dt, progress = pot - L.st[31];
             rew = ((alive + progress) + -0.1f * L.scal[5]) + 0.f;
             L.red[0] = pot;
+        } else if (KIND == 4) { /* MjAnt.py:36-97, then ant_maze_mj_env.py:66-78 */
+            const float alive = L.st[2] > 0.26f ? 1.f : -1.f;
+            int idone = alive < 0.f;
+            for (int i = 0; i < 29; ++i) if (!isfinite(L.st[i])) idone = 1;
+            const float wtd = L.scal[3], pot = -wtd / c.dt, progress = pot - L.st[31];
+            const float inner = ((alive + progress) + -0.1f * L.scal[5]) + 0.f;
+            rew = inner * c.inner_rew_weight;
+            done = idone;
+            if (wtd < c.tol) { rew += 1.f; done = 1; }
+            L.red[0] = pot;
         } else { /* upstream WalkerBaseBulletEnv.step, then ant_maze_bullet_env.py:84-95 */
             const float alive = (L.s28[0] + L.st[30] > 0.26f) ? 1.f : -1.f;
             int idone = alive < 0.f;
@@ -1313,7 +1342,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     x.each([&](int lane) { /* each LDS word below is read and written by one lane only */
         if (lane == 0) { L.aux[0] = L.aux[0] + 1; b.reward[e] = L.scal[0]; b.done[e] = (uint8_t)L.flags[1]; }
         if (lane == 1) L.aux[1] = L.aux[1] + 1;
-        if (lane == 2 && (KIND == 0 || KIND == 2)) L.st[31] = L.red[0];
+        if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
         if (lane >= 4 && lane < 8) {
             const int k = lane - 4;
@@ -1331,7 +1360,8 @@ HRL_DEV void step_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
         case 0: step_entry<0>(x, b, c, e); break;
         case 1: step_entry<1>(x, b, c, e); break;
         case 2: step_entry<2>(x, b, c, e); break;
-        default: step_entry<3>(x, b, c, e); break;
+        case 3: step_entry<3>(x, b, c, e); break;
+        default: step_entry<4>(x, b, c, e); break;
     }
 }
 template <class X>
@@ -1340,7 +1370,8 @@ HRL_DEV void reset_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
         case 0: reset_entry<0>(x, b, c, e); break;
         case 1: reset_entry<1>(x, b, c, e); break;
         case 2: reset_entry<2>(x, b, c, e); break;
-        default: reset_entry<3>(x, b, c, e); break;
+        case 3: reset_entry<3>(x, b, c, e); break;
+        default: reset_entry<4>(x, b, c, e); break;
     }
 }
 

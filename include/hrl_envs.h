@@ -33,6 +33,7 @@ extern "C" {
 #define HRL_ANT_GATHER 1   /* AntGatherBulletEnv: obs 26 + 2*n_bins (envs/gather/ant_gather_env.py:12-200) */
 #define HRL_ANT_MAZE 2     /* AntMazeBulletEnv: obs 26 + 2 + n_bins (envs/ant_maze/ant_maze_bullet_env.py) */
 #define HRL_POINT_GATHER 3 /* PointGatherBulletEnv: obs 8 + 2*n_bins (envs/gather/point_gather_env.py)     */
+#define HRL_ANT_MAZE_MJ 4  /* AntMazeMjEnv: obs 29 + 3*n_bins + 1 (envs/ant_maze/ant_maze_mj_env.py:17-78)    */
 
 /* buffer geometry (floats / ints per env) */
 #define HRL_STATE_STRIDE 32 /* state record: qpos[15] | qvel[14] | ep_return | initial_z | potential */
@@ -80,7 +81,7 @@ typedef struct hrl_model {
 
 typedef struct hrl_config {
     int32_t abi_version;       /* HRL_ABI_VERSION */
-    int32_t env_kind;          /* HRL_ANT_* / HRL_POINT_GATHER */
+    int32_t env_kind;          /* HRL_ANT_FLAT .. HRL_ANT_MAZE_MJ */
     int32_t num_envs;          /* envs owned by this handle (this GPU's shard) */
     int32_t max_episode_steps; /* 2000 (hrl_pybullet_envs/__init__.py:15); <= 0 disables */
     int64_t env_id_offset;     /* global id of local env 0: RNG streams are keyed by global id */

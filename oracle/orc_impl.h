@@ -381,6 +381,24 @@ void FN(orc_antmj_reward)(const REAL *state29, REAL potential_old, REAL potentia
     *done = d;
 }
 
+/* ant_maze_mj_env.py:57-78 `AntMazeMjEnv._get_obs` + `step` given the AntMjEnv.step result:
+ * obs = [state29 | walls(n_bins) | pit zeros | moveable zeros | t*0.001] with t BEFORE its increment (:68-70);
+ * rew = inner*weight (+1 and done when walk_target_dist < tol, :72-76). */
+void FN(orc_maze_mj_task)(const hrl_config *cfg, const REAL *state29, REAL yaw, REAL inner_rew, int inner_done,
+                          REAL walk_target_dist, int t_before, const REAL *lines, int n_lines, REAL *obs, REAL *rew, int *done) {
+    int no = 0, nb = cfg->n_bins;
+    for (int i = 0; i < 29; ++i) obs[no++] = state29[i];
+    FN(orc_sense_walls)(nb, FN(cfg_angle)(cfg->sensor_span), R_(cfg->sensor_range), state29, yaw, lines, n_lines,
+                        (double)cfg->sensor_span == (double)(float)6.283185307179586, obs + no); /* :58-59: pos = ant_obs[:2] */
+    no += nb;
+    for (int i = 0; i < 2 * nb; ++i) obs[no++] = 0; /* :61-62 */
+    obs[no++] = R_(t_before) * R_(0.001);           /* :64 */
+    REAL r = inner_rew * R_(cfg->inner_rew_weight);
+    int d = inner_done;
+    if (walk_target_dist < R_(cfg->tol)) { r += 1; d = 1; } /* :74-76 */
+    *rew = r; *done = d;
+}
+
 /* =================================================================================================================
  * PART 2 -- RIGID-BODY STEP (build's own specification; PARITY UNPINNED against pybullet, see header)
  * Replaces robot.apply_action + scene.global_step at ant_gather_env.py:77-78 (upstream: setJointMotorControl2 +
@@ -448,7 +466,7 @@ void FN(orc_world_init)(const hrl_config *cfg, FN(orc_world) * W) {
     memset(W, 0, sizeof(*W));
     REAL hx = 0, hy = 0;
     if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) { hx = R_(cfg->world_size[0]) / 2; hy = R_(cfg->world_size[1]) / 2; }
-    if (cfg->env_kind == HRL_ANT_MAZE) { hx = 5; hy = 9; } /* maze_scene.py:10 */
+    if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { hx = 5; hy = 9; } /* maze_scene.py:10 */
     if (hx > 0) { /* walls 0.1 thick centred on +-size/2 (sizeable_enclosed_scene.py:46-57, wall.xml:19) */
         REAL t = R_(0.05);
         REAL n[4][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}};
@@ -456,7 +474,7 @@ void FN(orc_world_init)(const hrl_config *cfg, FN(orc_world) * W) {
         W->n_planes = 4;
         for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) W->plane_n[i][k] = n[i][k]; W->plane_d[i] = d[i]; }
     }
-    if (cfg->env_kind == HRL_ANT_MAZE) { /* box.xml:19 6x4x2 at (-2,0,1) (maze_scene.py:12-13,35) */
+    if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { /* box.xml:19 6x4x2 at (-2,0,1) (maze_scene.py:12-13,35) */
         W->n_boxes = 1;
         FN(v3set)(W->box_lo[0], -5, -2, 0); FN(v3set)(W->box_hi[0], 1, 2, 2);
     }
@@ -1019,12 +1037,17 @@ static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *item
     }
     REAL s28[28], rpy[3], wtd, tgt[2] = {R_(cfg->walk_target[0]), R_(cfg->walk_target[1])};
     int nlim;
-    if (cfg->env_kind == HRL_ANT_MAZE) { tgt[0] = R_(cfg->targets[aux[3]][0]); tgt[1] = R_(cfg->targets[aux[3]][1]); }
+    if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { tgt[0] = R_(cfg->targets[aux[3]][0]); tgt[1] = R_(cfg->targets[aux[3]][1]); }
     FN(orc_ant_calc_state)(cfg, &E->K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
     if (wtd_out) *wtd_out = wtd;
     if (nlim_out) *nlim_out = nlim;
     if (s28_out) for (int i = 0; i < 28; ++i) s28_out[i] = s28[i];
     if (cfg->env_kind == HRL_ANT_FLAT) { for (int i = 0; i < 29; ++i) obs[i] = st[i]; return; } /* MjAnt.py:17-25 */
+    if (cfg->env_kind == HRL_ANT_MAZE_MJ) {
+        REAL r_; int d_;
+        FN(orc_maze_mj_task)(cfg, st, rpy[2], 0, 0, wtd, aux[0], &FN(maze_lines)[0][0], 7, obs, &r_, &d_);
+        return;
+    }
     if (cfg->env_kind == HRL_ANT_GATHER) {
         obs[0] = s28[0];
         for (int i = 3; i < 28; ++i) obs[i - 2] = s28[i];
@@ -1043,7 +1066,7 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     st[6] = 1; /* identity quaternion (x,y,z,w) */
     if (cfg->env_kind == HRL_POINT_GATHER) { st[2] = R_(0.5); st[HRL_INITZ_OFF] = 1; } /* point_bot.py:12,18 */
     else {
-        if (cfg->env_kind == HRL_ANT_MAZE) { /* ant_maze_bullet_env.py:108-118 */
+        if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { /* ant_maze_bullet_env.py:108-118, ant_maze_mj_env.py:85-101 */
             uint32_t r[4];
             orc_philox4x32(cfg->seed, env, ep, (3u << 16), 0, r);
             aux[3] = (int32_t)(r[0] % (uint32_t)cfg->n_targets);
@@ -1065,7 +1088,7 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     REAL feet[4] = {0, 0, 0, 0}, wtd = 0;
     FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0);
     /* upstream calc_potential = -dist/dt; only the flat and maze kinds use it */
-    st[HRL_POTENTIAL_OFF] = (cfg->env_kind == HRL_ANT_FLAT || cfg->env_kind == HRL_ANT_MAZE) ? -wtd / (E->K.h * R_(E->K.nsub)) : R_(0);
+    st[HRL_POTENTIAL_OFF] = (cfg->env_kind == HRL_ANT_FLAT || cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) ? -wtd / (E->K.h * R_(E->K.nsub)) : R_(0);
 }
 
 /* One env step on the packed record.  Mirrors hrl_step() of include/hrl_envs.h. */
@@ -1119,6 +1142,14 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         REAL pot = -wtd / (K->h * R_(K->nsub));
         FN(orc_antmj_reward)(obs, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &rew, &done);
         st[HRL_POTENTIAL_OFF] = pot;
+    } else if (cfg->env_kind == HRL_ANT_MAZE_MJ) { /* MjAnt.py:36-97 then ant_maze_mj_env.py:66-78 */
+        REAL wtd, s28[28], rpy[3], inner, tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};
+        int nlim, idone;
+        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+        REAL pot = -wtd / (K->h * R_(K->nsub));
+        FN(orc_antmj_reward)(st, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &inner, &idone);
+        st[HRL_POTENTIAL_OFF] = pot;
+        FN(orc_maze_mj_task)(cfg, st, rpy[2], inner, idone, wtd, aux[0], &FN(maze_lines)[0][0], 7, obs, &rew, &done);
     } else { /* maze: upstream WalkerBaseBulletEnv.step then ant_maze_bullet_env.py:77-97 */
         REAL wtd, s28[28], rpy[3], tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};
         int nlim;

@@ -455,6 +455,40 @@ def main():
                    'joints_at_limit': n_lim, 'joints_at_limit_cost': -0.1, 'rew': float(rew), 'done': bool(done)})
     G['antmj_step'] = mj
 
+    # ---------------------------------------------------------------- AntMazeMjEnv.step / _get_obs (ant_maze_mj_env.py:57-78)
+    from hrl_pybullet_envs.envs.ant_maze.ant_maze_mj_env import AntMazeMjEnv
+    mm = []
+    for k in range(50):
+        lrs = np.random.RandomState(11000 + k)
+        targets = ([2, -4], [2, 0], [2, 4], [0, 4], [-2, 4])
+        target = np.array(targets[lrs.randint(0, 5)])
+        xy = np.array([lrs.uniform(-4.5, 4.5), lrs.uniform(-8.5, 8.5)])
+        if k >= 38:
+            xy = target + lrs.uniform(-1.0, 1.0, 2)  # next to the target -> sparse reward / done
+        state = lrs.uniform(-1, 1, 29)
+        state[0], state[1], state[2] = xy[0], xy[1], lrs.uniform(0.2, 0.8)
+        rpy = [lrs.uniform(-.2, .2), lrs.uniform(-.2, .2), lrs.uniform(-np.pi, np.pi)]
+        pot_old = float(lrs.uniform(-700, -100)); pot_new = pot_old + float(lrs.uniform(-3, 3))
+        n_lim = int(lrs.randint(0, 4)); t0 = int(lrs.randint(0, 500))
+        centroid = xy + lrs.uniform(-0.3, 0.3, 2)
+        wtd = float(np.linalg.norm(target - centroid))
+        robot = NS(apply_action=lambda a: None, calc_state=lambda: state.copy(), initial_z=0.25, body_rpy=rpy,
+                   calc_potential=lambda: pot_new, feet=[], feet_contact=np.zeros(4), joints_at_limit=n_lim,
+                   walk_target_dist=wtd)
+        robot.alive_bonus = lambda z, pitch: MjAnt.alive_bonus(robot, z, pitch)
+        self = AntMazeMjEnv.__new__(AntMazeMjEnv)
+        self.__dict__.update(dict(robot=robot, scene=maze, potential=pot_old, joints_at_limit_cost=-0.1, ground_ids=set(),
+                                  reward=0.0, n_bins=10, sensor_span=2 * np.pi, sensor_range=5.0, targets=targets,
+                                  tol=1.5, inner_rew_weight=float(k % 3 == 0) * 0.5, t=t0, target=target, debug=0,
+                                  robot_body=Body([xy[0], xy[1], state[2]], rpy)))
+        maze.global_step = lambda: None
+        obs, rew, d, _ = AntMazeMjEnv.step(self, np.zeros(8))
+        mm.append({'state': state.tolist(), 'rpy': list(map(float, rpy)), 'target': target.tolist(), 't_before': t0,
+                   'potential_old': pot_old, 'potential_new': pot_new, 'joints_at_limit': n_lim,
+                   'walk_target_dist': wtd, 'inner_rew_weight': float(self.inner_rew_weight), 'obs': tolist(obs),
+                   'rew': float(rew), 'done': bool(d), 't_after': int(self.t)})
+    G['maze_mj_step'] = mm
+
     for name, val in G.items():
         with open(os.path.join(OUT_DIR, name + '.json'), 'w') as f:
             json.dump(val, f, allow_nan=True)

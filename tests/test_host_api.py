@@ -51,7 +51,7 @@ def test_struct_layout_matches_header():
         out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
     assert [int(x) for x in out] == [C.sizeof(K.hrl_config), C.sizeof(K.hrl_model), C.sizeof(K.hrl_buffers)]
     # product defaults == oracle defaults, byte for byte, for every kind
-    for kind in range(4):
+    for kind in range(5):
         assert bytes(_lib.default_config(kind)) == bytes(orc.default_config(kind))
 
 
@@ -60,7 +60,7 @@ def test_bad_config_is_rejected_with_a_reason():
     L = _lib.lib()
     h = C.c_void_p()
     for kw, frag in ((dict(n_food=12, n_poison=12), b'n_food'), (dict(num_envs=0), b'num_envs'),
-                     (dict(abi_version=99), b'abi_version'), (dict(use_sensor=0), b'use_sensor')):
+                     (dict(abi_version=99), b'abi_version'), (dict(robot_coll_dist=0), b'robot_coll_dist')):
         cfg = _lib.default_config(K.HRL_ANT_GATHER, **kw)
         assert L.hrl_create(C.byref(cfg), C.byref(h)) == K.HRL_ERR_BAD_ARG
         assert frag in L.hrl_last_error()
@@ -78,6 +78,8 @@ def test_env_classes_mirror_reference_constructor_api():
     assert H.AntMazeBulletEnv(sense_target=True, n_bins=8).observation_space.shape == (26 + 8 + 8,)
     assert H.AntMazeBulletEnv(sense_walls=False).observation_space.shape == (28,)
     assert H.AntMjEnv().observation_space.shape == (29,)                         # MjAnt.py:15
+    assert H.AntMazeMjEnv().observation_space.shape == (60,)                     # ant_maze_mj_env.py:50
+    assert H.AntMazeMjEnv()._cfg.n_targets == 5                                  # ant_maze_mj_env.py:13-14
     with pytest.raises(ValueError):
         H.AntMazeBulletEnv(target_encoding=5)                                    # PositionEncoding(5), utils.py:66-68
     assert isinstance(H.make('AntMazeBulletEnv-v0', tol=2.0), H.AntMazeBulletEnv)

@@ -205,3 +205,21 @@ def test_antmj_reward():
                                        C.c_double(c['potential_new']), c['joints_at_limit'],
                                        C.c_double(c['joints_at_limit_cost']), C.byref(rew), C.byref(done))
         assert rew.value == pytest.approx(c['rew'], abs=1e-9) and bool(done.value) == c['done']
+
+
+def test_maze_mj_step_task_half():
+    """ant_maze_mj_env.py:57-78 on top of MjAnt.py:36-97: observation assembly, t/1000, sparse reward."""
+    lines = arr(load('sense_walls')['maze_bounds']).reshape(-1, 4)
+    for c in load('maze_mj_step'):
+        cfg = orc.default_config(K.HRL_ANT_MAZE_MJ, inner_rew_weight=c['inner_rew_weight'])
+        assert orc.obs_dim(cfg) == 60 == len(c['obs'])
+        inner = C.c_double(); idone = C.c_int()
+        orc.lib().orc_antmj_reward_f64(orc.ptr(arr(c['state'])), C.c_double(c['potential_old']), C.c_double(c['potential_new']),
+                                       c['joints_at_limit'], C.c_double(-0.1), C.byref(inner), C.byref(idone))
+        obs = np.zeros(60); rew = C.c_double(); done = C.c_int()
+        orc.lib().orc_maze_mj_task_f64(C.byref(cfg), orc.ptr(arr(c['state'])), C.c_double(c['rpy'][2]), inner, idone,
+                                       C.c_double(c['walk_target_dist']), c['t_before'], orc.ptr(lines), 7, orc.ptr(obs),
+                                       C.byref(rew), C.byref(done))
+        np.testing.assert_allclose(obs, c['obs'], atol=1e-11)
+        assert rew.value == pytest.approx(c['rew'], abs=1e-9) and bool(done.value) == c['done']
+        assert c['t_after'] == c['t_before'] + 1
