@@ -3,14 +3,15 @@
 Same class names / constructor kwargs as the reference (hrl_pybullet_envs/__init__.py:3-16); `make(id)` resolves the
 reference's registered ids.  With gym installed the ids are also registered with `max_episode_steps=2000`."""
 from .envs.MjAnt import AntMjEnv
+from .envs.ant_flagrun.ant_flagrun_env import AntFlagrunBulletEnv
 from .envs.ant_maze.ant_maze_bullet_env import AntMazeBulletEnv
 from .envs.ant_maze.ant_maze_mj_env import AntMazeMjEnv
 from .envs.gather.ant_gather_env import AntGatherBulletEnv
 from .envs.gather.point_gather_env import PointGatherBulletEnv
 
-__all__ = ['AntGatherBulletEnv', 'AntMazeMjEnv', 'AntMazeBulletEnv', 'PointGatherBulletEnv', 'AntMjEnv', 'make']
+__all__ = ['AntGatherBulletEnv', 'AntMazeMjEnv', 'AntMazeBulletEnv', 'AntFlagrunBulletEnv', 'PointGatherBulletEnv', 'AntMjEnv', 'make']
 
-_REGISTRY = {f'{c.__name__}-v0': c for c in (AntGatherBulletEnv, AntMazeMjEnv, AntMazeBulletEnv, PointGatherBulletEnv, AntMjEnv)}
+_REGISTRY = {f'{c.__name__}-v0': c for c in (AntGatherBulletEnv, AntMazeMjEnv, AntMazeBulletEnv, AntFlagrunBulletEnv, PointGatherBulletEnv, AntMjEnv)}
 
 
 def make(env_id, **kwargs):

@@ -17,7 +17,7 @@ namespace hrl {
 /* reference constructor defaults: ant_gather_env.py:16-29, point_gather_env.py:8-21,
  * ant_maze_bullet_env.py:13-27, MjAnt.py:31-34; scene constants ant_gather_env.py:58 */
 inline int default_config(int32_t kind, hrl_config *c) {
-    if (!c || kind < HRL_ANT_FLAT || kind > HRL_ANT_MAZE_MJ) return HRL_ERR_BAD_ARG;
+    if (!c || kind < HRL_ANT_FLAT || kind > HRL_ANT_FLAGRUN) return HRL_ERR_BAD_ARG;
     memset(c, 0, sizeof(*c));
     c->abi_version = HRL_ABI_VERSION;
     c->env_kind = kind;
@@ -56,6 +56,12 @@ inline int default_config(int32_t kind, hrl_config *c) {
         c->start_pos[0] = -2.f; c->start_pos[1] = -5.f; c->start_pos[2] = 0.25f;
         c->centroid_n_static = 3; c->centroid_static_sum[0] = -7.f;
     }
+    c->flag_size = 10.f; c->flag_max_targets = 100; c->flag_timeout = 200; c->flag_switch_on_collision = 1; c->flag_enclosed = 1;
+    if (kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:14-16; arena (size+2)^2 :59-61; start (0,0,0.25) :144 */
+        c->use_sensor = 0; c->n_bins = 8; c->sensor_span = 3.14159265358979323846f; c->sensor_range = 4.f; c->tol = 0.5f;
+        c->world_size[0] = 12.f; c->world_size[1] = 12.f; c->start_pos[2] = 0.25f;
+        c->centroid_n_static = 2; c->centroid_static_sum[0] = -6.f;
+    }
     if (kind == HRL_ANT_FLAT) {
         c->walk_target[0] = 1000.f; c->centroid_n_static = 0; c->centroid_static_sum[0] = 0.f; m.ground_z = 0.f;
     }
@@ -71,6 +77,7 @@ inline int obs_dim(const hrl_config *c) {
         case HRL_POINT_GATHER: return 8 + nfo;       /* gather_base.py:53-55, point_bot.py:16 */
         case HRL_ANT_MAZE: return 28 - 2 + (c->sense_walls ? c->n_bins : 0) + (c->sense_target ? c->n_bins : 2); /* ant_maze_bullet_env.py:54-57 */
         case HRL_ANT_MAZE_MJ: return 29 + 3 * c->n_bins + 1; /* ant_maze_mj_env.py:50 */
+        case HRL_ANT_FLAGRUN: return 28 + (c->use_sensor ? c->n_bins : 0); /* ant_flagrun_env.py:53-55 */
     }
     return -1;
 }
@@ -81,7 +88,7 @@ inline std::string validate(const hrl_config *c) {
     char buf[256];
     if (!c) return "null config";
     if (c->abi_version != HRL_ABI_VERSION) return "abi_version mismatch";
-    if (c->env_kind < HRL_ANT_FLAT || c->env_kind > HRL_ANT_MAZE_MJ) return "unknown env_kind";
+    if (c->env_kind < HRL_ANT_FLAT || c->env_kind > HRL_ANT_FLAGRUN) return "unknown env_kind";
     if (c->num_envs <= 0) return "num_envs must be positive";
     const bool gather = c->env_kind == HRL_ANT_GATHER || c->env_kind == HRL_POINT_GATHER;
     if (gather) {
@@ -97,6 +104,12 @@ inline std::string validate(const hrl_config *c) {
         if (c->target_encoding != 0 && c->target_encoding != 1) return "target_encoding must be 0 (normed_vec) or 1 (angle)"; /* utils.py:66-68 */
         if (!c->sense_walls && !(c->sensor_span > 0)) return "sensor_span must be positive";
         if (!(c->sensor_range > 0)) return "sensor_range must be positive";
+    }
+    if (c->env_kind == HRL_ANT_FLAGRUN) {
+        if (c->flag_max_targets < 1 || c->flag_max_targets > 65535) return "flag_max_targets must be within 1..65535 (max_target_dist mode, ant_flagrun_env.py:80-89, is not implemented)";
+        if (c->flag_timeout > 32767) return "flag_timeout must be <= 32767";
+        if (!(c->flag_size > 1.0f)) return "flag_size must exceed 1 (targets are rejected within 0.5 of the origin)";
+        if (c->use_sensor && (c->n_bins < 2 || c->n_bins > HRL_MAX_BINS)) return "sensor_bins must be within 2..16";
     }
     if (obs_dim(c) > 64) { snprintf(buf, sizeof buf, "observation width %d exceeds 64", obs_dim(c)); return buf; }
     const hrl_model &m = c->model;
@@ -151,6 +164,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     /* static world: walls 0.1 thick centred on +-size/2 (sizeable_enclosed_scene.py:46-57, wall.xml:19); maze box (box.xml:19) */
     float hx = 0.f, hy = 0.f;
     if (c.env_kind == HRL_ANT_GATHER || c.env_kind == HRL_POINT_GATHER) { hx = c.world_size[0] / 2; hy = c.world_size[1] / 2; }
+    if (c.env_kind == HRL_ANT_FLAGRUN && (c.flag_enclosed || c.use_sensor)) { hx = c.world_size[0] / 2; hy = c.world_size[1] / 2; } /* ant_flagrun_env.py:59-61 */
     const bool maze_world = c.env_kind == HRL_ANT_MAZE || c.env_kind == HRL_ANT_MAZE_MJ;
     if (maze_world) { hx = 5.f; hy = 9.f; } /* maze_scene.py:10 */
     if (hx > 0.f) {
@@ -160,6 +174,8 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
         for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) d.plane_n[i][k] = n[i][k]; d.plane_d[i] = dd[i]; }
     }
     if (maze_world) { d.n_boxes = 1; d.box_lo[0] = -5; d.box_lo[1] = -2; d.box_lo[2] = 0; d.box_hi[0] = 1; d.box_hi[1] = 2; d.box_hi[2] = 2; }
+    d.flag_size = c.flag_size; d.flag_max_targets = c.flag_max_targets; d.flag_timeout = c.flag_timeout;
+    d.flag_switch = c.flag_switch_on_collision;
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
 }
 

@@ -20,6 +20,7 @@ using namespace hrl;
 namespace {
 
 thread_local std::string g_err;
+unsigned long long *g_stamps = nullptr; /* set only by the diagnostic entry point hrl_debug_set_stamps */
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -45,6 +46,26 @@ struct GpuExec {
      * lane-derived value of the unrolled solver (44 `lane == r` masks, LDS addresses, ...) is loop-invariant, gets
      * hoisted to the top of the kernel and is spilled to scratch for the whole substep loop. */
     __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(lane), "+v"(r.fn)); }
+#ifdef HRL_STAMPS
+    /* diagnostic build (never shipped): cycles between phase boundaries, summed per phase id; stamp id = the phase
+     * that just ENDED.  s_memtime + lgkmcnt(0) as one statement (cdna_hip_programming.md, In-kernel stamps). */
+    unsigned long long t_last = 0, acc[16] = {};
+    __device__ __forceinline__ void stamp(int id) {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (t_last) acc[id] += t - t_last;
+        t_last = t;
+    }
+    __device__ __forceinline__ void flush_stamps(const DevBufs &b) {
+        if (b.stamps && lane == 0)
+            for (int i = 0; i < 16; ++i) atomicAdd(&b.stamps[i], acc[i]);
+    }
+#else
+    __device__ __forceinline__ void stamp(int) {}
+    __device__ __forceinline__ void flush_stamps(const DevBufs &) {}
+#endif
     template <class F>
     __device__ __forceinline__ void each(F f) {
         f(lane);
@@ -101,6 +122,7 @@ kernel_fn step_kernel(int kind) {
         case HRL_ANT_GATHER: return k_step<HRL_ANT_GATHER>;
         case HRL_ANT_MAZE: return k_step<HRL_ANT_MAZE>;
         case HRL_ANT_MAZE_MJ: return k_step<HRL_ANT_MAZE_MJ>;
+        case HRL_ANT_FLAGRUN: return k_step<HRL_ANT_FLAGRUN>;
         default: return k_step<HRL_POINT_GATHER>;
     }
 }
@@ -110,6 +132,7 @@ kernel_fn reset_kernel(int kind) {
         case HRL_ANT_GATHER: return k_reset<HRL_ANT_GATHER>;
         case HRL_ANT_MAZE: return k_reset<HRL_ANT_MAZE>;
         case HRL_ANT_MAZE_MJ: return k_reset<HRL_ANT_MAZE_MJ>;
+        case HRL_ANT_FLAGRUN: return k_reset<HRL_ANT_FLAGRUN>;
         default: return k_reset<HRL_POINT_GATHER>;
     }
 }
@@ -138,6 +161,7 @@ DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
     DevBufs d;
     d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
     d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask;
+    d.stamps = g_stamps;
     return d;
 }
 
@@ -224,5 +248,10 @@ int hrl_set_state(hrl_handle *h, const hrl_buffers *b, const float *qpos, const 
 
 const char *hrl_last_error(void) { return g_err.c_str(); }
 const char *hrl_backend(void) { return "hip-gfx950"; }
+
+#ifdef HRL_STAMPS
+/* diagnostic builds only: device buffer of 16 u64 that k_step adds its per-phase cycle sums into */
+void hrl_debug_set_stamps(unsigned long long *dev16) { g_stamps = dev16; }
+#endif
 
 }  // extern "C"

@@ -78,6 +78,8 @@ struct DevCfg {
     float plane_n[4][3], plane_d[4];
     int n_boxes;
     float box_lo[3], box_hi[3];
+    float flag_size;
+    int flag_max_targets, flag_timeout, flag_switch;
     int obs_dim, act_dim;
 };
 
@@ -89,6 +91,7 @@ struct DevBufs {
     uint8_t *done;
     float *info;
     const uint8_t *mask;
+    unsigned long long *stamps; /* diagnostic builds only (tools/stamp_profile.py): per-phase cycle sums */
 };
 
 /* Per-wave LDS record ("LDS-staged link/joint state").  Two overlays keep it under 10 KB so that 16 waves fit a CU:
@@ -110,7 +113,7 @@ struct WaveLds {
             float iint[16];      /* per item: intensity */
             float irew[16];      /* per item: pickup reward */
             float red[16];
-            int flags[4];        /* 0: non-finite obs seen, 1: done */
+            int flags[8];        /* 0: non-finite obs seen, 1: done, 3: flagrun retarget, 4: flagrun packed goal state */
             float scal[8];       /* 0: reward, 1: food_rew, 2: dead_rew, 3: walk_target_dist, 4: yaw, 5: joints_at_limit */
         };
     };
@@ -632,22 +635,35 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
  * index would push the array out of registers into scratch memory. */
 template <int R>
 HRL_DEV void build_A_row(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag) {
-    float a = 0.f;
-    if (R < nR) { /* wave-uniform test; the rows form a flat sequence (no nesting) */
-        a = g.J[0] * L.Bt[R][0];
+    /* one entry: A[lane][R] = J_lane . B_R; computed unconditionally inside its group (rows >= nR read stale LDS and
+     * are replaced by 0), so that the four fma chains of a group are independent instruction streams */
+    float a = g.J[0] * L.Bt[R][0];
 #pragma unroll
-        for (int d = 1; d < 16; ++d) a = fma_(g.J[d], L.Bt[R][d], a);
-        diag = (R == lane) ? a : diag;
-    }
-    g.A[R] = a; /* unconditional: the register is fully redefined every substep */
+    for (int d = 1; d < 16; ++d) a = fma_(g.J[d], L.Bt[R][d], a);
+    a = (R < nR) ? a : 0.f;
+    diag = (R == lane && R < nR) ? a : diag;
+    g.A[R] = a;
 }
-template <int... Rs>
-HRL_DEV void build_A_rows(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag, std::integer_sequence<int, Rs...>) {
-    (build_A_row<Rs>(L, g, lane, nR, diag), ...);
+template <int G>
+HRL_DEV void build_A_group(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag) {
+    /* rows 4G..4G+3 behind one wave-uniform test (flat sequence of groups, no nesting) */
+    if (4 * G < nR) {
+        build_A_row<4 * G>(L, g, lane, nR, diag);
+        build_A_row<4 * G + 1>(L, g, lane, nR, diag);
+        build_A_row<4 * G + 2>(L, g, lane, nR, diag);
+        build_A_row<4 * G + 3>(L, g, lane, nR, diag);
+    } else {
+        g.A[4 * G] = 0.f; g.A[4 * G + 1] = 0.f; g.A[4 * G + 2] = 0.f; g.A[4 * G + 3] = 0.f;
+    }
+}
+template <int... Gs>
+HRL_DEV void build_A_rows(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag, std::integer_sequence<int, Gs...>) {
+    (build_A_group<Gs>(L, g, lane, nR, diag), ...);
 }
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nR) {
     float diag = 1.f;
-    build_A_rows(L, g, lane, nR, diag, std::make_integer_sequence<int, MAXR>{});
+    static_assert(MAXR % 4 == 0, "rows are built in groups of four");
+    build_A_rows(L, g, lane, nR, diag, std::make_integer_sequence<int, MAXR / 4>{});
     g.invd = 1.f / diag;
     float wi = g.J[0] * L.ustar[0];
 #pragma unroll
@@ -719,6 +735,7 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
     const int nR = ant ? nL + 3 * nC : 3 * nC;
     if (nR <= 0) return;
     x.each([&](int lane) { phase_build_A(L, x.reg(lane), lane, nR); });
+    x.stamp(8);
     float mu = c.mu;
     const int iters = c.iters;
     HRL_PIN_VGPR(mu);
@@ -726,6 +743,7 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
         x.refresh();
         pgs_sweep(x, mu, nR, std::make_integer_sequence<int, MAXR>{});
     }
+    x.stamp(9);
     x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });
     x.each([&](int lane) { /* dof map: u = u* + sum_r B_r * lambda_r */
         float v = L.ustar[lane & 15];
@@ -741,16 +759,34 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
     const float *q = L.q[qi];
     float *qn = L.q[qi ^ 1];
     x.refresh(); /* keep lane-derived values local to the substep (see GpuExec::refresh) */
+    x.stamp(0);
     x.each([&](int lane) { phase_kin_ankle(c, L, q, lane); });
+    x.stamp(1);
     x.each([&](int lane) { phase_hip(c, L, lane); });
+    x.stamp(2);
     x.each([&](int lane) { phase_base(c, L, lane); });
+    x.stamp(3);
     x.each([&](int lane) { const float v = phase_forward_vel(c, L, lane); x.reg(lane).ud = v; if (lane < 16) L.ustar[lane] = v; });
+    x.stamp(4);
     /* contacts in surface-major, sphere-minor order (ballot ranks follow lane order), at most MAXC kept:
      * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = boxes */
     int nC = 0;
+    /* Broad phase (wave-uniform): every contact sphere lies within 1.25 m of the torso centre (hip 0.283 + aux 0.283 +
+     * foot 0.566 + radius 0.08 + contact_dist), so a lateral surface farther than that from the torso cannot produce a
+     * contact and its pass is skipped.  Exactly the same contact list as testing every pair. */
+    const float reach = 0.2f * 1.41421356f + c.L1 + c.L2 + c.r_caps + c.cdist + 0.02f;
+    bool near_plane = false, near_box = false;
+    for (int f = 0; f < c.n_planes; ++f)
+        near_plane = near_plane || ((c.plane_n[f][0] * q[0] + c.plane_n[f][1] * q[1] + c.plane_n[f][2] * q[2]) - c.plane_d[f] < reach);
+    if (c.n_boxes > 0) {
+        float d2 = 0.f;
+        for (int k = 0; k < 3; ++k) { const float cp = clampf(q[k], c.box_lo[k], c.box_hi[k]); d2 += (q[k] - cp) * (q[k] - cp); }
+        near_box = d2 < reach * reach;
+    }
     for (int pass = 0; pass < 3; ++pass) {
         const int nsurf = pass == 0 ? 1 : (pass == 1 ? c.n_planes : c.n_boxes);
         if (nsurf == 0) continue;
+        if ((pass == 1 && !x.uniform(near_plane)) || (pass == 2 && !x.uniform(near_box))) continue;
         const int f0 = pass == 0 ? 0 : (pass == 1 ? 1 : 1 + c.n_planes);
         const int base = nC;
         int cnt = x.each_compact(
@@ -770,6 +806,7 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
         nC += cnt;
         if (nC > MAXC) nC = MAXC;
     }
+    x.stamp(5);
     /* joint limits (lane = joint) */
     int nL = x.each_compact(
         [&](int lane) {
@@ -783,7 +820,9 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
         },
         [&](int lane, int rank, const LimitHit &r) { L.ljoint[rank] = lane; L.lsign[rank] = r.sgn; L.ldist[rank] = r.dist; },
         [&](int, const LimitHit &) {});
+    x.stamp(6);
     x.each([&](int lane) { phase_build_row(c, L, x.reg(lane), lane, nL, nC); });
+    x.stamp(7);
     pgs_solve(x, c, nL, nC, true);
     x.each([&](int lane) {
         const int d = lane & 15;
@@ -874,7 +913,9 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
     });
     pgs_solve(x, c, 0, nC, false);
     x.each([&](int lane) { if (lane < 16) L.u[lane] = x.reg(lane).ud; });
+    x.stamp(10);
     x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });
+    x.stamp(11);
 }
 
 /* ================================================================================================= OBSERVATIONS */
@@ -949,9 +990,20 @@ HRL_DEV void maze_line(int l, float *a) {
     }
 }
 
+/* ant_flagrun_env.py:71-78 with counter-based draws: the k-th goal of episode `ep`; one stream shared by all envs
+ * (the reference shares one RandomState between its parallel envs, :38-39); at most 64 attempts */
+HRL_DEV void flag_goal(const DevCfg &c, uint32_t ep, uint32_t k, float *gx, float *gy) {
+    for (uint32_t a = 0; a < 64; ++a) {
+        uint32_t r[4];
+        philox4x32(c, 0, ep, (4u << 16) | k, a, r);
+        *gx = -c.flag_size / 2.f + c.flag_size * u01(r[0]); *gy = -c.flag_size / 2.f + c.flag_size * u01(r[1]);
+        if (!(sqrtf(*gx * *gx + *gy * *gy) < 0.5f)) break;
+    }
+}
+
 /* sizeable_enclosed_scene.py:63-97 `sense_walls`, one bin: the ray and all 7 maze lines are INFINITE lines
  * (intersection_utils.py:74-90), filtered by range and quadrant */
-HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, int i) {
+HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, int i, bool arena) {
     const float half_pi = 1.5707963267948966f;
     float phi;
     if (c.span_is_2pi) phi = half_pi + yaw + ((float)(i + 1) / (float)c.n_bins) * c.sensor_span;
@@ -959,9 +1011,13 @@ HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, in
     const float svx = rx + c.sensor_range * cosf(phi), svy = ry + c.sensor_range * sinf(phi);
     const int sq = quadrant(svx - rx, svy - ry);
     float best = 0.f;
-    for (int l = 0; l < 7; ++l) {
+    for (int l = 0; l < (arena ? 4 : 7); ++l) {
         float a[4], px, py;
-        maze_line(l, a);
+        if (arena) { /* the 4 world lines of a SizeableEnclosedScene (sizeable_enclosed_scene.py:28-34) */
+            const float hx = c.world_sx / 2.f, hy = c.world_sy / 2.f;
+            a[0] = l < 2 ? hx : -hx; a[1] = l < 2 ? hy : -hy;
+            a[2] = (l == 0 || l == 2) ? -hx : hx; a[3] = (l == 0) ? hy : ((l == 1) ? -hy : ((l == 2) ? hy : -hy));
+        } else maze_line(l, a);
         if (!inf_intersection(rx, ry, svx, svy, a[0], a[1], a[2], a[3], &px, &py)) continue;
         const float ddx = rx - px, ddy = ry - py, dist = sqrtf(ddx * ddx + ddy * ddy);
         if (dist > c.sensor_range) continue;
@@ -980,6 +1036,7 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
     float rpy[3];
     quat_to_rpy(qp + 3, rpy);
     float tx = c.walk_tx, ty = c.walk_ty;
+    if (KIND == 5) flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &tx, &ty);
     if (KIND == 2 || KIND == 4) { /* maze kinds: the episode's target */
         const int ti = L.aux[3];
         tx = c.targets[0][0]; ty = c.targets[0][1];
@@ -1077,9 +1134,13 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
     if (lane >= c.obs_dim) return;
     float v = 0.f;
     if (KIND == 0) v = L.st[lane];                       /* MjAnt.py:17-25: qpos | qvel */
+    else if (KIND == 5) { /* ant_flagrun_env.py:122-130: the full 28-vector (+ wall sensor over the arena's 4 lines) */
+        if (lane < 28) v = L.s28[lane];
+        else v = wall_sensor_bin(c, L.st[0], L.st[1], L.scal[4], lane - 28, true);
+    }
     else if (KIND == 4) { /* ant_maze_mj_env.py:57-64: state29 | walls | pit zeros | moveable zeros | t * 0.001 */
         if (lane < 29) v = L.st[lane];
-        else if (lane < 29 + c.n_bins) v = wall_sensor_bin(c, L.st[0], L.st[1], L.scal[4], lane - 29);
+        else if (lane < 29 + c.n_bins) v = wall_sensor_bin(c, L.st[0], L.st[1], L.scal[4], lane - 29, false);
         else if (lane == 29 + 3 * c.n_bins) v = (float)L.aux[0] * 0.001f;
     }
     else if (KIND == 3) {                                /* point: calc_state(8) | food | poison */
@@ -1130,7 +1191,7 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
                     }
                 }
             }
-        } else v = wall_sensor_bin(c, rx, ry, yaw, lane - 26 - ntar); /* lane = bin */
+        } else v = wall_sensor_bin(c, rx, ry, yaw, lane - 26 - ntar, false); /* lane = bin */
     }
     L.obs[lane] = v;
     if (!isfinite(v)) L.flags[0] = 1;
@@ -1161,7 +1222,7 @@ HRL_DEV void phase_point_state(const DevCfg &c, WaveLds &L, int lane) {
 template <int KIND, class X>
 HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
     WaveLds &L = x.lds();
-    const bool centroid = (KIND == 0 || KIND == 2 || KIND == 4);
+    const bool centroid = (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5);
     if (centroid) { /* link positions of the final pose for the parts centroid; its LDS hand-off area overlays the
                        task scratch, so it runs before anything below is written */
         x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
@@ -1170,7 +1231,7 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
     x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
     if (KIND == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
     else {
-        const bool feet = step_mode && KIND == 2; /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
+        const bool feet = step_mode && (KIND == 2 || KIND == 5); /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
         x.each([&](int lane) { phase_calc_state<KIND>(c, L, lane, feet, centroid); });
     }
     if (KIND == 1 || KIND == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode); });
@@ -1191,7 +1252,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
             if (KIND == 3) { if (lane == 2) v = 0.5f; if (lane == 30) v = 1.f; }
             else {
                 float z0 = 0.75f;
-                if (KIND == 2 || KIND == 4) { z0 = c.start_pos[2]; if (lane == 0) v = c.start_pos[0]; if (lane == 1) v = c.start_pos[1]; }
+                if (KIND == 2 || KIND == 4 || KIND == 5) { z0 = c.start_pos[2]; if (lane == 0) v = c.start_pos[0]; if (lane == 1) v = c.start_pos[1]; }
                 if (lane == 2 || lane == 30) v = z0;
                 if (lane >= 7 && lane < 15) {
                     const int j = lane - 7;
@@ -1212,6 +1273,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
         }
         if (lane < 16) L.u[lane] = 0.f;
         if (lane < 8) L.tau[lane] = 0.f;
+        if (lane == 63 && KIND == 5) L.aux[3] = 1; /* first goal popped, steps_since_goal_change = 0, not rewarded */
         if (lane == 63 && (KIND == 2 || KIND == 4)) {
             uint32_t r[4];
             philox4x32(c, env, ep, (3u << 16), 0u, r);
@@ -1220,7 +1282,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
     });
     x.each([&](int lane) { if (lane == 0) L.aux[0] = 0; if (lane == 2) L.aux[2] = L.aux[2] + 1; });
     compute_obs<KIND>(x, c, env, false);
-    x.each([&](int lane) { if (lane == 31) L.st[31] = (KIND == 0 || KIND == 2 || KIND == 4) ? -L.scal[3] / c.dt : 0.f; }); /* upstream calc_potential */
+    x.each([&](int lane) { if (lane == 31) L.st[31] = (KIND == 1 || KIND == 3) ? 0.f : -L.scal[3] / c.dt; }); /* upstream calc_potential */
 }
 
 template <class X>
@@ -1274,6 +1336,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             } else L.tau[j] = c.torque_scale * clampf(L.act[j], -1.f, 1.f);
         }
     });
+    x.stamp(12);
     int qi = 0;
     HRL_PIN_INT(qi);
 #pragma unroll 1
@@ -1289,7 +1352,9 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             L.st[15 + k] = k < 3 ? L.u[3 + k] : (k < 6 ? L.u[k - 3] : L.u[k]);
         }
     });
+    x.stamp(13);
     compute_obs<KIND>(x, c, env, true);
+    x.stamp(14);
     /* reward / done (uniform values, every lane computes them; lane-selected stores) */
     x.each([&](int lane) {
         float rew = 0.f, food = 0.f, dead = 0.f;
@@ -1307,6 +1372,27 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             const float pot = -L.scal[3] / c.dt, progress = pot - L.st[31];
             rew = ((alive + progress) + -0.1f * L.scal[5]) + 0.f;
             L.red[0] = pot;
+        } else if (KIND == 5) { /* upstream WalkerBaseBulletEnv.step with zeroed cost weights (ant_flagrun_env.py:133-135),
+                                   then ant_flagrun_env.py:162-204: goal reward, retarget on reach / timeout, out of goals */
+            const float alive = (L.s28[0] + L.st[30] > 0.26f) ? 1.f : -1.f;
+            int idone = alive < 0.f;
+            for (int i = 0; i < 28; ++i) if (!isfinite(L.s28[i])) idone = 1;
+            const float wtd = L.scal[3], pot = -wtd / c.dt, progress = pot - L.st[31];
+            L.red[0] = pot;
+            int steps = ((L.aux[3] >> 16) & 0x7fff) + 1, rewarded = (L.aux[3] >> 31) & 1, cur = L.aux[3] & 0xffff, retarget = 0;
+            rew = (alive + progress) * 1.f;
+            done = idone;
+            if (wtd < c.tol) {
+                if (!rewarded) { rew += 5000.f; rewarded = 1; }
+                if (c.flag_switch) {
+                    if (cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
+                }
+            }
+            if (c.flag_timeout > 0 && c.flag_timeout <= steps) {
+                if (cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
+            }
+            L.flags[4] = (int)((uint32_t)cur | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
+            L.flags[3] = retarget;
         } else if (KIND == 4) { /* MjAnt.py:36-97, then ant_maze_mj_env.py:66-78 */
             const float alive = L.st[2] > 0.26f ? 1.f : -1.f;
             int idone = alive < 0.f;
@@ -1342,15 +1428,22 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     x.each([&](int lane) { /* each LDS word below is read and written by one lane only */
         if (lane == 0) { L.aux[0] = L.aux[0] + 1; b.reward[e] = L.scal[0]; b.done[e] = (uint8_t)L.flags[1]; }
         if (lane == 1) L.aux[1] = L.aux[1] + 1;
-        if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4)) L.st[31] = L.red[0];
+        if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
+        if (lane == 8 && KIND == 5) L.aux[3] = L.flags[4];
         if (lane >= 4 && lane < 8) {
             const int k = lane - 4;
             b.info[(size_t)e * 4 + k] = k == 0 ? L.scal[1] : (k == 1 ? L.scal[2] : (k == 2 ? L.red[1] : L.red[2]));
         }
     });
-    if (x.uniform(L.flags[1]) && c.auto_reset) reset_env<KIND>(x, c, env);
+    const int done_u = x.uniform(L.flags[1]);
+    if constexpr (KIND == 5) { /* ant_flagrun_env.py:110-118: the returned state is calc_state() w.r.t. the NEW goal */
+        if (x.uniform(L.flags[3])) compute_obs<KIND>(x, c, env, true);
+    }
+    if (done_u && c.auto_reset) reset_env<KIND>(x, c, env);
     store_env(x, b, c, e);
+    x.stamp(15);
+    x.flush_stamps(b);
 }
 
 /* run-time kind -> compile-time KIND (each instantiation only contains its own env's code) */
@@ -1361,7 +1454,8 @@ HRL_DEV void step_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
         case 1: step_entry<1>(x, b, c, e); break;
         case 2: step_entry<2>(x, b, c, e); break;
         case 3: step_entry<3>(x, b, c, e); break;
-        default: step_entry<4>(x, b, c, e); break;
+        case 4: step_entry<4>(x, b, c, e); break;
+        default: step_entry<5>(x, b, c, e); break;
     }
 }
 template <class X>
@@ -1371,7 +1465,8 @@ HRL_DEV void reset_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
         case 1: reset_entry<1>(x, b, c, e); break;
         case 2: reset_entry<2>(x, b, c, e); break;
         case 3: reset_entry<3>(x, b, c, e); break;
-        default: reset_entry<4>(x, b, c, e); break;
+        case 4: reset_entry<4>(x, b, c, e); break;
+        default: reset_entry<5>(x, b, c, e); break;
     }
 }
 

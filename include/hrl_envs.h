@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HRL_ABI_VERSION 1
+#define HRL_ABI_VERSION 2
 
 /* env kinds */
 #define HRL_ANT_FLAT 0     /* AntMjEnv: flat ground, obs 29 (envs/MjAnt.py:31-97)                        */
@@ -34,6 +34,7 @@ extern "C" {
 #define HRL_ANT_MAZE 2     /* AntMazeBulletEnv: obs 26 + 2 + n_bins (envs/ant_maze/ant_maze_bullet_env.py) */
 #define HRL_POINT_GATHER 3 /* PointGatherBulletEnv: obs 8 + 2*n_bins (envs/gather/point_gather_env.py)     */
 #define HRL_ANT_MAZE_MJ 4  /* AntMazeMjEnv: obs 29 + 3*n_bins + 1 (envs/ant_maze/ant_maze_mj_env.py:17-78)    */
+#define HRL_ANT_FLAGRUN 5  /* AntFlagrunBulletEnv: obs 28 (+ sensor_bins) (envs/ant_flagrun/ant_flagrun_env.py) */
 
 /* buffer geometry (floats / ints per env) */
 #define HRL_STATE_STRIDE 32 /* state record: qpos[15] | qvel[14] | ep_return | initial_z | potential */
@@ -45,7 +46,7 @@ extern "C" {
 #define HRL_ITEMS_STRIDE 32 /* 16 items x (x,y): food slots first, then poison slots */
 #define HRL_MAX_ITEMS 16
 #define HRL_MAX_BINS 16
-#define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index */
+#define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
 #define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
 #define HRL_MAX_TARGETS 8
 
@@ -81,7 +82,7 @@ typedef struct hrl_model {
 
 typedef struct hrl_config {
     int32_t abi_version;       /* HRL_ABI_VERSION */
-    int32_t env_kind;          /* HRL_ANT_FLAT .. HRL_ANT_MAZE_MJ */
+    int32_t env_kind;          /* HRL_ANT_FLAT .. HRL_ANT_FLAGRUN */
     int32_t num_envs;          /* envs owned by this handle (this GPU's shard) */
     int32_t max_episode_steps; /* 2000 (hrl_pybullet_envs/__init__.py:15); <= 0 disables */
     int64_t env_id_offset;     /* global id of local env 0: RNG streams are keyed by global id */
@@ -103,6 +104,11 @@ typedef struct hrl_config {
     int32_t centroid_n_static;
     float centroid_static_sum[2];
     float walk_target[2];      /* flat: (1e3, 0) upstream default; maze: overwritten by the episode's target */
+    /* flagrun task (ant_flagrun_env.py:14-16); tolerance -> tol, sensor_bins -> n_bins, use_sensor/sensor_* shared */
+    float flag_size;           /* 10: targets ~ U(-size/2, size/2)^2, arena (size+2)^2 */
+    int32_t flag_max_targets;  /* 100 goals per episode; the episode ends when they run out */
+    int32_t flag_timeout;      /* 200 steps without reaching the goal -> next goal */
+    int32_t flag_switch_on_collision, flag_enclosed;
     hrl_model model;
 } hrl_config;
 

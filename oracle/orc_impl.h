@@ -399,6 +399,38 @@ void FN(orc_maze_mj_task)(const hrl_config *cfg, const REAL *state29, REAL yaw, 
     *rew = r; *done = d;
 }
 
+/* ant_flagrun_env.py:71-78 `create_target`: g ~ U(-size/2, size/2)^2 redrawn while |g| < 0.5 (numpy uniform(lo, hi) =
+ * lo + (hi - lo) * u).  Uniforms from `draws` (two per attempt); returns the number of uniforms consumed or -1. */
+int FN(orc_flag_create_target)(REAL size, const REAL *draws, int n_draws, REAL *goal) {
+    for (int k = 0; 2 * k + 1 < n_draws; ++k) {
+        REAL gx = -size / 2 + size * draws[2 * k], gy = -size / 2 + size * draws[2 * k + 1];
+        if (!(RSQRT(gx * gx + gy * gy) < R_(0.5))) { goal[0] = gx; goal[1] = gy; return 2 * k + 2; }
+    }
+    return -1;
+}
+
+/* ant_flagrun_env.py:162-204 `step` after `super().step(a)`: goal reward, retargeting, timeout, running out of goals.
+ * io: steps (steps_since_goal_change), rewarded, goals_left.  *retarget = 1 when next_target() succeeded. */
+void FN(orc_flagrun_task)(const hrl_config *cfg, REAL inner_rew, int inner_done, REAL walk_target_dist, int *steps,
+                          int *rewarded, int *goals_left, REAL *rew, int *done, int *retarget) {
+    REAL r = inner_rew * 1; /* ant_env_rew_weight = 1; path_rew_weight = dist_rew_weight = 0 (:157-159) */
+    int d = inner_done;
+    *retarget = 0;
+    *steps += 1; /* :171 */
+    if (walk_target_dist < R_(cfg->tol)) { /* :183 */
+        if (!*rewarded) { r += 5000; *rewarded = 1; } /* :184-186, goal_reach_rew :160 */
+        if (cfg->flag_switch_on_collision) {
+            if (*goals_left > 0) { *goals_left -= 1; *rewarded = 0; *steps = 0; *retarget = 1; } /* next_target :110-118 */
+            else d = 1; /* goals.pop() raises IndexError :193-194 */
+        }
+    }
+    if (cfg->flag_timeout > 0 && cfg->flag_timeout <= *steps) { /* :196 */
+        if (*goals_left > 0) { *goals_left -= 1; *rewarded = 0; *steps = 0; *retarget = 1; }
+        else d = 1;
+    }
+    *rew = r; *done = d;
+}
+
 /* =================================================================================================================
  * PART 2 -- RIGID-BODY STEP (build's own specification; PARITY UNPINNED against pybullet, see header)
  * Replaces robot.apply_action + scene.global_step at ant_gather_env.py:77-78 (upstream: setJointMotorControl2 +
@@ -466,6 +498,7 @@ void FN(orc_world_init)(const hrl_config *cfg, FN(orc_world) * W) {
     memset(W, 0, sizeof(*W));
     REAL hx = 0, hy = 0;
     if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) { hx = R_(cfg->world_size[0]) / 2; hy = R_(cfg->world_size[1]) / 2; }
+    if (cfg->env_kind == HRL_ANT_FLAGRUN && (cfg->flag_enclosed || cfg->use_sensor)) { hx = R_(cfg->world_size[0]) / 2; hy = R_(cfg->world_size[1]) / 2; } /* ant_flagrun_env.py:59-61 */
     if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { hx = 5; hy = 9; } /* maze_scene.py:10 */
     if (hx > 0) { /* walls 0.1 thick centred on +-size/2 (sizeable_enclosed_scene.py:46-57, wall.xml:19) */
         REAL t = R_(0.05);
@@ -1009,6 +1042,18 @@ static void FN(gather_obs_tail)(const hrl_config *cfg, const REAL *xy, REAL yaw,
     }
 }
 
+/* the k-th goal of episode `ep` (k = 1, 2, ...): Philox stream shared by ALL envs, like the reference's common
+ * RandomState (ant_flagrun_env.py:38-39), with create_target's rejection (:71-78); at most 64 attempts */
+static void FN(flag_goal)(const hrl_config *cfg, uint32_t ep, uint32_t k, REAL *g) {
+    REAL size = R_(cfg->flag_size);
+    for (uint32_t a = 0; a < 64; ++a) {
+        uint32_t r[4];
+        orc_philox4x32(cfg->seed, 0, ep, (4u << 16) | k, a, r);
+        g[0] = -size / 2 + size * FN(u01)(r[0]); g[1] = -size / 2 + size * FN(u01)(r[1]);
+        if (!(RSQRT(g[0] * g[0] + g[1] * g[1]) < R_(0.5))) break;
+    }
+}
+void FN(orc_flag_goal)(const hrl_config *cfg, int ep, int k, REAL *g) { FN(flag_goal)(cfg, (uint32_t)ep, (uint32_t)k, g); } /* tests */
 static const REAL FN(maze_lines)[7][4] = { /* MazeScene.bounds: maze_scene.py:15-21 + sizeable_enclosed_scene.py:28-34 */
     {5, 9, -5, 9}, {5, 9, 5, -9}, {-5, -9, -5, 9}, {-5, -9, 5, -9}, {1, 2, 1, -2}, {-5, -2, -5, 2}, {-5, -2, 1, -2}};
 
@@ -1038,11 +1083,22 @@ static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *item
     REAL s28[28], rpy[3], wtd, tgt[2] = {R_(cfg->walk_target[0]), R_(cfg->walk_target[1])};
     int nlim;
     if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { tgt[0] = R_(cfg->targets[aux[3]][0]); tgt[1] = R_(cfg->targets[aux[3]][1]); }
+    if (cfg->env_kind == HRL_ANT_FLAGRUN) FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)aux[3] & 0xffffu, tgt);
     FN(orc_ant_calc_state)(cfg, &E->K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
     if (wtd_out) *wtd_out = wtd;
     if (nlim_out) *nlim_out = nlim;
     if (s28_out) for (int i = 0; i < 28; ++i) s28_out[i] = s28[i];
     if (cfg->env_kind == HRL_ANT_FLAT) { for (int i = 0; i < 29; ++i) obs[i] = st[i]; return; } /* MjAnt.py:17-25 */
+    if (cfg->env_kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:122-130: the 28-vector (+ wall sensor over the 4 arena lines) */
+        for (int i = 0; i < 28; ++i) obs[i] = s28[i];
+        if (cfg->use_sensor) {
+            REAL hx = R_(cfg->world_size[0]) / 2, hy = R_(cfg->world_size[1]) / 2;
+            REAL ln[4][4] = {{hx, hy, -hx, hy}, {hx, hy, hx, -hy}, {-hx, -hy, -hx, hy}, {-hx, -hy, hx, -hy}}; /* sizeable_enclosed_scene.py:28-34 */
+            FN(orc_sense_walls)(cfg->n_bins, FN(cfg_angle)(cfg->sensor_span), R_(cfg->sensor_range), st, rpy[2], &ln[0][0], 4,
+                                (double)cfg->sensor_span == (double)(float)6.283185307179586, obs + 28);
+        }
+        return;
+    }
     if (cfg->env_kind == HRL_ANT_MAZE_MJ) {
         REAL r_; int d_;
         FN(orc_maze_mj_task)(cfg, st, rpy[2], 0, 0, wtd, aux[0], &FN(maze_lines)[0][0], 7, obs, &r_, &d_);
@@ -1066,7 +1122,10 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     st[6] = 1; /* identity quaternion (x,y,z,w) */
     if (cfg->env_kind == HRL_POINT_GATHER) { st[2] = R_(0.5); st[HRL_INITZ_OFF] = 1; } /* point_bot.py:12,18 */
     else {
-        if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { /* ant_maze_bullet_env.py:108-118, ant_maze_mj_env.py:85-101 */
+        if (cfg->env_kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:132-155: start (0,0,0.25), first goal popped */
+            aux[3] = 1;
+            st[0] = R_(cfg->start_pos[0]); st[1] = R_(cfg->start_pos[1]); st[2] = R_(cfg->start_pos[2]);
+        } else if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { /* ant_maze_bullet_env.py:108-118, ant_maze_mj_env.py:85-101 */
             uint32_t r[4];
             orc_philox4x32(cfg->seed, env, ep, (3u << 16), 0, r);
             aux[3] = (int32_t)(r[0] % (uint32_t)cfg->n_targets);
@@ -1084,11 +1143,11 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
         for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
         for (int i = 0; i < cfg->n_food + cfg->n_poison; ++i) FN(respawn_item)(cfg, env, ep, 1, i, origin, items + 2 * i);
     }
-    aux[0] = 0; aux[2] = (int32_t)(ep + 1);
+    aux[0] = 0; aux[2] = (int32_t)(ep + 1); /* NB: the flagrun goal stream is keyed by the NEW episode index */
     REAL feet[4] = {0, 0, 0, 0}, wtd = 0;
     FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0);
     /* upstream calc_potential = -dist/dt; only the flat and maze kinds use it */
-    st[HRL_POTENTIAL_OFF] = (cfg->env_kind == HRL_ANT_FLAT || cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) ? -wtd / (E->K.h * R_(E->K.nsub)) : R_(0);
+    st[HRL_POTENTIAL_OFF] = (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) ? R_(0) : -wtd / (E->K.h * R_(E->K.nsub));
 }
 
 /* One env step on the packed record.  Mirrors hrl_step() of include/hrl_envs.h. */
@@ -1142,6 +1201,22 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         REAL pot = -wtd / (K->h * R_(K->nsub));
         FN(orc_antmj_reward)(obs, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &rew, &done);
         st[HRL_POTENTIAL_OFF] = pot;
+    } else if (cfg->env_kind == HRL_ANT_FLAGRUN) { /* upstream WalkerBaseBulletEnv.step with its cost weights zeroed
+                                                     (ant_flagrun_env.py:133-135), then ant_flagrun_env.py:162-204 */
+        REAL wtd, s28[28], rpy[3], tgt[2];
+        int nlim, steps = (aux[3] >> 16) & 0x7fff, rewarded = (aux[3] >> 31) & 1, cur = aux[3] & 0xffff, retarget;
+        FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)cur, tgt);
+        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+        REAL alive = (s28[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
+        int idone = alive < 0;
+        for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
+        REAL pot = -wtd / (K->h * R_(K->nsub)), progress = pot - st[HRL_POTENTIAL_OFF];
+        st[HRL_POTENTIAL_OFF] = pot; /* next_target() re-reads the same stale potential (:116), i.e. leaves it unchanged */
+        int goals_left = cfg->flag_max_targets - cur;
+        FN(orc_flagrun_task)(cfg, alive + progress, idone, wtd, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
+        cur = cfg->flag_max_targets - goals_left;
+        aux[3] = (int32_t)((uint32_t)cur | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
+        FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0); /* calc_state w.r.t. the (possibly new) goal */
     } else if (cfg->env_kind == HRL_ANT_MAZE_MJ) { /* MjAnt.py:36-97 then ant_maze_mj_env.py:66-78 */
         REAL wtd, s28[28], rpy[3], inner, tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};
         int nlim, idone;

@@ -21,6 +21,8 @@ struct CpuExec {
     LaneRegs &reg(int lane) { return regs[lane]; }
     int uniform(int v) { return v; }
     void refresh() {}
+    void stamp(int) {}
+    void flush_stamps(const DevBufs &) {}
     template <class F> void each(F f) {
         if (!reverse) for (int lane = 0; lane < 64; ++lane) f(lane);
         else for (int lane = 63; lane >= 0; --lane) f(lane);
@@ -56,7 +58,7 @@ struct CpuExec {
 static DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
     DevBufs d;
     d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
-    d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask;
+    d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask; d.stamps = nullptr;
     return d;
 }
 

@@ -489,6 +489,50 @@ def main():
                    'rew': float(rew), 'done': bool(d), 't_after': int(self.t)})
     G['maze_mj_step'] = mm
 
+    # ---------------------------------------------------------------- AntFlagrunBulletEnv.step bookkeeping (ant_flagrun_env.py:162-204)
+    from hrl_pybullet_envs.envs.ant_flagrun.ant_flagrun_env import AntFlagrunBulletEnv
+    fr = []
+    for k in range(60):
+        lrs = np.random.RandomState(13000 + k)
+        n_goals = int(lrs.randint(0, 4))                      # goals left in the list (0 -> IndexError -> done)
+        goals = [tuple(lrs.uniform(-5, 5, 2)) for _ in range(n_goals)]
+        tol, timeout = 0.5, int(lrs.choice([5, 200]))
+        switch = bool(lrs.randint(0, 2)) if k % 4 == 0 else True
+        steps0 = int(lrs.randint(0, 7)); rewarded0 = bool(lrs.randint(0, 2)) if not switch else False
+        wtd = float(lrs.uniform(0.0, 1.0)) if k % 2 == 0 else float(lrs.uniform(0.5, 6.0))
+        inner_r = float(lrs.uniform(-2, 2)); inner_d = bool(lrs.randint(0, 8) == 0)
+        s_old = lrs.uniform(-1, 1, 28).astype(np.float32); s_new = lrs.uniform(-1, 1, 28).astype(np.float32)
+        pos = lrs.uniform(-4, 4, 3)
+        robot = NS(walk_target_dist=wtd, walk_target_x=0.0, walk_target_y=0.0, body_real_xyz=pos,
+                   robot_body=NS(get_position=lambda: pos), calc_potential=lambda: -wtd / 0.0165,
+                   calc_state=lambda: s_new.copy())
+        self = AntFlagrunBulletEnv.__new__(AntFlagrunBulletEnv)
+        self.__dict__.update(dict(robot=robot, tol=tol, timeout=timeout, switch_flag_on_collision=switch, max_targets=100,
+                                  goals=list(goals), steps_since_goal_change=steps0, _rewarded=rewarded0, debug=False,
+                                  use_sensor=False, isRender=False, flag=None, walk_target_x=1.0, walk_target_y=2.0,
+                                  _sq_dist_goal=3.0, _goal_start_pos=np.array([0.5, 0.5]), potential=-77.0,
+                                  _super_step_result=(s_old.copy(), inner_r, inner_d, {})))
+        obs, r, d, info = AntFlagrunBulletEnv.step(self, np.zeros(8))
+        fr.append({'n_goals': n_goals, 'last_goal': list(map(float, goals[-1])) if goals else None, 'tol': tol, 'timeout': timeout,
+                   'switch': switch, 'steps_before': steps0, 'rewarded_before': rewarded0, 'walk_target_dist': wtd,
+                   'inner_rew': inner_r, 'inner_done': inner_d, 'rew': float(r), 'done': bool(d),
+                   'steps_after': int(self.steps_since_goal_change), 'rewarded_after': bool(self._rewarded),
+                   'goals_left': len(self.goals), 'retargeted': bool('target' in info),
+                   'obs_is_new_state': bool(np.array_equal(obs, s_new)),
+                   'target_after': [float(self.walk_target_x), float(self.walk_target_y)]})
+    G['flagrun_step'] = fr
+    # create_target rejection logic (ant_flagrun_env.py:71-78) with the uniforms it consumed
+    class LogU:
+        def __init__(self, seed): self.rs = np.random.RandomState(seed); self.log = []
+        def uniform(self, lo, hi):
+            u = self.rs.uniform(lo, hi); self.log.append(float(u)); return u
+    ct = []
+    for k in range(40):
+        self = NS(size=10 if k % 2 == 0 else 1.2, mpi_common_rand=LogU(14000 + k))
+        g = AntFlagrunBulletEnv.create_target(self)
+        ct.append({'size': self.size, 'draws': self.mpi_common_rand.log, 'goal': [float(g[0]), float(g[1])]})
+    G['flagrun_create_target'] = ct
+
     for name, val in G.items():
         with open(os.path.join(OUT_DIR, name + '.json'), 'w') as f:
             json.dump(val, f, allow_nan=True)

@@ -9,7 +9,7 @@ import emu_env
 import orc
 from hrl_pybullet_envs_amd import _capi as K
 
-KINDS = [K.HRL_ANT_FLAT, K.HRL_ANT_GATHER, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER, K.HRL_ANT_MAZE_MJ]
+KINDS = [K.HRL_ANT_FLAT, K.HRL_ANT_GATHER, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER, K.HRL_ANT_MAZE_MJ, K.HRL_ANT_FLAGRUN]
 
 
 @pytest.mark.parametrize('kind', KINDS)
@@ -108,6 +108,31 @@ def test_abs_pos_observation_variant(kind, n_bins, nf, npo):
     assert np.all(np.diff(d2, axis=1) >= -1e-4)
 
 
+def test_flagrun_goals_rewards_and_exhaustion():
+    """Teleport the ants onto their goals: +5000 and a new goal each time, `done` once the 4 goals are used up."""
+    import ctypes as C
+    n = 16
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=6, auto_reset=1, flag_max_targets=4, use_sensor=1)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    rng = np.random.RandomState(3)
+    hits = dones = 0
+    for t in range(24):
+        if t % 2 == 1:
+            for i in range(n):
+                g = np.zeros(2, np.float32)
+                orc.lib().orc_flag_goal_f32(C.byref(cfg), int(o.aux[i, 2]), int(o.aux[i, 3] & 0xffff), orc.ptr(g))
+                # walk_target_dist is measured from the parts centroid (13 links + floor + wall at (-6, 0)): invert it
+                o.state[i, 0:2] = np.clip([(15 * g[0] + 6) / 13, 15 * g[1] / 13], -5.5, 5.5); o.state[i, 2] = 0.6
+            e.state[...] = o.state
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        hits += int((o.rew > 1000).sum()); dones += int(o.done.sum())
+        for name in ('state', 'aux', 'obs', 'rew', 'done'):
+            assert np.array_equal(getattr(o, name), getattr(e, name)), (t, name)
+    assert o.obs.shape == (n, 36) and hits >= 4 * n and dones >= n
+
+
 def test_validation_errors():
     import ctypes as C
     L = emu_env.lib()
@@ -126,4 +151,4 @@ def test_product_defaults_equal_oracle_defaults():
     for kind in KINDS:
         a = K.hrl_config(); emu_env.lib().emu_default_config(kind, C.byref(a))
         assert bytes(a) == bytes(orc.default_config(kind))
-        assert emu_env.lib().emu_obs_dim(C.byref(a)) == orc.obs_dim(a) == {0: 29, 1: 46, 2: 38, 3: 18, 4: 60}[kind]
+        assert emu_env.lib().emu_obs_dim(C.byref(a)) == orc.obs_dim(a) == {0: 29, 1: 46, 2: 38, 3: 18, 4: 60, 5: 28}[kind]

@@ -16,7 +16,7 @@ import orc
 from hrl_pybullet_envs_amd import _capi as K
 
 pytestmark = pytest.mark.gpu
-KINDS = [K.HRL_ANT_GATHER, K.HRL_ANT_FLAT, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER, K.HRL_ANT_MAZE_MJ]
+KINDS = [K.HRL_ANT_GATHER, K.HRL_ANT_FLAT, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER, K.HRL_ANT_MAZE_MJ, K.HRL_ANT_FLAGRUN]
 OBS_ATOL = 2e-6
 
 

@@ -51,7 +51,7 @@ def test_struct_layout_matches_header():
         out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
     assert [int(x) for x in out] == [C.sizeof(K.hrl_config), C.sizeof(K.hrl_model), C.sizeof(K.hrl_buffers)]
     # product defaults == oracle defaults, byte for byte, for every kind
-    for kind in range(5):
+    for kind in range(6):
         assert bytes(_lib.default_config(kind)) == bytes(orc.default_config(kind))
 
 
@@ -80,6 +80,10 @@ def test_env_classes_mirror_reference_constructor_api():
     assert H.AntMjEnv().observation_space.shape == (29,)                         # MjAnt.py:15
     assert H.AntMazeMjEnv().observation_space.shape == (60,)                     # ant_maze_mj_env.py:50
     assert H.AntMazeMjEnv()._cfg.n_targets == 5                                  # ant_maze_mj_env.py:13-14
+    assert H.AntFlagrunBulletEnv().observation_space.shape == (28,)              # ant_flagrun_env.py:53-55
+    assert H.AntFlagrunBulletEnv(use_sensor=True).observation_space.shape == (36,)
+    with pytest.raises(AssertionError):
+        H.AntFlagrunBulletEnv(max_targets=5, max_target_dist=3)                  # ant_flagrun_env.py:17-18
     with pytest.raises(ValueError):
         H.AntMazeBulletEnv(target_encoding=5)                                    # PositionEncoding(5), utils.py:66-68
     assert isinstance(H.make('AntMazeBulletEnv-v0', tol=2.0), H.AntMazeBulletEnv)

@@ -223,3 +223,25 @@ def test_maze_mj_step_task_half():
         np.testing.assert_allclose(obs, c['obs'], atol=1e-11)
         assert rew.value == pytest.approx(c['rew'], abs=1e-9) and bool(done.value) == c['done']
         assert c['t_after'] == c['t_before'] + 1
+
+
+def test_flagrun_step_bookkeeping_and_targets():
+    """ant_flagrun_env.py:162-204 (goal reward, retarget on reach / timeout, running out of goals) and :71-78."""
+    for c in load('flagrun_step'):
+        cfg = orc.default_config(K.HRL_ANT_FLAGRUN, tol=c['tol'], flag_timeout=c['timeout'], flag_switch_on_collision=int(c['switch']))
+        steps = C.c_int(c['steps_before']); rewarded = C.c_int(int(c['rewarded_before'])); left = C.c_int(c['n_goals'])
+        rew = C.c_double(); done = C.c_int(); retarget = C.c_int()
+        orc.lib().orc_flagrun_task_f64(C.byref(cfg), C.c_double(c['inner_rew']), int(c['inner_done']), C.c_double(c['walk_target_dist']),
+                                       C.byref(steps), C.byref(rewarded), C.byref(left), C.byref(rew), C.byref(done), C.byref(retarget))
+        assert rew.value == pytest.approx(c['rew'], abs=1e-9) and bool(done.value) == c['done']
+        assert steps.value == c['steps_after'] and bool(rewarded.value) == c['rewarded_after'] and left.value == c['goals_left']
+        assert bool(retarget.value) == c['retargeted'] == c['obs_is_new_state']
+        if c['retargeted']:
+            assert c['target_after'] == c['last_goal']  # goals.pop(): the LAST goal of the list is next
+    for c in load('flagrun_create_target'):
+        g = np.zeros(2)
+        used = orc.lib().orc_flag_create_target_f64(C.c_double(c['size']), orc.ptr(arr([(u + c['size'] / 2) / c['size'] for u in c['draws']])),
+                                                    len(c['draws']), orc.ptr(g))
+        assert used == len(c['draws'])
+        np.testing.assert_allclose(g, c['goal'], atol=1e-12)
+        assert np.linalg.norm(g) >= 0.5
