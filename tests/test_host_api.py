@@ -101,3 +101,39 @@ def test_shard_range_partitions_all_envs():
         assert spans[0][0] == 0 and sum(c for _, c in spans) == total
         for (o0, c0), (o1, _) in zip(spans, spans[1:]):
             assert o0 + c0 == o1
+
+
+def test_gymnasium_adapter_five_tuple():
+    import torch
+    from hrl_pybullet_envs_amd.adapters import GymnasiumAdapter
+
+    class Fake:  # old-gym shaped, like the env classes
+        observation_space = action_space = None
+        max_episode_steps = 5
+
+        def __init__(self, n):
+            self.num_envs, self.t = n, 0
+
+        def seed(self, s):
+            self.seeded = s
+
+        def reset(self):
+            self.t = 0
+            return 'obs0'
+
+        def step(self, a):
+            self.t += 1
+            if self.num_envs == 1:
+                return 'o', 1.0, self.t >= 5, ({'TimeLimit.truncated': True} if self.t >= 5 else {})
+            done = torch.tensor([self.t >= 5, self.t == 2], dtype=torch.uint8)
+            return 'o', torch.ones(2), done, {'episode_length': torch.tensor([float(self.t), 2.0])}
+
+    g = GymnasiumAdapter(Fake(1))
+    assert g.reset(seed=3) == ('obs0', {}) and g.env.seeded == 3
+    outs = [g.step(None) for _ in range(5)]
+    assert outs[0][2:4] == (False, False) and outs[-1][2:4] == (False, True)
+    gb = GymnasiumAdapter(Fake(2))
+    gb.reset()
+    o = [gb.step(None) for _ in range(5)]
+    assert o[1][2].tolist() == [False, True] and o[1][3].tolist() == [False, False]   # env 1 terminated at t=2
+    assert o[4][2].tolist() == [False, False] and o[4][3].tolist() == [True, False]   # env 0 truncated at the limit
