@@ -190,6 +190,22 @@ HRL_DEV void quat_axes(float x, float y, float z, float w, float *X, float *Y, f
     Z[0] = 2.f * fma_(x, z, w * y); Z[1] = 2.f * fma_(y, z, -(w * x)); Z[2] = fma_(-2.f, fma_(x, x, y * y), 1.f);
 }
 HRL_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* Solver clamp = median of three, specified with the semantics of gfx950's v_med3_f32 so that the device can use the
+ * single instruction: any NaN operand -> minimum of the non-NaN operands; zeros ordered -0 < +0. */
+HRL_DEV float med3_spec(float x, float lo, float hi) {
+#ifdef HRL_EMU
+    auto lt = [](float a, float b) { return a < b || (a == b && signbit(a) && !signbit(b)); };
+    auto mn = [&](float a, float b) { return isnan(a) ? b : (isnan(b) ? a : (lt(b, a) ? b : a)); };
+    auto mx = [&](float a, float b) { return isnan(a) ? b : (isnan(b) ? a : (lt(a, b) ? b : a)); };
+    if (isnan(x) || isnan(lo) || isnan(hi)) return mn(mn(x, lo), hi);
+    const float m3 = mx(mx(x, lo), hi);
+    if (m3 == x && signbit(m3) == signbit(x)) return mx(lo, hi);
+    if (m3 == lo && signbit(m3) == signbit(lo)) return mx(x, hi);
+    return mx(x, lo);
+#else
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#endif
+}
 /* symmetric 6x6 stored as the upper triangle, row-major (21 floats) */
 HRL_DEV constexpr int si(int a, int b) { return a <= b ? a * 6 - (a * (a - 1)) / 2 + (b - a) : b * 6 - (b * (b - 1)) / 2 + (a - b); }
 HRL_DEV void sym6_matvec(float *o, const float *A, const float *x) {
@@ -713,7 +729,7 @@ HRL_DEV void pgs_row(X &x, float mu, int nR) { /* update of solver row R (compil
             [&](int lane) {
                 const LaneRegs &g = x.reg(lane);
                 F2b o;
-                o.ln = clampf(fma_(-(g.w + g.bias), g.invd, g.lam), g.lo, g.hi);
+                o.ln = med3_spec(fma_(-(g.w + g.bias), g.invd, g.lam), g.lo, g.hi);
                 o.dl = o.ln - g.lam;
                 return o;
             },

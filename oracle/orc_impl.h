@@ -87,6 +87,18 @@ static inline void FN(dyn_sincos)(REAL x, REAL *sn, REAL *cs) {
 #endif
 }
 static inline REAL FN(clampr)(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* Solver clamp = median of three with the semantics of gfx950's v_med3_f32: any NaN operand -> minimum
+ * of the non-NaN operands; zeros ordered -0 < +0. */
+static inline int FN(zlt)(REAL a, REAL b) { return a < b || (a == b && signbit(a) && !signbit(b)); }
+static inline REAL FN(zmin)(REAL a, REAL b) { return isnan(a) ? b : (isnan(b) ? a : (FN(zlt)(b, a) ? b : a)); }
+static inline REAL FN(zmax)(REAL a, REAL b) { return isnan(a) ? b : (isnan(b) ? a : (FN(zlt)(a, b) ? b : a)); }
+static inline REAL FN(med3)(REAL x, REAL lo, REAL hi) {
+    if (isnan(x) || isnan(lo) || isnan(hi)) return FN(zmin)(FN(zmin)(x, lo), hi);
+    REAL m3 = FN(zmax)(FN(zmax)(x, lo), hi);
+    if (m3 == x && signbit(m3) == signbit(x)) return FN(zmax)(lo, hi);
+    if (m3 == lo && signbit(m3) == signbit(lo)) return FN(zmax)(x, hi);
+    return FN(zmax)(x, lo);
+}
 /* hrl_config stores angles as float; the reference kwargs are python floats (np.pi, 2*np.pi): promote exact matches */
 static inline REAL FN(cfg_angle)(float v) {
     if (v == (float)3.14159265358979323846) return R_(3.14159265358979323846);
@@ -740,7 +752,7 @@ static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, 
     }
     for (int it = 0; it < iters; ++it)
         for (int r = 0; r < nr; ++r) {
-            REAL ln = FN(clampr)(FMA_(-(w[r] + bias[r]), invd[r], lam[r]), lo[r], hi[r]);
+            REAL ln = FN(med3)(FMA_(-(w[r] + bias[r]), invd[r], lam[r]), lo[r], hi[r]);
             REAL dl = ln - lam[r];
             lam[r] = ln;
             for (int i = 0; i < nr; ++i) {
