@@ -599,20 +599,23 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
         g.bias = 0.f; g.fn = -1; g.lam = 0.f; g.lo = 0.f; g.hi = 0.f;
         return;
     }
+    /* limit rows and contact rows only differ in their impulse (phi / joint impulse) and parameters: those are set
+     * in the (divergent) branches, the expensive impulse response is computed once, outside them */
+    float phi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, th = 0.f, ta = 0.f;
+    int level = 0, leg = 0;
     if (row_id < nL) {
         const int j = L.ljoint[row_id];
         const float sgn = L.lsign[row_id], dist = L.ldist[row_id];
-        float zero6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NJ; ++k) J[6 + k] = (k == j) ? sgn : 0.f;
-        response(L, zero6, 0, j >> 1, (j & 1) ? 0.f : sgn, (j & 1) ? sgn : 0.f, B);
+        leg = j >> 1; th = (j & 1) ? 0.f : sgn; ta = (j & 1) ? sgn : 0.f;
         bias = (dist > 0.f ? dist : c.erp_l * dist) * c.inv_h;
         hi = c.limp_max;
     } else {
         const int row = row_id - nL;
         const int ci = row < nC ? row : (row - nC) >> 1, which = row < nC ? 0 : 1 + ((row - nC) & 1);
         float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
-        float t1[3], t2[3], phi[6];
+        float t1[3], t2[3];
         tangent_basis(n, t1, t2);
         float d[3];
 #pragma unroll
@@ -620,7 +623,7 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
         cross3(phi, r, d);
 #pragma unroll
         for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
-        const int level = L.clink[ci] & 3, leg = L.clink[ci] >> 2;
+        level = L.clink[ci] & 3; leg = L.clink[ci] >> 2;
 #pragma unroll
         for (int k = 0; k < 6; ++k) J[k] = phi[k];
         const float jh = dot6(phi, L.S[2 * leg]), ja = dot6(phi, L.S[2 * leg + 1]);
@@ -629,13 +632,13 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
             J[6 + 2 * k] = (k == leg && level >= 1) ? jh : 0.f;
             J[7 + 2 * k] = (k == leg && level >= 2) ? ja : 0.f;
         }
-        response(L, phi, level, leg, 0.f, 0.f, B);
         if (which == 0) {
             const float dist = L.cdist_[ci];
             bias = (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h;
             hi = 1e30f;
         } else { bias = 0.f; frn = nL + ci; }
     }
+    response(L, phi, level, leg, th, ta, B);
 #pragma unroll
     for (int k = 0; k < 16; ++k) g.J[k] = J[k];
     if (active) {
