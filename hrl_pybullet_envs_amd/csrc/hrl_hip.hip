@@ -4,7 +4,8 @@
  * One 64-thread workgroup = one wavefront = one environment.  The wave runs the phases of step_core.h with
  *   - per-wave state staged in LDS (WaveLds < 10 KB and <= 128 VGPRs -> 16 waves per CU, 4 per SIMD),
  *   - coalesced 128-byte loads/stores of the packed state / item records (lane i <-> float i of the record),
- *   - a DPP row-rotate butterfly for the 16-lane J.u reductions of the contact/limit solver (no LDS, no barrier),
+ *   - the contact/limit solver entirely in lane registers: row r lives in lane r, its update is broadcast with
+ *     v_readlane_b32 (no LDS, no barrier, no reduction on the dependent chain),
  *   - ballot + mbcnt for compacting active contacts / limits into solver rows.
  * There is no cross-workgroup communication, so no XCD-aware block remap is needed: blockIdx.x = env index and the
  * dispatcher's round-robin over the 8 XCDs spreads the envs evenly.
@@ -21,19 +22,6 @@ namespace {
 
 thread_local std::string g_err;
 unsigned long long *g_stamps = nullptr; /* set only by the diagnostic entry point hrl_debug_set_stamps */
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-/* butterfly over a 16-lane DPP row: pairs at distance 8, 4, 2, 1 -- every lane ends with the same bits */
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_mov<0x128>(v); /* row_ror:8 */
-    v += dpp_mov<0x124>(v); /* row_ror:4 */
-    v += dpp_mov<0x122>(v); /* row_ror:2 */
-    v += dpp_mov<0x121>(v); /* row_ror:1 */
-    return v;
-}
 
 struct GpuExec {
     WaveLds &L;
@@ -80,11 +68,6 @@ struct GpuExec {
         post(lane, h);
         __syncthreads();
         return __popcll(m);
-    }
-    template <class P, class C>
-    __device__ __forceinline__ void each_reduce16(P produce, C consume) {
-        const float v = row16_sum(produce(lane));
-        consume(lane, v);
     }
     /* every lane produces a pair, lane `src`'s pair is broadcast to the wave (two v_readlane_b32) */
     template <class P, class C>

@@ -10,7 +10,7 @@
  *   raw-state obs + locomotion reward                             MjAnt.py:17-25,36-97
  * written as a sequence of wave-wide PHASES.  A phase is a function of (lane, LDS); lanes communicate only
  * through the per-wave LDS record `WaveLds` between phases (plus three wave primitives supplied by the executor:
- * a 16-lane rotate-add reduction, a ballot/prefix compaction and per-lane persistent registers).  The executor `X`
+ * a ballot/prefix compaction, a lane broadcast and per-lane persistent registers).  The executor `X`
  * is the HIP wave (hrl_hip.hip: one 64-thread workgroup = one wavefront = one env, phases separated by a
  * workgroup barrier); tests/emu provides a lock-step host executor so the same phases can be checked on a box
  * without a GPU -- that executor is test infrastructure and is never used by the product.
@@ -34,11 +34,7 @@
 #define HRL_DEV inline
 #define HRL_PIN_VGPR(x) ((void)0)
 #define HRL_PIN_INT(x) ((void)0)
-#define HRL_SCHED_FENCE() ((void)0)
 #else
-/* keep the instruction scheduler from moving code across this point (used between the unrolled rows of the
- * A build: without it all 44 rows' LDS loads are hoisted to the front and spill) */
-#define HRL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define HRL_DEV __device__ __forceinline__
 /* Materialise a wave-uniform value in a VGPR here.  Used before the solver loop: a constant that is still an
  * outstanding scalar load inside the loop makes hipcc wait on lgkmcnt(0) there, which also drains the loop's LDS
@@ -53,8 +49,6 @@ constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (
 constexpr int MAXC = 12;  /* contacts kept per substep */
 constexpr int MAXR = 44;  /* constraint rows per substep: 8 limits + 12 * (normal + 2 friction) */
 
-struct F2 { float x, y; };
-struct alignas(16) F4 { float x, y, z, w; };
 
 /* Everything the kernels need from hrl_config, plus constants derived from it on the host (host_cfg.h). */
 struct DevCfg {
@@ -240,15 +234,6 @@ HRL_DEV void crf(float *o, const float *v, const float *f) { /* spatial force cr
     cross3(a, v, f); cross3(b, v + 3, f + 3); cross3(c, v, f + 3);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
-}
-/* balanced butterfly sum over 16 slots: the order the 16-lane rotate-add reduction produces */
-HRL_DEV float tree16(const float *x) {
-    float a[8], b[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = x[i] + x[i + 8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = a[i] + a[i + 4];
-    return (b[0] + b[2]) + (b[1] + b[3]);
 }
 HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
     if (fabsf(n[2]) > 0.70710678118654752440f) {

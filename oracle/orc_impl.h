@@ -38,14 +38,6 @@ static inline REAL FN(v3dot)(const REAL *a, const REAL *b) { return FMA_(a[2], b
 static inline REAL FN(dot6)(const REAL *a, const REAL *b) {
     return FMA_(a[5], b[5], FMA_(a[4], b[4], FMA_(a[3], b[3], FMA_(a[2], b[2], FMA_(a[1], b[1], a[0] * b[0])))));
 }
-/* balanced butterfly over 16 slots: pairs (i,i+8), then +4, +2, +1 -- the order a 16-lane rotate-add tree produces */
-static inline REAL FN(sum16_tree)(const REAL *x) {
-    REAL a[8], b[4], c[2];
-    for (int i = 0; i < 8; ++i) a[i] = x[i] + x[i + 8];
-    for (int i = 0; i < 4; ++i) b[i] = a[i] + a[i + 4];
-    for (int i = 0; i < 2; ++i) c[i] = b[i] + b[i + 2];
-    return c[0] + c[1];
-}
 #if REAL_IS_FLOAT
 #define RSQRT(x) sqrtf(x)
 #define RSIN(x) sinf(x)

@@ -44,15 +44,6 @@ struct CpuExec {
         if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, v[src]);
         else for (int lane = 63; lane >= 0; --lane) consume(lane, v[src]);
     }
-    template <class P, class C> void each_reduce16(P produce, C consume) {
-        float v[64];
-        if (!reverse) for (int lane = 0; lane < 64; ++lane) v[lane] = produce(lane);
-        else for (int lane = 63; lane >= 0; --lane) v[lane] = produce(lane);
-        float s[4];
-        for (int g = 0; g < 4; ++g) s[g] = tree16(v + 16 * g);
-        if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, s[lane >> 4]);
-        else for (int lane = 63; lane >= 0; --lane) consume(lane, s[lane >> 4]);
-    }
 };
 
 static DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
