@@ -160,7 +160,10 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.L1 = (float)Ls[0]; d.L2 = (float)Ls[1]; d.r_torso = (float)rt; d.r_caps = (float)rc;
     const double lo[NJ] = {-40, 30, -40, -100, -40, -100, -40, 30}, hi[NJ] = {40, 100, 40, -30, 40, -30, 40, 100}; /* ant.xml:18-54 */
     const double d2r = pi / 180.0;
-    for (int j = 0; j < NJ; ++j) { d.jlo[j] = (float)(lo[j] * d2r); d.jhi[j] = (float)(hi[j] * d2r); }
+    for (int j = 0; j < NJ; ++j) {
+        d.jlo[j] = (float)(lo[j] * d2r); d.jhi[j] = (float)(hi[j] * d2r);
+        d.jmid[j] = 0.5f * (d.jlo[j] + d.jhi[j]); d.jscale[j] = 2.0f / (d.jhi[j] - d.jlo[j]);
+    }
     /* static world: walls 0.1 thick centred on +-size/2 (sizeable_enclosed_scene.py:46-57, wall.xml:19); maze box (box.xml:19) */
     float hx = 0.f, hy = 0.f;
     if (c.env_kind == HRL_ANT_GATHER || c.env_kind == HRL_POINT_GATHER) { hx = c.world_size[0] / 2; hy = c.world_size[1] / 2; }

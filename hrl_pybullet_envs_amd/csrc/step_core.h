@@ -67,7 +67,7 @@ struct DevCfg {
     float h, inv_h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z, torque_scale, point_force, dt;
     int iters, nsub;
     float m0, a0, b0, m1, a1, b1, m2, a2, b2, L1, L2, r_torso, r_caps;
-    float jlo[NJ], jhi[NJ];
+    float jlo[NJ], jhi[NJ], jmid[NJ], jscale[NJ]; /* limits; mid-point and 2/(hi-lo) for the scaled joint observation */
     int n_planes;
     float plane_n[4][3], plane_d[4];
     int n_boxes;
@@ -1063,22 +1063,27 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
         cy = ((13.f * qp[1] + sy) + c.centroid_sy) / np_;
     }
     const float dx = tx - cx, dy = ty - cy;
-    const float theta = atan2f(dy, dx), wtd = sqrtf(dy * dy + dx * dx), ang = theta - rpy[2];
+    /* AntGather / PointGather drop the two angle-to-target entries (ant_gather_env.py:81) and never use the target
+     * distance: skip their transcendental work there */
+    float sin_ang = 0.f, cos_ang = 0.f, wtd = 0.f;
+    if (KIND != 1) {
+        const float theta = atan2f(dy, dx), ang = theta - rpy[2];
+        wtd = sqrtf(dy * dy + dx * dx); sin_ang = sinf(ang); cos_ang = cosf(ang);
+    }
     const float cs = cosf(-rpy[2]), sn = sinf(-rpy[2]);
     const float vx = cs * qv[0] - sn * qv[1], vy = sn * qv[0] + cs * qv[1], vz = qv[2];
     int nlim = 0;
     float mine = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const float mid = 0.5f * (c.jlo[j] + c.jhi[j]);
-        const float rel = 2.f * (qp[7 + j] - mid) / (c.jhi[j] - c.jlo[j]);
+        const float rel = (qp[7 + j] - c.jmid[j]) * c.jscale[j];
         if (fabsf(rel) > 0.99f) ++nlim;
         mine = (lane == 8 + 2 * j) ? rel : mine;
         mine = (lane == 9 + 2 * j) ? 0.1f * qv[6 + j] : mine;
     }
     mine = (lane == 0) ? qp[2] - L.st[30] : mine;
-    mine = (lane == 1) ? sinf(ang) : mine;
-    mine = (lane == 2) ? cosf(ang) : mine;
+    mine = (lane == 1) ? sin_ang : mine;
+    mine = (lane == 2) ? cos_ang : mine;
     mine = (lane == 3) ? 0.3f * vx : mine;
     mine = (lane == 4) ? 0.3f * vy : mine;
     mine = (lane == 5) ? 0.3f * vz : mine;

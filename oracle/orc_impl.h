@@ -1002,8 +1002,8 @@ void FN(orc_ant_calc_state)(const hrl_config *cfg, const FN(orc_consts) * K, con
     out28[3] = R_(0.3) * vx; out28[4] = R_(0.3) * vy; out28[5] = R_(0.3) * vz; out28[6] = rpy[0]; out28[7] = rpy[1];
     int nlim = 0;
     for (int j = 0; j < NJ; ++j) {
-        REAL mid = R_(0.5) * (K->lo[j] + K->hi[j]);
-        REAL rel = 2 * (qpos[7 + j] - mid) / (K->hi[j] - K->lo[j]);
+        REAL mid = R_(0.5) * (K->lo[j] + K->hi[j]), scale = R_(2) / (K->hi[j] - K->lo[j]);
+        REAL rel = (qpos[7 + j] - mid) * scale; /* upstream: 2 * (pos - mid) / (hi - lo) */
         out28[8 + 2 * j] = rel; out28[9 + 2 * j] = R_(0.1) * qvel[6 + j];
         if (RFABS(rel) > R_(0.99)) ++nlim;
     }
