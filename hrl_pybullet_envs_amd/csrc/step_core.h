@@ -138,7 +138,9 @@ struct WaveLds {
  * (the solver's working set; on the GPU these are VGPRs, the row-space solver never touches LDS in its sweeps) */
 struct LaneRegs {
     float ud;                        /* dof map: the lane's velocity component */
-    float J[16], A[MAXR];            /* row map: the row's Jacobian and its row of A = J M^-1 J^T */
+    float Jb[6], Jh, Ja;             /* row map: the row's Jacobian, sparse: torso twist part + the hip / ankle entries */
+    int jslot;                       /* row map: dof slot of Jh (Ja is the next slot): 6 + 2 * leg                   */
+    float A[MAXR];                   /* row map: the row's line of A = J M^-1 J^T                                    */
     float w, lam, bias, invd, lo, hi; /* row map: constraint velocity, impulse, bias, 1/A_ii, bounds */
     int fn;                          /* row map: friction rows: index of their normal row, else -1 */
 };
@@ -574,13 +576,12 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
      * would, and the 60 of them would be spilled in the register-hungry leg phases). */
     const bool active = lane < nR;
     const int row_id = active ? lane : 0;
-    float J[16], B[16], bias, hi = 0.f;
+    float B[16], bias, hi = 0.f, Jh = 0.f, Ja = 0.f;
     int frn = -1;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) J[k] = 0.f;
     if (nR == 0) { /* no rows this substep (wave-uniform): still define every register */
 #pragma unroll
-        for (int k = 0; k < 16; ++k) g.J[k] = 0.f;
+        for (int k = 0; k < 6; ++k) g.Jb[k] = 0.f;
+        g.Jh = 0.f; g.Ja = 0.f; g.jslot = 6;
         g.bias = 0.f; g.fn = -1; g.lam = 0.f; g.lo = 0.f; g.hi = 0.f;
         return;
     }
@@ -591,9 +592,8 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
     if (row_id < nL) {
         const int j = L.ljoint[row_id];
         const float sgn = L.lsign[row_id], dist = L.ldist[row_id];
-#pragma unroll
-        for (int k = 0; k < NJ; ++k) J[6 + k] = (k == j) ? sgn : 0.f;
         leg = j >> 1; th = (j & 1) ? 0.f : sgn; ta = (j & 1) ? sgn : 0.f;
+        Jh = th; Ja = ta; /* J = +-e_j */
         bias = (dist > 0.f ? dist : c.erp_l * dist) * c.inv_h;
         hi = c.limp_max;
     } else {
@@ -609,14 +609,8 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
 #pragma unroll
         for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
         level = L.clink[ci] & 3; leg = L.clink[ci] >> 2;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) J[k] = phi[k];
         const float jh = dot6(phi, L.S[2 * leg]), ja = dot6(phi, L.S[2 * leg + 1]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            J[6 + 2 * k] = (k == leg && level >= 1) ? jh : 0.f;
-            J[7 + 2 * k] = (k == leg && level >= 2) ? ja : 0.f;
-        }
+        Jh = level >= 1 ? jh : 0.f; Ja = level >= 2 ? ja : 0.f; /* J = [phi | phi.S on the joints between torso and body] */
         if (which == 0) {
             const float dist = L.cdist_[ci];
             bias = (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h;
@@ -625,7 +619,8 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
     }
     response(L, phi, level, leg, th, ta, B);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) g.J[k] = J[k];
+    for (int k = 0; k < 6; ++k) g.Jb[k] = phi[k]; /* zero for limit rows */
+    g.Jh = Jh; g.Ja = Ja; g.jslot = 6 + 2 * leg;
     if (active) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) L.Bt[lane][k] = B[k];
@@ -641,9 +636,12 @@ template <int R>
 HRL_DEV void build_A_row(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag) {
     /* one entry: A[lane][R] = J_lane . B_R; computed unconditionally inside its group (rows >= nR read stale LDS and
      * are replaced by 0), so that the four fma chains of a group are independent instruction streams */
-    float a = g.J[0] * L.Bt[R][0];
+    /* the 16-slot fma chain with its exact zeros left out: the torso part, then the row's two joint slots in order */
+    float a = g.Jb[0] * L.Bt[R][0];
 #pragma unroll
-    for (int d = 1; d < 16; ++d) a = fma_(g.J[d], L.Bt[R][d], a);
+    for (int d = 1; d < 6; ++d) a = fma_(g.Jb[d], L.Bt[R][d], a);
+    a = fma_(g.Jh, L.Bt[R][g.jslot], a);
+    a = fma_(g.Ja, L.Bt[R][g.jslot + 1], a);
     a = (R < nR) ? a : 0.f;
     diag = (R == lane && R < nR) ? a : diag;
     g.A[R] = a;
@@ -669,9 +667,11 @@ HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nR) {
     static_assert(MAXR % 4 == 0, "rows are built in groups of four");
     build_A_rows(L, g, lane, nR, diag, std::make_integer_sequence<int, MAXR / 4>{});
     g.invd = 1.f / diag;
-    float wi = g.J[0] * L.ustar[0];
+    float wi = g.Jb[0] * L.ustar[0];
 #pragma unroll
-    for (int d = 1; d < 16; ++d) wi = fma_(g.J[d], L.ustar[d], wi);
+    for (int d = 1; d < 6; ++d) wi = fma_(g.Jb[d], L.ustar[d], wi);
+    wi = fma_(g.Jh, L.ustar[g.jslot], wi);
+    wi = fma_(g.Ja, L.ustar[g.jslot + 1], wi);
     g.w = wi;
 }
 
@@ -903,18 +903,21 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
         LaneRegs &g = x.reg(lane);
         const int ci = lane < nC ? lane : (lane - nC) >> 1, which = lane < nC ? 0 : 1 + ((lane - nC) & 1);
         float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
-        float t1[3], t2[3], d[3], J[16], B[16];
+        float t1[3], t2[3], d[3], J[6], B[16];
         tangent_basis(n, t1, t2);
 #pragma unroll
         for (int k = 0; k < 3; ++k) d[k] = which == 0 ? n[k] : (which == 1 ? t1[k] : t2[k]);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { J[k] = 0.f; B[k] = 0.f; }
+        for (int k = 0; k < 16; ++k) B[k] = 0.f;
         cross3(J, r, d);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { J[3 + k] = d[k]; B[k] = J[k] / I; B[3 + k] = d[k] / m; }
         const float dist = L.cdist_[ci];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { g.J[k] = J[k]; L.Bt[lane][k] = B[k]; }
+        for (int k = 0; k < 6; ++k) g.Jb[k] = J[k];
+        g.Jh = 0.f; g.Ja = 0.f; g.jslot = 6;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) L.Bt[lane][k] = B[k];
         g.bias = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h : 0.f;
         g.fn = which == 0 ? -1 : ci; g.lam = 0.f; g.lo = 0.f; g.hi = which == 0 ? 1e30f : 0.f;
     });
