@@ -7,7 +7,8 @@
  *   wall sensor / target obs / sparse reward                      ant_maze_bullet_env.py:63-97,
  *                                                                 sizeable_enclosed_scene.py:63-97, intersection_utils.py:74-104
  *   PointBot force + state                                        point_bot.py:28-31,48-67
- *   raw-state obs + locomotion reward                             MjAnt.py:17-25,36-97
+ *   raw-state obs + locomotion reward                             MjAnt.py:17-25,36-97, ant_maze_mj_env.py:57-78
+ *   goal chasing (reward, retarget, timeout)                      ant_flagrun_env.py:162-204
  * written as a sequence of wave-wide PHASES.  A phase is a function of (lane, LDS); lanes communicate only
  * through the per-wave LDS record `WaveLds` between phases (plus three wave primitives supplied by the executor:
  * a ballot/prefix compaction, a lane broadcast and per-lane persistent registers).  The executor `X`
@@ -18,7 +19,8 @@
  * Lane maps used by the phases:
  *   leg map : leg = lane >> 4 (four 16-lane rows, one per leg; the 16 lanes of a row compute the same values)
  *   dof map : dof = lane & 15 (0-2 omega, 3-5 v, 6-13 joint rates, 14-15 zero padding)
- *   row map : lane = constraint row (limits, contact normals, friction pairs; <= 48 rows)
+ *   sphere map: lane = contact sphere x lateral surface (ballot-compacted into contacts)
+ *   row map : lane = constraint row (limits, contact normals, friction pairs; <= 44 rows), its solver state in registers
  *   item map: lane = food/poison slot (<= 16);  bin map: lane = sensor bin
  *
  * Numerics: fp32 throughout.  The algorithm is the build's own specification of the
@@ -36,9 +38,8 @@
 #define HRL_PIN_INT(x) ((void)0)
 #else
 #define HRL_DEV __device__ __forceinline__
-/* Materialise a wave-uniform value in a VGPR here.  Used before the solver loop: a constant that is still an
- * outstanding scalar load inside the loop makes hipcc wait on lgkmcnt(0) there, which also drains the loop's LDS
- * prefetches (scalar loads and LDS share that counter). */
+/* Materialise a wave-uniform value in a register at this point (and make it opaque to the optimizer): keeps
+ * scalar loads of constants out of the solver loop, and keeps run-time what must not be specialised at compile time. */
 #define HRL_PIN_VGPR(x) asm volatile("" : "+v"(x))
 #define HRL_PIN_INT(x) asm volatile("" : "+s"(x))
 #endif
@@ -48,7 +49,6 @@ namespace hrl {
 constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (assets/ant.xml:18-54) */
 constexpr int MAXC = 12;  /* contacts kept per substep */
 constexpr int MAXR = 44;  /* constraint rows per substep: 8 limits + 12 * (normal + 2 friction) */
-
 
 /* Everything the kernels need from hrl_config, plus constants derived from it on the host (host_cfg.h). */
 struct DevCfg {
@@ -88,10 +88,9 @@ struct DevBufs {
     unsigned long long *stamps; /* diagnostic builds only (tools/stamp_profile.py): per-phase cycle sums */
 };
 
-/* Per-wave LDS record ("LDS-staged link/joint state").  Two overlays keep it under 10 KB so that 16 waves fit a CU:
- * the task scratch (observation packing, after the substeps) shares storage with the solver's J/B table, and the
- * per-leg articulated inertias handed to the base (phase K -> phase B) share storage with the row parameters
- * (written later, in phase R). */
+/* Per-wave LDS record ("LDS-staged link/joint state"), 5.9 KB.  Three users with disjoint lifetimes share the first
+ * block: the K1 -> K2 hand-off of a substep, the velocity responses B of the solver rows (written in phase R1, read
+ * until the end of the substep) and the task scratch of the epilogue (observation packing, after the substeps). */
 struct WaveLds {
     union {
         float Bt[MAXR][16];      /* B[r][d] = (M^-1 J_r^T)[d]: velocity response of every solver row */
@@ -134,8 +133,8 @@ struct WaveLds {
     int gtouch[16];
 };
 
-/* Per-lane registers that live across phases (the solver's working set):
- * (the solver's working set; on the GPU these are VGPRs, the row-space solver never touches LDS in its sweeps) */
+/* Per-lane registers that live across phases: the solver's working set.  On the GPU these are VGPRs (the row-space
+ * solver never touches LDS in its sweeps); every field is fully redefined in every substep. */
 struct LaneRegs {
     float ud;                        /* dof map: the lane's velocity component */
     float Jb[6], Jh, Ja;             /* row map: the row's Jacobian, sparse: torso twist part + the hip / ankle entries */
@@ -144,7 +143,7 @@ struct LaneRegs {
     float w, lam, bias, invd, lo, hi; /* row map: constraint velocity, impulse, bias, 1/A_ii, bounds */
     int fn;                          /* row map: friction rows: index of their normal row, else -1 */
 };
-struct F2b { float ln, dl; };
+struct F2b { float ln, dl; }; /* a row's new impulse and its change, broadcast from the row's lane */
 
 /* ------------------------------------------------------------------------------------------------ small math */
 /* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
