@@ -152,3 +152,23 @@ def test_product_defaults_equal_oracle_defaults():
         a = K.hrl_config(); emu_env.lib().emu_default_config(kind, C.byref(a))
         assert bytes(a) == bytes(orc.default_config(kind))
         assert emu_env.lib().emu_obs_dim(C.byref(a)) == orc.obs_dim(a) == {0: 29, 1: 46, 2: 38, 3: 18, 4: 60, 5: 28}[kind]
+
+
+@pytest.mark.parametrize('kind,n,kw', [
+    (K.HRL_ANT_GATHER, 5, dict(n_bins=7, n_food=5, n_poison=3, sensor_range=9.0, sensor_span=2.0, world_size=(9.0, 11.0))),
+    (K.HRL_ANT_GATHER, 4, dict(respawn=0, robot_coll_dist=4.0, dying_cost=-3.0)),
+    (K.HRL_ANT_MAZE, 6, dict(sense_target=1, n_bins=8)),
+    (K.HRL_ANT_MAZE, 5, dict(target_encoding=1, sense_walls=0, tol=3.0, targ_dist_rew=1, max_steps=20, done_at_target=0)),
+    (K.HRL_ANT_MAZE_MJ, 4, dict(inner_rew_weight=0.5, n_bins=6)),
+    (K.HRL_ANT_GATHER, 3, dict(model_solver_iters=2, model_frame_skip=2, model_limit_margin=0.1)),
+])
+def test_non_default_configs_bit_exact(kind, n, kw):
+    cfg = orc.default_config(kind, num_envs=n, seed=17, auto_reset=1, max_episode_steps=25, **kw)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    rng = np.random.RandomState(4)
+    for t in range(60):
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        o.step(a); e.step(a)
+        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
+            assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, name)

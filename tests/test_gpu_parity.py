@@ -202,3 +202,35 @@ def test_determinism_on_device():
         torch.cuda.synchronize()
         outs.append((g.state.clone(), g.items.clone(), g.obs.clone()))
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+CONFIG_MATRIX = [
+    (K.HRL_ANT_GATHER, 37, dict(n_bins=7, n_food=5, n_poison=3, sensor_range=9.0, sensor_span=2.0, world_size=(9.0, 11.0), centroid_static_sum=(-4.5, 0.0))),
+    (K.HRL_ANT_GATHER, 64, dict(respawn=0, robot_coll_dist=4.0, dying_cost=-3.0)),
+    (K.HRL_ANT_GATHER, 33, dict(use_sensor=0)),
+    (K.HRL_POINT_GATHER, 50, dict(n_bins=9, robot_object_spacing=3.0)),
+    (K.HRL_ANT_MAZE, 65, dict(sense_target=1, n_bins=8)),
+    (K.HRL_ANT_MAZE, 31, dict(target_encoding=1, sense_walls=0, tol=3.0, targ_dist_rew=1, max_steps=20, done_at_target=0)),
+    (K.HRL_ANT_MAZE_MJ, 40, dict(inner_rew_weight=0.5, n_bins=6)),
+    (K.HRL_ANT_FLAGRUN, 48, dict(use_sensor=1, n_bins=8, flag_timeout=9, flag_max_targets=3)),
+    (K.HRL_ANT_FLAT, 1, dict()),
+    (K.HRL_ANT_GATHER, 3, dict(model_solver_iters=2, model_frame_skip=2, model_limit_margin=0.1)),
+]
+
+
+@pytest.mark.parametrize('kind,n,kw', CONFIG_MATRIX)
+def test_non_default_configs_match_oracle(kind, n, kw):
+    """Non-default constructor branches and odd batch sizes, free-running for 60 steps."""
+    g, o = make(kind, n, seed=17, max_episode_steps=25, **kw)
+    g.reset(); o.reset()
+    assert np.array_equal(g.state.cpu().numpy(), o.state) and obs_bad_rows(g.obs.cpu().numpy(), o.obs).sum() == 0
+    rng = np.random.RandomState(4)
+    flips = 0
+    for t in range(60):
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
+        flips += int(obs_bad_rows(go.cpu().numpy(), o.obs).sum())
+    assert flips <= 1
+    assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux)
