@@ -57,8 +57,9 @@ def cpu_baseline(kind, seconds_budget=15.0):
         ncpu = os.cpu_count() or 1
     ncpu = max(1, min(ncpu, 16))  # the GPU box gives one GPU's job a 16-core share
     cfg_n = orc.default_config(KINDS[kind], num_envs=4096, seed=0, auto_reset=1)
-    dtn = L.orc_bench_f32(C.byref(cfg_n), 4, ncpu, C.byref(cs))
-    nsteps = max(4, int(4 / dtn * 5.0))
+    L.orc_bench_f32(C.byref(cfg_n), 2, ncpu, C.byref(cs))  # start the OpenMP team
+    dtn = L.orc_bench_f32(C.byref(cfg_n), 40, ncpu, C.byref(cs))  # calibrate
+    nsteps = max(40, int(40 / dtn * 6.0))
     dtn = L.orc_bench_f32(C.byref(cfg_n), nsteps, ncpu, C.byref(cs))
     out['all_cores'] = {'value': 4096 * nsteps / dtn, 'cores': ncpu,
                         'sample': f'same oracle, 4096 envs x {nsteps} steps, OpenMP over {ncpu} threads, {dtn:.1f} s'}
