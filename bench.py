@@ -63,7 +63,30 @@ def cpu_baseline(kind, seconds_budget=15.0):
     dtn = L.orc_bench_f32(C.byref(cfg_n), nsteps, ncpu, C.byref(cs))
     out['all_cores'] = {'value': 4096 * nsteps / dtn, 'cores': ncpu,
                         'sample': f'same oracle, 4096 envs x {nsteps} steps, OpenMP over {ncpu} threads, {dtn:.1f} s'}
+    out['reference'] = reference_probe()
     return out
+
+
+def reference_probe():
+    """the pybullet reference's README loop can only be timed where pybullet, gym and the reference
+    package are importable; that is never the case on the build/GPU images (no network), so this reports why not."""
+    missing = []
+    for mod in ('gym', 'pybullet', 'pybullet_envs', 'hrl_pybullet_envs'):
+        try:
+            __import__(mod)
+        except Exception as e:  # noqa: BLE001
+            missing.append(f'{mod} ({type(e).__name__})')
+    if missing:
+        return 'unavailable on this box: ' + ', '.join(missing)
+    import gym  # pragma: no cover
+    import numpy as np  # pragma: no cover
+    env = gym.make('AntGatherBulletEnv-v0'); env.seed(0); env.reset()  # README.md:24-34  # pragma: no cover
+    t0, n = time.perf_counter(), 0  # pragma: no cover
+    for _ in range(1000):  # pragma: no cover
+        _, _, d, _ = env.step(np.random.uniform(-1, 1, 8)); n += 1
+        if d:
+            env.reset()
+    return {'value': n / (time.perf_counter() - t0), 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference'}  # pragma: no cover
 
 
 def profiled_traffic(kind, n):
