@@ -69,14 +69,17 @@ struct GpuExec {
         __syncthreads();
         return __popcll(m);
     }
-    /* every lane produces a pair, lane `src`'s pair is broadcast to the wave (two v_readlane_b32) */
+    /* every lane produces a candidate pair; the change `dl` of lane `src` is broadcast to the wave (v_readlane_b32) */
     template <class P, class C>
     __device__ __forceinline__ void each_bcast(int src, P produce, C consume) {
         const F2b v = produce(lane);
-        F2b b;
-        b.ln = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.ln), src));
-        b.dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.dl), src));
-        consume(lane, b);
+        consume(lane, v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.dl), src)));
+    }
+    /* every lane fetches the value of the lane it names (ds_bpermute_b32: LDS crossbar, no memory) */
+    template <class V, class I, class C>
+    __device__ __forceinline__ void each_shuffle(V value, I index, C consume) {
+        const float v = value(lane);
+        consume(lane, __int_as_float(__builtin_amdgcn_ds_bpermute(index(lane) << 2, __float_as_int(v))));
     }
 };
 

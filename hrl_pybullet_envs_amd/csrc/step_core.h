@@ -49,6 +49,9 @@ namespace hrl {
 constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (assets/ant.xml:18-54) */
 constexpr int MAXC = 12;  /* contacts kept per substep */
 constexpr int MAXR = 44;  /* constraint rows per substep: 8 limits + 12 * (normal + 2 friction) */
+constexpr int MAXB = NJ + MAXC; /* bounded rows that come first in the sweep order: joint limits, then contact normals */
+constexpr int MAXF = 2 * MAXC;  /* friction rows, a pair per contact, after all the normals */
+static_assert(MAXB + MAXF == MAXR && MAXB % 4 == 0 && MAXF % 4 == 0, "row blocks are built in groups of four");
 
 /* Everything the kernels need from hrl_config, plus constants derived from it on the host (host_cfg.h). */
 struct DevCfg {
@@ -93,7 +96,8 @@ struct DevBufs {
  * until the end of the substep) and the task scratch of the epilogue (observation packing, after the substeps). */
 struct WaveLds {
     union {
-        float Bt[MAXR][16];      /* B[r][d] = (M^-1 J_r^T)[d]: velocity response of every solver row */
+        float Bt[MAXR + 2][16];  /* B[r][d] = (M^-1 J_r^T)[d]: velocity response of every solver row (+2: the last
+                                    group of four friction columns may read two rows past the end, values unused) */
         struct {                 /* phase K1 -> K2 hand-off (dead before the rows are built) */
             float Iaf[4][24];    /* articulated inertia of the foot seen through the ankle (upper triangle) */
             float paf[4][8];     /* its bias force */
@@ -139,11 +143,11 @@ struct LaneRegs {
     float ud;                        /* dof map: the lane's velocity component */
     float Jb[6], Jh, Ja;             /* row map: the row's Jacobian, sparse: torso twist part + the hip / ankle entries */
     int jslot;                       /* row map: dof slot of Jh (Ja is the next slot): 6 + 2 * leg                   */
-    float A[MAXR];                   /* row map: the row's line of A = J M^-1 J^T                                    */
-    float w, lam, bias, invd, lo, hi; /* row map: constraint velocity, impulse, bias, 1/A_ii, bounds */
+    float An[MAXB], Af[MAXF];        /* row map: the row's line of A = J M^-1 J^T: limit/normal columns, friction columns */
+    float w, lam, bias, invd, lo, hi; /* row map: constraint velocity (bias included), impulse, bias, 1/A_ii, bounds */
     int fn;                          /* row map: friction rows: index of their normal row, else -1 */
 };
-struct F2b { float ln, dl; }; /* a row's new impulse and its change, broadcast from the row's lane */
+struct F2b { float ln, dl; }; /* a row's candidate impulse and its change; the change of the row being solved is broadcast */
 
 /* ------------------------------------------------------------------------------------------------ small math */
 /* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
@@ -628,50 +632,49 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
 }
 
 /* Phase R2 (row map): the row's line of A = J M^-1 J^T (A[i][r] = J_i . B_r), 1/A_ii and the initial constraint
- * velocity w_i = J_i . u*.  Sequential fma chains over the 16 dof slots; B_r and u* are LDS broadcast reads.
- * The row index is a template parameter (pack expansion over 0..MAXR-1) so that A[] is statically indexed: a runtime
- * index would push the array out of registers into scratch memory. */
-template <int R>
-HRL_DEV void build_A_row(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag) {
-    /* one entry: A[lane][R] = J_lane . B_R; computed unconditionally inside its group (rows >= nR read stale LDS and
-     * are replaced by 0), so that the four fma chains of a group are independent instruction streams */
-    /* the 16-slot fma chain with its exact zeros left out: the torso part, then the row's two joint slots in order */
-    float a = g.Jb[0] * L.Bt[R][0];
+ * velocity w_i = J_i . u* + bias_i.  Sequential fma chains over the 16 dof slots with their exact zeros left out (the
+ * torso part, then the row's two joint slots in order); B_r and u* are LDS reads.
+ * The line is kept in two register arrays, split where the sweep order changes kind: An[r] for the limit and normal
+ * rows r < nB, Af[k] for the friction rows nB + k.  Both are indexed by template parameters (pack expansion) so that
+ * they stay in registers: a runtime index would push them out into scratch memory. */
+HRL_DEV float row_dot(const LaneRegs &g, const float *Brow) {
+    float a = g.Jb[0] * Brow[0];
 #pragma unroll
-    for (int d = 1; d < 6; ++d) a = fma_(g.Jb[d], L.Bt[R][d], a);
-    a = fma_(g.Jh, L.Bt[R][g.jslot], a);
-    a = fma_(g.Ja, L.Bt[R][g.jslot + 1], a);
-    a = (R < nR) ? a : 0.f;
-    diag = (R == lane && R < nR) ? a : diag;
-    g.A[R] = a;
+    for (int d = 1; d < 6; ++d) a = fma_(g.Jb[d], Brow[d], a);
+    a = fma_(g.Jh, Brow[g.jslot], a);
+    return fma_(g.Ja, Brow[g.jslot + 1], a);
 }
+/* columns 4G..4G+3 of a block behind one wave-uniform test (flat sequence of groups, no nesting).  Columns past the
+ * block's end inside its last group are computed from whatever LDS holds and never read by the sweeps. */
 template <int G>
-HRL_DEV void build_A_group(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag) {
-    /* rows 4G..4G+3 behind one wave-uniform test (flat sequence of groups, no nesting) */
-    if (4 * G < nR) {
-        build_A_row<4 * G>(L, g, lane, nR, diag);
-        build_A_row<4 * G + 1>(L, g, lane, nR, diag);
-        build_A_row<4 * G + 2>(L, g, lane, nR, diag);
-        build_A_row<4 * G + 3>(L, g, lane, nR, diag);
+HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB) {
+    if (4 * G < nB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = row_dot(g, L.Bt[4 * G + i]);
     } else {
-        g.A[4 * G] = 0.f; g.A[4 * G + 1] = 0.f; g.A[4 * G + 2] = 0.f; g.A[4 * G + 3] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = 0.f;
     }
 }
-template <int... Gs>
-HRL_DEV void build_A_rows(const WaveLds &L, LaneRegs &g, int lane, int nR, float &diag, std::integer_sequence<int, Gs...>) {
-    (build_A_group<Gs>(L, g, lane, nR, diag), ...);
-}
-HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nR) {
-    float diag = 1.f;
-    static_assert(MAXR % 4 == 0, "rows are built in groups of four");
-    build_A_rows(L, g, lane, nR, diag, std::make_integer_sequence<int, MAXR / 4>{});
-    g.invd = 1.f / diag;
-    float wi = g.Jb[0] * L.ustar[0];
+template <int G>
+HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF) {
+    if (4 * G < nF) {
 #pragma unroll
-    for (int d = 1; d < 6; ++d) wi = fma_(g.Jb[d], L.ustar[d], wi);
-    wi = fma_(g.Jh, L.ustar[g.jslot], wi);
-    wi = fma_(g.Ja, L.ustar[g.jslot + 1], wi);
-    g.w = wi;
+        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = row_dot(g, L.Bt[nB + 4 * G + i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = 0.f;
+    }
+}
+template <int... Gn, int... Gf>
+HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, std::integer_sequence<int, Gn...>, std::integer_sequence<int, Gf...>) {
+    (build_An_group<Gn>(L, g, nB), ...);
+    (build_Af_group<Gf>(L, g, nB, nF), ...);
+}
+HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF) {
+    build_A_blocks(L, g, nB, nF, std::make_integer_sequence<int, MAXB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
+    g.invd = 1.f / row_dot(g, L.Bt[lane < nB + nF ? lane : 0]); /* A_ii; idle lanes carry row 0's registers */
+    g.w = row_dot(g, L.ustar) + g.bias;
 }
 
 /* Phase I (uniform): clamp joint rates was done in the dof map; integrate positions */
@@ -703,51 +706,69 @@ HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float 
     if (lane < 16) qn[lane] = mine;
 }
 
-/* Projected Gauss-Seidel in ROW SPACE: lane i owns solver row i -- its constraint velocity w_i,
- * impulse, bounds and its row of A -- all in registers.  Updating row r: lane r's candidate impulse is broadcast with a
- * lane read, every lane applies w_i += A[i][r] * dl, and the friction rows of a just-updated normal row refresh
- * their bounds.  No LDS and no cross-lane reduction on the solver's dependent chain.  Rows run in order (limits,
- * normals, friction pairs), c.iters sweeps; the velocity is reconstructed once at the end from the impulses. */
+/* Projected Gauss-Seidel in ROW SPACE: lane i owns solver row i -- its constraint velocity w_i (bias
+ * included), impulse, bounds and its row of A -- all in registers.  Solving row r: every lane forms the candidate
+ * impulse of its own row, lane r's change is broadcast with a lane read and every lane applies w_i += A[i][r] * dl.
+ * No LDS and no cross-lane reduction on the solver's dependent chain.  Rows run in order (limits, normals, then the
+ * friction pairs); the friction rows take their bounds +-mu * (normal impulse) from their normal's lane once per
+ * sweep, after the last normal row, which is exactly when a row-by-row update would have last changed them.
+ * c.iters sweeps; the velocity is reconstructed once at the end from the impulses. */
+HRL_DEV F2b pgs_candidate(const LaneRegs &g) {
+    F2b o;
+    o.ln = med3_spec(fma_(-g.w, g.invd, g.lam), g.lo, g.hi);
+    o.dl = o.ln - g.lam;
+    return o;
+}
 template <int R, class X>
-HRL_DEV bool pgs_row(X &x, float mu, int nR) { /* update of solver row R (compile-time index: A[R] is a register) */
-    if (R >= nR) return false; /* wave-uniform: ends the sweep (the fold below short-circuits) */
-    {
-        x.each_bcast(
-            R,
-            [&](int lane) {
-                const LaneRegs &g = x.reg(lane);
-                F2b o;
-                o.ln = med3_spec(fma_(-(g.w + g.bias), g.invd, g.lam), g.lo, g.hi);
-                o.dl = o.ln - g.lam;
-                return o;
-            },
-            [&](int lane, const F2b &b) {
-                LaneRegs &g = x.reg(lane);
-                g.w = fma_(g.A[R], b.dl, g.w);
-                if (lane == R) g.lam = b.ln;
-                if (g.fn == R) { g.hi = mu * b.ln; g.lo = -g.hi; }
-            });
-    }
+HRL_DEV bool pgs_row_bounded(X &x, int nB) { /* limit or normal row R (compile-time index: An[R] is a register) */
+    if (R >= nB) return false; /* wave-uniform: ends the block (the fold below short-circuits) */
+    x.each_bcast(
+        R, [&](int lane) { return pgs_candidate(x.reg(lane)); },
+        [&](int lane, const F2b &own, float dl) {
+            LaneRegs &g = x.reg(lane);
+            g.w = fma_(g.An[R], dl, g.w);
+            if (lane == R) g.lam = own.ln;
+        });
     return true;
 }
-template <class X, int... Rs>
-HRL_DEV void pgs_sweep(X &x, float mu, int nR, std::integer_sequence<int, Rs...>) {
-    /* rows in order as a flat sequence with one forward exit (no nesting: 44 nested wave-uniform ifs cost an SGPR pair each) */
-    (void)(pgs_row<Rs>(x, mu, nR) && ...);
+template <int K, class X>
+HRL_DEV bool pgs_row_friction(X &x, int nB, int nF) { /* friction row nB + K */
+    if (K >= nF) return false;
+    x.each_bcast(
+        nB + K, [&](int lane) { return pgs_candidate(x.reg(lane)); },
+        [&](int lane, const F2b &own, float dl) {
+            LaneRegs &g = x.reg(lane);
+            g.w = fma_(g.Af[K], dl, g.w);
+            if (lane == nB + K) g.lam = own.ln;
+        });
+    return true;
+}
+template <class X, int... Rs, int... Ks>
+HRL_DEV void pgs_sweep(X &x, float mu, int nB, int nF, std::integer_sequence<int, Rs...>, std::integer_sequence<int, Ks...>) {
+    /* rows in order as flat sequences with one forward exit each (no nesting: nested wave-uniform ifs cost an SGPR pair each) */
+    (void)(pgs_row_bounded<Rs>(x, nB) && ...);
+    if (nF <= 0) return;
+    x.each_shuffle([&](int lane) { return x.reg(lane).lam; },
+                   [&](int lane) { const int fn = x.reg(lane).fn; return fn >= 0 ? fn : lane; },
+                   [&](int lane, float ln) {
+                       LaneRegs &g = x.reg(lane);
+                       if (g.fn >= 0) { g.hi = mu * ln; g.lo = -g.hi; }
+                   });
+    (void)(pgs_row_friction<Ks>(x, nB, nF) && ...);
 }
 template <class X>
 HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
     WaveLds &L = x.lds();
-    const int nR = ant ? nL + 3 * nC : 3 * nC;
+    const int nB = ant ? nL + nC : nC, nF = 2 * nC, nR = nB + nF;
     if (nR <= 0) return;
-    x.each([&](int lane) { phase_build_A(L, x.reg(lane), lane, nR); });
+    x.each([&](int lane) { phase_build_A(L, x.reg(lane), lane, nB, nF); });
     x.stamp(8);
     float mu = c.mu;
     const int iters = c.iters;
     HRL_PIN_VGPR(mu);
     for (int it = 0; it < iters; ++it) {
         x.refresh();
-        pgs_sweep(x, mu, nR, std::make_integer_sequence<int, MAXR>{});
+        pgs_sweep(x, mu, nB, nF, std::make_integer_sequence<int, MAXB>{}, std::make_integer_sequence<int, MAXF>{});
     }
     x.stamp(9);
     x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });
@@ -898,8 +919,9 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
         if (nC > MAXC) nC = MAXC;
     }
     x.each([&](int lane) { /* row map */
-        if (lane >= 3 * nC) return;
         LaneRegs &g = x.reg(lane);
+        g.fn = -1;
+        if (lane >= 3 * nC) return;
         const int ci = lane < nC ? lane : (lane - nC) >> 1, which = lane < nC ? 0 : 1 + ((lane - nC) & 1);
         float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
         float t1[3], t2[3], d[3], J[6], B[16];

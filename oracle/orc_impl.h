@@ -740,11 +740,12 @@ static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, 
         invd[i] = R_(1) / A[i][i];
         REAL wi = J[i][0] * un[0];
         for (int d = 1; d < 16; ++d) wi = FMA_(J[i][d], un[d], wi);
-        w[i] = wi; lam[i] = 0; lo[i] = 0; hi[i] = frn[i] >= 0 ? R_(0) : hic[i];
+        w[i] = wi + bias[i]; /* w carries the row's bias: w_i = J_i u + b_i, the quantity the row drives to >= 0 */
+        lam[i] = 0; lo[i] = 0; hi[i] = frn[i] >= 0 ? R_(0) : hic[i];
     }
     for (int it = 0; it < iters; ++it)
         for (int r = 0; r < nr; ++r) {
-            REAL ln = FN(med3)(FMA_(-(w[r] + bias[r]), invd[r], lam[r]), lo[r], hi[r]);
+            REAL ln = FN(med3)(FMA_(-w[r], invd[r], lam[r]), lo[r], hi[r]);
             REAL dl = ln - lam[r];
             lam[r] = ln;
             for (int i = 0; i < nr; ++i) {

@@ -41,8 +41,15 @@ struct CpuExec {
         F2b v[64];
         if (!reverse) for (int lane = 0; lane < 64; ++lane) v[lane] = produce(lane);
         else for (int lane = 63; lane >= 0; --lane) v[lane] = produce(lane);
-        if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, v[src]);
-        else for (int lane = 63; lane >= 0; --lane) consume(lane, v[src]);
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, v[lane], v[src].dl);
+        else for (int lane = 63; lane >= 0; --lane) consume(lane, v[lane], v[src].dl);
+    }
+    template <class V, class I, class C> void each_shuffle(V value, I index, C consume) {
+        float v[64];
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) v[lane] = value(lane);
+        else for (int lane = 63; lane >= 0; --lane) v[lane] = value(lane);
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, v[index(lane) & 63]);
+        else for (int lane = 63; lane >= 0; --lane) consume(lane, v[index(lane) & 63]);
     }
 };
 
