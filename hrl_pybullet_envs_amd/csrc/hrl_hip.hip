@@ -34,6 +34,8 @@ struct GpuExec {
      * lane-derived value of the unrolled solver (44 `lane == r` masks, LDS addresses, ...) is loop-invariant, gets
      * hoisted to the top of the kernel and is spilled to scratch for the whole substep loop. */
     __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(lane), "+v"(r.fn)); }
+    /* same for a wave-uniform value: comparisons against it are redone (one s_cmp each) after this point */
+    __device__ __forceinline__ void refresh_uniform(int &v) { asm volatile("" : "+s"(v)); }
 #ifdef HRL_STAMPS
     /* diagnostic build (never shipped): cycles between phase boundaries, summed per phase id; stamp id = the phase
      * that just ENDED.  s_memtime + lgkmcnt(0) as one statement (cdna_hip_programming.md, In-kernel stamps). */
@@ -69,11 +71,15 @@ struct GpuExec {
         __syncthreads();
         return __popcll(m);
     }
-    /* every lane produces a candidate pair; the change `dl` of lane `src` is broadcast to the wave (v_readlane_b32) */
+    /* solver row `src` (wave-uniform): every lane produces the candidate {impulse, change} of its own row; lane `src`
+     * keeps its candidate impulse (v_cndmask on a scalar lane mask) and its change is broadcast to the wave
+     * (v_readlane_b32) for every lane to apply */
     template <class P, class C>
-    __device__ __forceinline__ void each_bcast(int src, P produce, C consume) {
+    __device__ __forceinline__ void each_row(int src, P produce, C apply) {
         const F2b v = produce(lane);
-        consume(lane, v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.dl), src)));
+        const unsigned long long owner = 1ull << src;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r.lam) : "v"(r.lam), "v"(v.ln), "s"(owner));
+        apply(lane, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.dl), src)));
     }
     /* every lane fetches the value of the lane it names (ds_bpermute_b32: LDS crossbar, no memory) */
     template <class V, class I, class C>

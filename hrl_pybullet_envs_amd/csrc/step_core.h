@@ -708,7 +708,8 @@ HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float 
 
 /* Projected Gauss-Seidel in ROW SPACE: lane i owns solver row i -- its constraint velocity w_i (bias
  * included), impulse, bounds and its row of A -- all in registers.  Solving row r: every lane forms the candidate
- * impulse of its own row, lane r's change is broadcast with a lane read and every lane applies w_i += A[i][r] * dl.
+ * impulse of its own row, lane r keeps its candidate, its change is broadcast with a lane read and every lane applies
+ * w_i += A[i][r] * dl (one executor primitive, each_row).
  * No LDS and no cross-lane reduction on the solver's dependent chain.  Rows run in order (limits, normals, then the
  * friction pairs); the friction rows take their bounds +-mu * (normal impulse) from their normal's lane once per
  * sweep, after the last normal row, which is exactly when a row-by-row update would have last changed them.
@@ -722,25 +723,15 @@ HRL_DEV F2b pgs_candidate(const LaneRegs &g) {
 template <int R, class X>
 HRL_DEV bool pgs_row_bounded(X &x, int nB) { /* limit or normal row R (compile-time index: An[R] is a register) */
     if (R >= nB) return false; /* wave-uniform: ends the block (the fold below short-circuits) */
-    x.each_bcast(
-        R, [&](int lane) { return pgs_candidate(x.reg(lane)); },
-        [&](int lane, const F2b &own, float dl) {
-            LaneRegs &g = x.reg(lane);
-            g.w = fma_(g.An[R], dl, g.w);
-            if (lane == R) g.lam = own.ln;
-        });
+    x.each_row(R, [&](int lane) { return pgs_candidate(x.reg(lane)); },
+               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.w = fma_(g.An[R], dl, g.w); });
     return true;
 }
 template <int K, class X>
 HRL_DEV bool pgs_row_friction(X &x, int nB, int nF) { /* friction row nB + K */
     if (K >= nF) return false;
-    x.each_bcast(
-        nB + K, [&](int lane) { return pgs_candidate(x.reg(lane)); },
-        [&](int lane, const F2b &own, float dl) {
-            LaneRegs &g = x.reg(lane);
-            g.w = fma_(g.Af[K], dl, g.w);
-            if (lane == nB + K) g.lam = own.ln;
-        });
+    x.each_row(nB + K, [&](int lane) { return pgs_candidate(x.reg(lane)); },
+               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.w = fma_(g.Af[K], dl, g.w); });
     return true;
 }
 template <class X, int... Rs, int... Ks>
@@ -767,8 +758,11 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
     const int iters = c.iters;
     HRL_PIN_VGPR(mu);
     for (int it = 0; it < iters; ++it) {
+        int nb = nB, nf = nF;
         x.refresh();
-        pgs_sweep(x, mu, nB, nF, std::make_integer_sequence<int, MAXB>{}, std::make_integer_sequence<int, MAXF>{});
+        x.refresh_uniform(nb); /* keeps the 44 row-count tests inside the sweep as scalar compares (hoisted out of */
+        x.refresh_uniform(nf); /* the loop they become 44 live lane-mask pairs, most of them spilled)             */
+        pgs_sweep(x, mu, nb, nf, std::make_integer_sequence<int, MAXB>{}, std::make_integer_sequence<int, MAXF>{});
     }
     x.stamp(9);
     x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });

@@ -21,6 +21,7 @@ struct CpuExec {
     LaneRegs &reg(int lane) { return regs[lane]; }
     int uniform(int v) { return v; }
     void refresh() {}
+    void refresh_uniform(int &) {}
     void stamp(int) {}
     void flush_stamps(const DevBufs &) {}
     template <class F> void each(F f) {
@@ -37,12 +38,13 @@ struct CpuExec {
         else { for (int lane = 63; lane >= 0; --lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane]); } }
         return n;
     }
-    template <class P, class C> void each_bcast(int src, P produce, C consume) {
+    template <class P, class C> void each_row(int src, P produce, C apply) {
         F2b v[64];
         if (!reverse) for (int lane = 0; lane < 64; ++lane) v[lane] = produce(lane);
         else for (int lane = 63; lane >= 0; --lane) v[lane] = produce(lane);
-        if (!reverse) for (int lane = 0; lane < 64; ++lane) consume(lane, v[lane], v[src].dl);
-        else for (int lane = 63; lane >= 0; --lane) consume(lane, v[lane], v[src].dl);
+        regs[src].lam = v[src].ln;
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) apply(lane, v[src].dl);
+        else for (int lane = 63; lane >= 0; --lane) apply(lane, v[src].dl);
     }
     template <class V, class I, class C> void each_shuffle(V value, I index, C consume) {
         float v[64];
