@@ -94,7 +94,7 @@ struct DevBufs {
 /* Per-wave LDS record ("LDS-staged link/joint state"), 5.9 KB.  Three users with disjoint lifetimes share the first
  * block: the K1 -> K2 hand-off of a substep, the velocity responses B of the solver rows (written in phase R1, read
  * until the end of the substep) and the task scratch of the epilogue (observation packing, after the substeps). */
-struct WaveLds {
+struct alignas(16) WaveLds {
     union {
         float Bt[MAXR + 2][16];  /* B[r][d] = (M^-1 J_r^T)[d]: velocity response of every solver row (+2: the last
                                     group of four friction columns may read two rows past the end, values unused) */
