@@ -114,7 +114,8 @@ struct alignas(16) WaveLds {
             float scal[8];       /* 0: reward, 1: food_rew, 2: dead_rew, 3: walk_target_dist, 4: yaw, 5: joints_at_limit */
         };
     };
-    float legI[4][24], legp[4][8]; /* per-leg articulated inertia / bias force handed to the base */
+    float legI[4][28];   /* per leg, handed to the base: articulated inertia [0..20] (upper triangle), bias force [21..26] */
+    float bsum[28];      /* their sum over the legs, (l0 + l1) + (l2 + l3), same layout */
     float lamf[MAXR];    /* final impulses, for the velocity reconstruction */
     float ustar[16];     /* unconstrained velocity (dof order) */
     float st[32];        /* packed state record as stored in HBM */
@@ -127,7 +128,7 @@ struct alignas(16) WaveLds {
     float ph[4][4], pa[4][4], tip[4][4];
     float S[NJ][8], U[NJ][8], cb[NJ][8];
     float invD[NJ], uterm[NJ];
-    float I0inv[36];
+    float Lb[16], idb[8]; /* base articulated inertia = L D L^T: strictly lower part of L (tl() order), 1/D */
     float a0[8];
     float cr[MAXC][4], cn[MAXC][4];
     float cdist_[MAXC];
@@ -251,45 +252,44 @@ HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
         t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
     }
 }
-/* explicit inverse of an SPD 6x6 via Cholesky, A = L L^T, Ainv = Linv^T Linv; all three in triangular storage
- * (tri(i, j), i >= j) so that the whole computation stays in registers */
-HRL_DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-HRL_DEV void spd6_inverse(float *Ainv /* [21], si() layout */, const float *A /* [21], si() layout */) {
-    float Lm[21], Li[21];
+/* Square-root-free Cholesky of an SPD 6x6 (si() layout): A = L D L^T with L unit lower triangular; the strictly lower
+ * part of L in tl(i, j) order (i > j) and id = 1/D.  x = A^-1 b is then two triangular solves and a scaling. */
+HRL_DEV constexpr int tl(int i, int j) { return i * (i - 1) / 2 + j; }
+HRL_DEV void ldl6_factor(float *Lm /* [15] */, float *id /* [6] */, const float *A /* [21] */) {
+    float d[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        float s = A[si(j, j)];
+        float v[6], s = A[si(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s = fma_(-Lm[tri(j, k)], Lm[tri(j, k)], s);
-        float d = sqrtf(s), id = 1.f / d;
-        Lm[tri(j, j)] = d; Li[tri(j, j)] = id;
+        for (int k = 0; k < j; ++k) v[k] = Lm[tl(j, k)] * d[k];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = fma_(-Lm[tl(j, k)], v[k], s);
+        d[j] = s; id[j] = 1.f / s;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             float t = A[si(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t = fma_(-Lm[tri(i, k)], Lm[tri(j, k)], t);
-            Lm[tri(i, j)] = t * id;
+            for (int k = 0; k < j; ++k) t = fma_(-Lm[tl(i, k)], v[k], t);
+            Lm[tl(i, j)] = t * id[j];
         }
     }
+}
+HRL_DEV void ldl6_solve(float *x, const float *Lm, const float *id, const float *b) {
+    float y[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int i = 0; i < 6; ++i) {
+        float t = b[i];
 #pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = j; k < i; ++k) t = fma_(-Lm[tri(i, k)], Li[tri(k, j)], t);
-            Li[tri(i, j)] = t * Li[tri(i, i)];
-        }
+        for (int k = 0; k < i; ++k) t = fma_(-Lm[tl(i, k)], y[k], t);
+        y[i] = t;
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 5; i >= 0; --i) {
+        float t = y[i] * id[i];
 #pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = i; k < 6; ++k) t = fma_(Li[tri(k, i)], Li[tri(k, j)], t);
-            Ainv[si(j, i)] = t;
-        }
+        for (int k = i + 1; k < 6; ++k) t = fma_(-Lm[tl(k, i)], x[k], t);
+        x[i] = t;
+    }
 }
 /* Philox4x32-10, keyed like the oracle: key = (seed_lo, seed_hi ^ env_hi), counter = (env_lo, index, w2, w3) */
 HRL_DEV void philox4x32(const DevCfg &c, long long env, uint32_t index, uint32_t w2, uint32_t w3, uint32_t *out) {
@@ -339,12 +339,19 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
         cfoot[k] = fma_(c.L2 * 0.5f, e2[k], pa[k]);
     }
     const int jh = 2 * l, ja = jh + 1;
+    /* one destination at a time: stores to consecutive addresses that follow each other merge into wide LDS writes */
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        L.ph[l][k] = ph[k]; L.pa[l][k] = pa[k]; L.tip[l][k] = tip[k];
-        L.XYZ[k] = X[k]; L.XYZ[3 + k] = Y[k]; L.XYZ[6 + k] = Z[k];
-        L.kleg[l][k] = e1[k]; L.kleg[l][3 + k] = caux[k];
-    }
+    for (int k = 0; k < 3; ++k) L.ph[l][k] = ph[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.pa[l][k] = pa[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.tip[l][k] = tip[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.XYZ[k] = X[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.XYZ[3 + k] = Y[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.XYZ[6 + k] = Z[k];
     float Sh[6], Sa[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { Sh[k] = Z[k]; Sa[k] = axw[k]; }
@@ -358,7 +365,19 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
     crm(cbh, v0, vjh);
     crm(cba, vx, vja);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { L.S[jh][k] = Sh[k]; L.S[ja][k] = Sa[k]; L.cb[jh][k] = cbh[k]; L.cb[ja][k] = cba[k]; L.kleg[l][6 + k] = vx[k]; }
+    for (int k = 0; k < 6; ++k) L.S[jh][k] = Sh[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.S[ja][k] = Sa[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.cb[jh][k] = cbh[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.cb[ja][k] = cba[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.kleg[l][k] = e1[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.kleg[l][3 + k] = caux[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.kleg[l][6 + k] = vx[k];
     float If[21], Iv[6], f[6], pAf[6], ng[3];
     spatial_inertia(If, c.m2, c.a2, c.b2, e2, cfoot);
     { /* bias force of the foot: v x* (I v) - gravity wrench */
@@ -378,7 +397,9 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
     sym6_matvec(Iac, If, cba);
     const float ud = uta * invDa;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) { L.paf[l][a] = fma_(Ua[a], ud, pAf[a] + Iac[a]); L.U[ja][a] = Ua[a]; }
+    for (int a = 0; a < 6; ++a) L.paf[l][a] = fma_(Ua[a], ud, pAf[a] + Iac[a]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) L.U[ja][a] = Ua[a];
 #pragma unroll
     for (int k = 0; k < 21; ++k) L.Iaf[l][k] = If[k];
     L.invD[ja] = invDa; L.uterm[ja] = uta;
@@ -415,13 +436,20 @@ HRL_DEV void phase_hip(const DevCfg &c, WaveLds &L, int lane) {
     sym6_matvec(Iac, Ix, cbh);
     const float ud = uth * invDh;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) { L.legp[l][a] = fma_(Uh[a], ud, pAx[a] + Iac[a]); L.U[jh][a] = Uh[a]; }
+    for (int a = 0; a < 6; ++a) L.U[jh][a] = Uh[a];
 #pragma unroll
     for (int k = 0; k < 21; ++k) L.legI[l][k] = Ix[k];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) L.legI[l][21 + a] = fma_(Uh[a], ud, pAx[a] + Iac[a]);
     L.invD[jh] = invDh; L.uterm[jh] = uth;
 }
 
-/* Phase B (uniform): torso + leg sums, inverse of the base articulated inertia, base acceleration. */
+/* Phase S (entry map): what the four legs hand to the base, summed entry by entry, (l0 + l1) + (l2 + l3) */
+HRL_DEV void phase_leg_sum(WaveLds &L, int lane) {
+    if (lane < 27) L.bsum[lane] = (L.legI[0][lane] + L.legI[1][lane]) + (L.legI[2][lane] + L.legI[3][lane]);
+}
+
+/* Phase B (uniform): torso + leg sums, factorization of the base articulated inertia, base acceleration. */
 HRL_DEV void phase_base(const DevCfg &c, WaveLds &L, int lane) {
     float Z[3] = {L.XYZ[6], L.XYZ[7], L.XYZ[8]}, zero3[3] = {0.f, 0.f, 0.f};
     float I0[21], v0[6], Iv[6], f[6], p0[6];
@@ -435,19 +463,21 @@ HRL_DEV void phase_base(const DevCfg &c, WaveLds &L, int lane) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { p0[k] = f[k] - ng[k]; p0[3 + k] = f[3 + k] - fg[k]; }
 #pragma unroll
-    for (int k = 0; k < 21; ++k) I0[k] += (L.legI[0][k] + L.legI[1][k]) + (L.legI[2][k] + L.legI[3][k]);
+    for (int k = 0; k < 21; ++k) I0[k] += L.bsum[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) p0[k] = p0[k] + ((L.legp[0][k] + L.legp[1][k]) + (L.legp[2][k] + L.legp[3][k]));
-    float Ainv[21], a0[6];
-    spd6_inverse(Ainv, I0);
-    sym6_matvec(a0, Ainv, p0);
+    for (int k = 0; k < 6; ++k) p0[k] = p0[k] + L.bsum[21 + k];
+    float Lm[15], id[6], a0[6];
+    ldl6_factor(Lm, id, I0);
+    ldl6_solve(a0, Lm, id, p0);
+    /* every lane holds the same values; one lane group stores them */
+    if (lane < 16) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a) L.a0[a] = -a0[a];
+        for (int a = 0; a < 6; ++a) L.a0[a] = -a0[a];
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+        for (int k = 0; k < 15; ++k) L.Lb[k] = Lm[k];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) L.I0inv[a * 6 + b] = Ainv[si(a, b)];
-    (void)lane;
+        for (int k = 0; k < 6; ++k) L.idb[k] = id[k];
+    }
 }
 
 /* Phase V (dof map): forward pass of the lane's leg, then the unconstrained velocity update into the lane register. */
@@ -504,8 +534,9 @@ HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, fl
         for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
     }
     float dv0[6];
+    ldl6_solve(dv0, L.Lb, L.idb, p);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) dv0[a] = -dot6(L.I0inv + 6 * a, p);
+    for (int a = 0; a < 6; ++a) dv0[a] = -dv0[a];
 #pragma unroll
     for (int k = 0; k < 6; ++k) du[k] = dv0[k];
 #pragma unroll
@@ -785,6 +816,7 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
     x.stamp(1);
     x.each([&](int lane) { phase_hip(c, L, lane); });
     x.stamp(2);
+    x.each([&](int lane) { phase_leg_sum(L, lane); });
     x.each([&](int lane) { phase_base(c, L, lane); });
     x.stamp(3);
     x.each([&](int lane) { const float v = phase_forward_vel(c, L, lane); x.reg(lane).ud = v; if (lane < 16) L.ustar[lane] = v; });

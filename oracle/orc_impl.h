@@ -522,7 +522,7 @@ typedef struct FN(orc_dyn) {
     REAL X[3], Y[3], Z[3];
     REAL ph[4][3], pa[4][3], tip[4][3]; /* hip anchor, ankle anchor, foot tip, relative to O = torso COM, world axes */
     REAL S[NJ][6], U[NJ][6], invD[NJ], uterm[NJ], cb[NJ][6];
-    REAL I0inv[6][6];
+    REAL Lb[6][6], idb[6]; /* base articulated inertia I0^A = L D L^T: unit lower L (strictly lower part used), 1/D */
     REAL a0[6], qdd[NJ];
 } FN(orc_dyn);
 
@@ -559,33 +559,35 @@ static void FN(crf)(REAL *o, const REAL *v, const REAL *f) { /* spatial force cr
     for (int i = 0; i < 3; ++i) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
 }
 
-/* explicit inverse of a symmetric positive-definite 6x6 via Cholesky: A = L L^T, Ainv = Linv^T Linv */
-static void FN(spd6_inverse)(REAL Ainv[6][6], REAL A[6][6]) {
-    REAL L[6][6], Li[6][6];
-    memset(L, 0, sizeof(L)); memset(Li, 0, sizeof(Li));
+/* Square-root-free Cholesky of a symmetric positive-definite 6x6: A = L D L^T with L unit lower triangular.
+ * Only the strictly lower part of L and id = 1/D are produced; the lower triangle of A is read. */
+static void FN(ldl6_factor)(REAL L[6][6], REAL *id, REAL A[6][6]) {
+    REAL d[6];
     for (int j = 0; j < 6; ++j) {
-        REAL s = A[j][j];
-        for (int k = 0; k < j; ++k) s = FMA_(-L[j][k], L[j][k], s);
-        REAL d = RSQRT(s), id = R_(1) / d;
-        L[j][j] = d; Li[j][j] = id;
+        REAL v[6], s = A[j][j];
+        for (int k = 0; k < j; ++k) v[k] = L[j][k] * d[k];
+        for (int k = 0; k < j; ++k) s = FMA_(-L[j][k], v[k], s);
+        d[j] = s; id[j] = R_(1) / s;
         for (int i = j + 1; i < 6; ++i) {
             REAL t = A[i][j];
-            for (int k = 0; k < j; ++k) t = FMA_(-L[i][k], L[j][k], t);
-            L[i][j] = t * id;
+            for (int k = 0; k < j; ++k) t = FMA_(-L[i][k], v[k], t);
+            L[i][j] = t * id[j];
         }
     }
-    for (int j = 0; j < 6; ++j) /* Li = L^-1 (lower), column by column; its diagonal is the 1/d computed above */
-        for (int i = j + 1; i < 6; ++i) {
-            REAL t = 0;
-            for (int k = j; k < i; ++k) t = FMA_(-L[i][k], Li[k][j], t);
-            Li[i][j] = t * Li[i][i];
-        }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j <= i; ++j) {
-            REAL t = 0;
-            for (int k = i; k < 6; ++k) t = FMA_(Li[k][i], Li[k][j], t);
-            Ainv[i][j] = t; Ainv[j][i] = t;
-        }
+}
+/* x = A^-1 b through the factors: L y = b, z = y / D, L^T x = z */
+static void FN(ldl6_solve)(REAL *x, REAL L[6][6], const REAL *id, const REAL *b) {
+    REAL y[6];
+    for (int i = 0; i < 6; ++i) {
+        REAL t = b[i];
+        for (int k = 0; k < i; ++k) t = FMA_(-L[i][k], y[k], t);
+        y[i] = t;
+    }
+    for (int i = 5; i >= 0; --i) {
+        REAL t = y[i] * id[i];
+        for (int k = i + 1; k < 6; ++k) t = FMA_(-L[k][i], x[k], t);
+        x[i] = t;
+    }
 }
 
 /* Kinematics at q, articulated inertias, and (if u/tau given) forward dynamics qdd, a0.
@@ -669,8 +671,9 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
         for (int b = 0; b < 6; ++b) IA[0][a][b] += (Ileg[0][a][b] + Ileg[1][a][b]) + (Ileg[2][a][b] + Ileg[3][a][b]);
         p0[a] = pA[0][a] + ((pleg[0][a] + pleg[1][a]) + (pleg[2][a] + pleg[3][a]));
     }
-    FN(spd6_inverse)(D->I0inv, IA[0]);
-    for (int a = 0; a < 6; ++a) D->a0[a] = -FN(dot6)(D->I0inv[a], p0);
+    memset(D->Lb, 0, sizeof(D->Lb));
+    FN(ldl6_factor)(D->Lb, D->idb, IA[0]);
+    { REAL s0[6]; FN(ldl6_solve)(s0, D->Lb, D->idb, p0); for (int a = 0; a < 6; ++a) D->a0[a] = -s0[a]; }
     for (int l = 0; l < 4; ++l) { /* forward pass */
         REAL ap[6], ax_[6];
         int jh = 2 * l, ja = jh + 1;
@@ -696,7 +699,7 @@ static void FN(orc_response)(const FN(orc_dyn) * D, const REAL *phi, int level, 
     { REAL s = uh * D->invD[jh]; for (int k = 0; k < 6; ++k) p[k] = FMA_(D->U[jh][k], s, p[k]); }
     if (level == 0) for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
     REAL dv0[6];
-    for (int a = 0; a < 6; ++a) dv0[a] = -FN(dot6)(D->I0inv[a], p);
+    { REAL s0[6]; FN(ldl6_solve)(s0, ((FN(orc_dyn) *)D)->Lb, D->idb, p); for (int a = 0; a < 6; ++a) dv0[a] = -s0[a]; }
     for (int k = 0; k < 6; ++k) du[k] = dv0[k];
     for (int l = 0; l < 4; ++l) {
         int h_ = 2 * l, a_ = h_ + 1;

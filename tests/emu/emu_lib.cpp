@@ -93,6 +93,7 @@ extern "C" void emu_dyn_dump(const hrl_config *cfg, const float *q, const float 
     for (int j = 0; j < 8; ++j) L.tau[j] = tau[j];
     x.each([&](int lane) { phase_kin_ankle(c, L, L.q[0], lane); });
     x.each([&](int lane) { phase_hip(c, L, lane); });
+    x.each([&](int lane) { phase_leg_sum(L, lane); });
     x.each([&](int lane) { phase_base(c, L, lane); });
     int o = 0;
     for (int j = 0; j < 8; ++j) for (int k = 0; k < 6; ++k) out[o++] = L.S[j][k];
@@ -100,6 +101,6 @@ extern "C" void emu_dyn_dump(const hrl_config *cfg, const float *q, const float 
     for (int j = 0; j < 8; ++j) for (int k = 0; k < 6; ++k) out[o++] = L.cb[j][k];
     for (int j = 0; j < 8; ++j) out[o++] = L.invD[j];
     for (int j = 0; j < 8; ++j) out[o++] = L.uterm[j];
-    for (int k = 0; k < 36; ++k) out[o++] = L.I0inv[k];
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[o++] = a > b ? L.Lb[tl(a, b)] : (a == b ? L.idb[a] : 0.f);
     for (int k = 0; k < 6; ++k) out[o++] = L.a0[k];
 }
