@@ -130,7 +130,8 @@ struct alignas(16) WaveLds {
     float invD[NJ], uterm[NJ];
     float Lb[16], idb[8]; /* base articulated inertia = L D L^T: strictly lower part of L (tl() order), 1/D */
     float a0[8];
-    float cr[MAXC][4], cn[MAXC][4];
+    float cr[MAXC][4];       /* contact point relative to O */
+    float cdir[3][MAXC][4];  /* contact frame: normal, tangent 1, tangent 2 (tangent_basis of the normal) */
     float cdist_[MAXC];
     int clink[MAXC];     /* level | leg << 2 */
     int ljoint[NJ];
@@ -251,6 +252,17 @@ HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
         t1[0] = -n[1] * k; t1[1] = n[0] * k; t1[2] = 0.f;
         t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
     }
+}
+/* the three row directions of a contact, computed once by the lane that found it (phase C) for its three rows (R1) */
+HRL_DEV void store_contact_frame(WaveLds &L, int i, const float *n) {
+    float t1[3], t2[3];
+    tangent_basis(n, t1, t2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.cdir[0][i][k] = n[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.cdir[1][i][k] = t1[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L.cdir[2][i][k] = t2[k];
 }
 /* Square-root-free Cholesky of an SPD 6x6 (si() layout): A = L D L^T with L unit lower triangular; the strictly lower
  * part of L in tl(i, j) order (i > j) and id = 1/D.  x = A^-1 b is then two triangular solves and a scaling. */
@@ -633,12 +645,8 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
     } else {
         const int row = row_id - nL;
         const int ci = row < nC ? row : (row - nC) >> 1, which = row < nC ? 0 : 1 + ((row - nC) & 1);
-        float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
-        float t1[3], t2[3];
-        tangent_basis(n, t1, t2);
-        float d[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d[k] = which == 0 ? n[k] : (which == 1 ? t1[k] : t2[k]);
+        const float r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
+        const float d[3] = {L.cdir[which][ci][0], L.cdir[which][ci][1], L.cdir[which][ci][2]}; /* the row's direction */
         cross3(phi, r, d);
 #pragma unroll
         for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
@@ -708,32 +716,29 @@ HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int 
     g.w = row_dot(g, L.ustar) + g.bias;
 }
 
-/* Phase I (uniform): clamp joint rates was done in the dof map; integrate positions */
+/* Phase I (dof map): integrate positions; the joint rates were clamped by the caller.  Lane k < 16 produces element k
+ * of the new q: the quaternion (exponential map, every lane computes it) or one fma for a position / joint angle. */
 HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float *qn, int lane) {
-    float u[16];
-#pragma unroll
-    for (int k = 0; k < 14; ++k) u[k] = L.u[k];
     const float h = c.h;
-    float wn = sqrtf(dot3(u, u)), th = wn * h, dq[4];
-    if (th > 1e-6f) { float sh_, ch_; sincos_spec(0.5f * th, &sh_, &ch_); float s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
-    else { float s = 0.5f * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1.f; }
+    const float u0 = L.u[0], u1 = L.u[1], u2 = L.u[2];
+    float wn = sqrtf(fma_(u2, u2, fma_(u1, u1, u0 * u0))), th = wn * h, dq[4];
+    if (th > 1e-6f) { float sh_, ch_; sincos_spec(0.5f * th, &sh_, &ch_); float s = sh_ / wn; dq[0] = u0 * s; dq[1] = u1 * s; dq[2] = u2 * s; dq[3] = ch_; }
+    else { float s = 0.5f * h; dq[0] = u0 * s; dq[1] = u1 * s; dq[2] = u2 * s; dq[3] = 1.f; }
     float x = q[3], y = q[4], z = q[5], w = q[6];
     float nx = fma_(-dq[2], y, fma_(dq[1], z, fma_(dq[0], w, dq[3] * x)));
     float ny = fma_(dq[2], x, fma_(dq[1], w, fma_(-dq[0], z, dq[3] * y)));
     float nz = fma_(dq[2], w, fma_(-dq[1], x, fma_(dq[0], y, dq[3] * z)));
     float nw = fma_(-dq[2], z, fma_(-dq[1], y, fma_(-dq[0], x, dq[3] * w)));
     float inv = 1.f / sqrtf(fma_(nx, nx, ny * ny) + fma_(nz, nz, nw * nw));
-    float nq[16];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) nq[k] = fma_(h, u[3 + k], q[k]);
-    nq[3] = nx * inv; nq[4] = ny * inv; nq[5] = nz * inv; nq[6] = nw * inv;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) nq[7 + j] = fma_(h, u[6 + j], q[7 + j]);
-    nq[15] = 0.f;
-    /* every lane holds the same 16 values; lane k < 16 stores element k */
-    float mine = nq[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) mine = (lane == k) ? nq[k] : mine;
+    const int k = lane & 15;
+    /* position k < 3 advances with the linear velocity u[3 + k], joint angle q[7 + j] with the joint rate u[6 + j] */
+    const int ui = k < 3 ? k + 3 : (k >= 7 && k < 15 ? k - 1 : 0);
+    float mine = fma_(h, L.u[ui], q[k]);
+    mine = (k == 3) ? nx * inv : mine;
+    mine = (k == 4) ? ny * inv : mine;
+    mine = (k == 5) ? nz * inv : mine;
+    mine = (k == 6) ? nw * inv : mine;
+    mine = (k == 15) ? 0.f : mine;
     if (lane < 16) qn[lane] = mine;
 }
 
@@ -851,7 +856,8 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
                 const int i = base + rank;
                 if (i < MAXC) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { L.cn[i][k] = h.n[k]; L.cr[i][k] = fma_(-h.rad, h.n[k], h.c[k]); }
+                    for (int k = 0; k < 3; ++k) L.cr[i][k] = fma_(-h.rad, h.n[k], h.c[k]);
+                    store_contact_frame(L, i, h.n);
                     L.cdist_[i] = h.dist; L.clink[i] = h.link;
                 }
             },
@@ -936,7 +942,7 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
                 const int i = base + rank;
                 if (i < MAXC) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { L.cn[i][k] = h.n[k]; L.cr[i][k] = h.c[k]; }
+                    for (int k = 0; k < 3; ++k) { L.cr[i][k] = h.c[k]; L.cdir[0][i][k] = h.n[k]; }
                     L.cdist_[i] = h.dist;
                 }
             },
@@ -944,16 +950,17 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
         nC += cnt;
         if (nC > MAXC) nC = MAXC;
     }
+    x.each([&](int lane) { /* contact map: tangents of the kept contacts */
+        if (lane < nC) { const float n[3] = {L.cdir[0][lane][0], L.cdir[0][lane][1], L.cdir[0][lane][2]}; store_contact_frame(L, lane, n); }
+    });
     x.each([&](int lane) { /* row map */
         LaneRegs &g = x.reg(lane);
         g.fn = -1;
         if (lane >= 3 * nC) return;
         const int ci = lane < nC ? lane : (lane - nC) >> 1, which = lane < nC ? 0 : 1 + ((lane - nC) & 1);
-        float n[3] = {L.cn[ci][0], L.cn[ci][1], L.cn[ci][2]}, r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
-        float t1[3], t2[3], d[3], J[6], B[16];
-        tangent_basis(n, t1, t2);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d[k] = which == 0 ? n[k] : (which == 1 ? t1[k] : t2[k]);
+        const float r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
+        const float d[3] = {L.cdir[which][ci][0], L.cdir[which][ci][1], L.cdir[which][ci][2]};
+        float J[6], B[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) B[k] = 0.f;
         cross3(J, r, d);
