@@ -4,8 +4,8 @@
  * One 64-thread workgroup = one wavefront = one environment.  The wave runs the phases of step_core.h with
  *   - per-wave state staged in LDS (WaveLds < 10 KB and <= 128 VGPRs -> 16 waves per CU, 4 per SIMD),
  *   - coalesced 128-byte loads/stores of the packed state / item records (lane i <-> float i of the record),
- *   - the contact/limit solver entirely in lane registers: row r lives in lane r, its update is broadcast with
- *     v_readlane_b32 (no LDS, no barrier, no reduction on the dependent chain),
+ *   - the contact/limit solver entirely in lane registers: row r lives in lane r, its impulse change is broadcast with
+ *     one v_readlane_b32 (no LDS, no barrier, no reduction on the dependent chain),
  *   - ballot + mbcnt for compacting active contacts / limits into solver rows.
  * There is no cross-workgroup communication, so no XCD-aware block remap is needed: blockIdx.x = env index and the
  * dispatcher's round-robin over the 8 XCDs spreads the envs evenly.

@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU box: the rocprofv3 passes whose summaries are committed under profiles/ (tools/summarize_profile.py condenses them).
+#   usage: tools/profile_round.sh gpurun_out/prof_<tag>
+# Kernel trace + stats and every counter group run as separate passes of the same bench command.
+O=${1:?out dir}; mkdir -p $O
+B="python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/bench_trace.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/f.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/w.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU \
+  --kernel-trace --output-format csv -d $O/pmc_sq1 -- $B > $O/s1.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
+  --kernel-trace --output-format csv -d $O/pmc_sq2 -- $B > $O/s2.log 2>&1 || exit 1
+echo profiled into $O
