@@ -101,7 +101,6 @@ struct alignas(16) WaveLds {
         struct {                 /* phase K1 -> K2 hand-off (dead before the rows are built) */
             float Iaf[4][24];    /* articulated inertia of the foot seen through the ankle (upper triangle) */
             float paf[4][8];     /* its bias force */
-            float kleg[4][16];   /* e1[3], caux[3], vx[6]: aux axis, aux COM, aux spatial velocity */
         };
         struct {
             float s28[32];       /* upstream 28-vector (WalkerBase.calc_state) */
@@ -143,6 +142,7 @@ struct alignas(16) WaveLds {
  * solver never touches LDS in its sweeps); every field is fully redefined in every substep. */
 struct LaneRegs {
     float ud;                        /* dof map: the lane's velocity component */
+    float rI[21], rp[6];             /* body map (phases K1 -> K2 -> B): the lane's rigid-body spatial inertia and bias force */
     float Jb[6], Jh, Ja;             /* row map: the row's Jacobian, sparse: torso twist part + the hip / ankle entries */
     int jslot;                       /* row map: dof slot of Jh (Ja is the next slot): 6 + 2 * leg                   */
     float An[MAXB], Af[MAXF];        /* row map: the row's line of A = J M^-1 J^T: limit/normal columns, friction columns */
@@ -320,12 +320,16 @@ HRL_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f
 
 /* ================================================================================================= ANT SUBSTEP */
 
-/* Phase K1 (leg map): kinematics of one leg and its ankle joint (foot -> aux), results to LDS.
+/* Phase K1 (body map): lane group g = lane >> 2 owns one rigid body -- g 0..3 the foot of leg g, 4..7 the aux body of
+ * leg g - 4, 8.. the torso.  Every lane computes the kinematics of its leg, then ONE instruction stream forms the
+ * spatial inertia and bias force of all nine bodies at once (the lanes only differ in the parameters they select).
+ * The foot lanes go on to the ankle joint (foot -> aux) and publish the leg's kinematic data; the aux and torso
+ * lanes keep their rigid-body quantities in registers for phases K2 / B.
  * The two articulated-body joints of a leg are split over two phases so that only one 6x6 inertia is live in
  * registers at a time (<= 128 VGPRs without scratch). */
-HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int lane) {
+HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const float *q, int lane) {
     const float is2 = 0.70710678118654752440f;
-    const int l = (lane >> 4) & 3;
+    const int grp = lane >> 2, type = grp >> 2, l = grp & 3;
     float x = q[3], y = q[4], z = q[5], w = q[6];
     float X[3], Y[3], Z[3];
     quat_axes(x, y, z, w, X, Y, Z);
@@ -351,6 +355,39 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
         cfoot[k] = fma_(c.L2 * 0.5f, e2[k], pa[k]);
     }
     const int jh = 2 * l, ja = jh + 1;
+    float Sh[6], Sa[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Sh[k] = Z[k]; Sa[k] = axw[k]; }
+    cross3(Sh + 3, ph, Z);
+    cross3(Sa + 3, pa, axw);
+    float v0[6], vjh[6], vx[6], vja[6], vf[6], cbh[6], cba[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { v0[k] = L.u[k]; vjh[k] = Sh[k] * qdh; vx[k] = v0[k] + vjh[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { vja[k] = Sa[k] * qda; vf[k] = vx[k] + vja[k]; }
+    crm(cbh, v0, vjh);
+    crm(cba, vx, vja);
+    /* the lane's rigid body: mass model, axis, COM (relative to O) and spatial velocity */
+    const float bm = type == 0 ? c.m2 : (type == 1 ? c.m1 : c.m0);
+    const float bal = type == 0 ? c.a2 : (type == 1 ? c.a1 : c.a0), bbe = type == 0 ? c.b2 : (type == 1 ? c.b1 : c.b0);
+    float be[3], bc[3], bv[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        be[k] = type == 0 ? e2[k] : (type == 1 ? e1[k] : Z[k]);
+        bc[k] = type == 0 ? cfoot[k] : (type == 1 ? caux[k] : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bv[k] = type == 0 ? vf[k] : (type == 1 ? vx[k] : v0[k]);
+    float *If = g.rI, *pAf = g.rp; /* stay in the lane's registers: the aux and torso lanes use them in K2 / B */
+    float Iv[6], f[6], ng[3];
+    spatial_inertia(If, bm, bal, bbe, be, bc);
+    { /* bias force of the body: v x* (I v) - gravity wrench */
+        float fg2[3] = {0.f, 0.f, -bm * c.g};
+        sym6_matvec(Iv, If, bv); crf(f, bv, Iv); cross3(ng, bc, fg2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pAf[k] = f[k] - ng[k]; pAf[3 + k] = f[3 + k] - fg2[k]; }
+    }
+    if (type != 0) return; /* aux body: continues in K2; torso: in B */
     /* one destination at a time: stores to consecutive addresses that follow each other merge into wide LDS writes */
 #pragma unroll
     for (int k = 0; k < 3; ++k) L.ph[l][k] = ph[k];
@@ -364,18 +401,6 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
     for (int k = 0; k < 3; ++k) L.XYZ[3 + k] = Y[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) L.XYZ[6 + k] = Z[k];
-    float Sh[6], Sa[6];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { Sh[k] = Z[k]; Sa[k] = axw[k]; }
-    cross3(Sh + 3, ph, Z);
-    cross3(Sa + 3, pa, axw);
-    float v0[6], vjh[6], vx[6], vja[6], vf[6], cbh[6], cba[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { v0[k] = L.u[k]; vjh[k] = Sh[k] * qdh; vx[k] = v0[k] + vjh[k]; }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { vja[k] = Sa[k] * qda; vf[k] = vx[k] + vja[k]; }
-    crm(cbh, v0, vjh);
-    crm(cba, vx, vja);
 #pragma unroll
     for (int k = 0; k < 6; ++k) L.S[jh][k] = Sh[k];
 #pragma unroll
@@ -384,20 +409,6 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
     for (int k = 0; k < 6; ++k) L.cb[jh][k] = cbh[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) L.cb[ja][k] = cba[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.kleg[l][k] = e1[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.kleg[l][3 + k] = caux[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) L.kleg[l][6 + k] = vx[k];
-    float If[21], Iv[6], f[6], pAf[6], ng[3];
-    spatial_inertia(If, c.m2, c.a2, c.b2, e2, cfoot);
-    { /* bias force of the foot: v x* (I v) - gravity wrench */
-        float fg2[3] = {0.f, 0.f, -c.m2 * c.g};
-        sym6_matvec(Iv, If, vf); crf(f, vf, Iv); cross3(ng, cfoot, fg2);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { pAf[k] = f[k] - ng[k]; pAf[3 + k] = f[3 + k] - fg2[k]; }
-    }
     float Ua[6], Iac[6];
     sym6_matvec(Ua, If, Sa);
     const float invDa = 1.f / dot6(Sa, Ua);
@@ -417,26 +428,18 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, const float *q, int la
     L.invD[ja] = invDa; L.uterm[ja] = uta;
 }
 
-/* Phase K2 (leg map): aux body + what the ankle handed over, then the hip joint (aux -> torso). */
-HRL_DEV void phase_hip(const DevCfg &c, WaveLds &L, int lane) {
-    const int l = (lane >> 4) & 3, jh = 2 * l;
-    float e1[3], caux[3], vx[6], Sh[6], cbh[6];
+/* Phase K2 (body map, same lanes as K1): the aux lanes add what the ankle handed over to their rigid part and process
+ * the hip joint (aux -> torso).  Every lane runs the stream on its own registers; only the aux lanes publish. */
+HRL_DEV void phase_hip(WaveLds &L, const LaneRegs &g, int lane) {
+    const int grp = lane >> 2, type = grp >> 2, l = grp & 3, jh = 2 * l;
+    float Sh[6], cbh[6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { e1[k] = L.kleg[l][k]; caux[k] = L.kleg[l][3 + k]; }
+    for (int k = 0; k < 6; ++k) { Sh[k] = L.S[jh][k]; cbh[k] = L.cb[jh][k]; }
+    float Ix[21], pAx[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { vx[k] = L.kleg[l][6 + k]; Sh[k] = L.S[jh][k]; cbh[k] = L.cb[jh][k]; }
-    float Ix[21], Iv[6], f[6], pAx[6], ng[3];
-    spatial_inertia(Ix, c.m1, c.a1, c.b1, e1, caux);
-    {
-        float fg[3] = {0.f, 0.f, -c.m1 * c.g};
-        sym6_matvec(Iv, Ix, vx); crf(f, vx, Iv); cross3(ng, caux, fg);
+    for (int a = 0; a < 6; ++a) pAx[a] = g.rp[a] + L.paf[l][a];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { pAx[k] = f[k] - ng[k]; pAx[3 + k] = f[3 + k] - fg[k]; }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) pAx[a] += L.paf[l][a];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) Ix[k] += L.Iaf[l][k];
+    for (int k = 0; k < 21; ++k) Ix[k] = g.rI[k] + L.Iaf[l][k];
     float Uh[6], Iac[6];
     sym6_matvec(Uh, Ix, Sh);
     const float invDh = 1.f / dot6(Sh, Uh);
@@ -447,6 +450,7 @@ HRL_DEV void phase_hip(const DevCfg &c, WaveLds &L, int lane) {
         for (int b = a; b < 6; ++b) Ix[si(a, b)] = fma_(-(Uh[a] * invDh), Uh[b], Ix[si(a, b)]);
     sym6_matvec(Iac, Ix, cbh);
     const float ud = uth * invDh;
+    if (type != 1) return;
 #pragma unroll
     for (int a = 0; a < 6; ++a) L.U[jh][a] = Uh[a];
 #pragma unroll
@@ -461,28 +465,18 @@ HRL_DEV void phase_leg_sum(WaveLds &L, int lane) {
     if (lane < 27) L.bsum[lane] = (L.legI[0][lane] + L.legI[1][lane]) + (L.legI[2][lane] + L.legI[3][lane]);
 }
 
-/* Phase B (uniform): torso + leg sums, factorization of the base articulated inertia, base acceleration. */
-HRL_DEV void phase_base(const DevCfg &c, WaveLds &L, int lane) {
-    float Z[3] = {L.XYZ[6], L.XYZ[7], L.XYZ[8]}, zero3[3] = {0.f, 0.f, 0.f};
-    float I0[21], v0[6], Iv[6], f[6], p0[6];
-    spatial_inertia(I0, c.m0, c.a0, c.b0, Z, zero3);
+/* Phase B (body map; the torso lanes count): torso (rigid part from K1, in registers) + leg sums, factorization of the base articulated inertia, base acceleration. */
+HRL_DEV void phase_base(WaveLds &L, const LaneRegs &g, int lane) {
+    float I0[21], p0[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) v0[k] = L.u[k];
-    sym6_matvec(Iv, I0, v0);
-    crf(f, v0, Iv);
-    float fg[3] = {0.f, 0.f, -c.m0 * c.g}, ng[3];
-    cross3(ng, zero3, fg);
+    for (int k = 0; k < 21; ++k) I0[k] = g.rI[k] + L.bsum[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { p0[k] = f[k] - ng[k]; p0[3 + k] = f[3 + k] - fg[k]; }
-#pragma unroll
-    for (int k = 0; k < 21; ++k) I0[k] += L.bsum[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) p0[k] = p0[k] + L.bsum[21 + k];
+    for (int k = 0; k < 6; ++k) p0[k] = g.rp[k] + L.bsum[21 + k];
     float Lm[15], id[6], a0[6];
     ldl6_factor(Lm, id, I0);
     ldl6_solve(a0, Lm, id, p0);
-    /* every lane holds the same values; one lane group stores them */
-    if (lane < 16) {
+    /* the torso lanes (32..63) hold the base's values; one group of them stores */
+    if (lane >= 32 && lane < 48) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) L.a0[a] = -a0[a];
 #pragma unroll
@@ -817,12 +811,12 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
     float *qn = L.q[qi ^ 1];
     x.refresh(); /* keep lane-derived values local to the substep (see GpuExec::refresh) */
     x.stamp(0);
-    x.each([&](int lane) { phase_kin_ankle(c, L, q, lane); });
+    x.each([&](int lane) { phase_kin_ankle(c, L, x.reg(lane), q, lane); });
     x.stamp(1);
-    x.each([&](int lane) { phase_hip(c, L, lane); });
+    x.each([&](int lane) { phase_hip(L, x.reg(lane), lane); });
     x.stamp(2);
     x.each([&](int lane) { phase_leg_sum(L, lane); });
-    x.each([&](int lane) { phase_base(c, L, lane); });
+    x.each([&](int lane) { phase_base(L, x.reg(lane), lane); });
     x.stamp(3);
     x.each([&](int lane) { const float v = phase_forward_vel(c, L, lane); x.reg(lane).ud = v; if (lane < 16) L.ustar[lane] = v; });
     x.stamp(4);
@@ -1295,7 +1289,7 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
     if (centroid) { /* link positions of the final pose for the parts centroid; its LDS hand-off area overlays the
                        task scratch, so it runs before anything below is written */
         x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
-        x.each([&](int lane) { phase_kin_ankle(c, L, L.q[0], lane); });
+        x.each([&](int lane) { phase_kin_ankle(c, L, x.reg(lane), L.q[0], lane); });
     }
     x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
     if (KIND == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
