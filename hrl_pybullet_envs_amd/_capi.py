@@ -1,7 +1,7 @@
 """ctypes mirror of include/hrl_envs.h (structs + constants only; no library loading here)."""
 import ctypes as C
 
-HRL_ABI_VERSION = 2
+HRL_ABI_VERSION = 3
 HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER, HRL_ANT_MAZE_MJ, HRL_ANT_FLAGRUN = 0, 1, 2, 3, 4, 5
 HRL_STATE_STRIDE = 32
 HRL_QPOS_OFF, HRL_QVEL_OFF, HRL_EPRET_OFF, HRL_INITZ_OFF, HRL_POTENTIAL_OFF = 0, 15, 29, 30, 31
@@ -41,7 +41,7 @@ class hrl_config(C.Structure):
                 ('centroid_n_static', C.c_int32), ('centroid_static_sum', C.c_float * 2),
                 ('walk_target', C.c_float * 2),
                 ('flag_size', C.c_float), ('flag_max_targets', C.c_int32), ('flag_timeout', C.c_int32),
-                ('flag_switch_on_collision', C.c_int32), ('flag_enclosed', C.c_int32),
+                ('flag_switch_on_collision', C.c_int32), ('flag_enclosed', C.c_int32), ('flag_max_target_dist', C.c_float),
                 ('model', hrl_model)]
 
     def copy(self):

@@ -106,7 +106,11 @@ inline std::string validate(const hrl_config *c) {
         if (!(c->sensor_range > 0)) return "sensor_range must be positive";
     }
     if (c->env_kind == HRL_ANT_FLAGRUN) {
-        if (c->flag_max_targets < 1 || c->flag_max_targets > 65535) return "flag_max_targets must be within 1..65535 (max_target_dist mode, ant_flagrun_env.py:80-89, is not implemented)";
+        /* ant_flagrun_env.py:17-18: a goal list (max_targets > 0) or goals near the robot (max_target_dist > 0), never both */
+        const bool list_mode = c->flag_max_target_dist == 0.f && c->flag_max_targets > 0, close_mode = c->flag_max_targets <= 0 && c->flag_max_target_dist > 0.f;
+        if (!list_mode && !close_mode) return "exactly one of flag_max_targets > 0 (with flag_max_target_dist == 0) and flag_max_target_dist > 0 (with flag_max_targets <= 0) must hold";
+        if (list_mode && c->flag_max_targets > 65535) return "flag_max_targets must be <= 65535";
+        if (close_mode && !(c->flag_max_target_dist / 2 > c->tol)) return "flag_max_target_dist / 2 must exceed tol (the per-axis offset is drawn from U(tol, max_target_dist / 2))";
         if (c->flag_timeout > 32767) return "flag_timeout must be <= 32767";
         if (!(c->flag_size > 1.0f)) return "flag_size must exceed 1 (targets are rejected within 0.5 of the origin)";
         if (c->use_sensor && (c->n_bins < 2 || c->n_bins > HRL_MAX_BINS)) return "sensor_bins must be within 2..16";
@@ -178,7 +182,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     }
     if (maze_world) { d.n_boxes = 1; d.box_lo[0] = -5; d.box_lo[1] = -2; d.box_lo[2] = 0; d.box_hi[0] = 1; d.box_hi[1] = 2; d.box_hi[2] = 2; }
     d.flag_size = c.flag_size; d.flag_max_targets = c.flag_max_targets; d.flag_timeout = c.flag_timeout;
-    d.flag_switch = c.flag_switch_on_collision;
+    d.flag_switch = c.flag_switch_on_collision; d.flag_mtd = c.flag_max_target_dist;
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
 }
 

@@ -204,10 +204,13 @@ int hrl_destroy(hrl_handle *h) {
     return HRL_OK;
 }
 
+static bool needs_items(const DevCfg &dc) {
+    return dc.kind == HRL_ANT_GATHER || dc.kind == HRL_POINT_GATHER || (dc.kind == HRL_ANT_FLAGRUN && dc.flag_mtd > 0.f);
+}
+
 int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *stream) {
     if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_reset: null handle or buffer");
-    const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
-    if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: gather kinds need the items buffer");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist)");
     hipLaunchKernelGGL(reset_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_reset launch");
@@ -216,8 +219,7 @@ int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *st
 int hrl_step(hrl_handle *h, const hrl_buffers *b, void *stream) {
     if (!h || !b || !b->state || !b->aux || !b->obs || !b->actions || !b->reward || !b->done || !b->info)
         return fail(HRL_ERR_BAD_ARG, "hrl_step: null handle or buffer");
-    const bool gather = h->dc.kind == HRL_ANT_GATHER || h->dc.kind == HRL_POINT_GATHER;
-    if (gather && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: gather kinds need the items buffer");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist)");
     hipLaunchKernelGGL(step_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_step launch");

@@ -75,7 +75,7 @@ struct DevCfg {
     float plane_n[4][3], plane_d[4];
     int n_boxes;
     float box_lo[3], box_hi[3];
-    float flag_size;
+    float flag_size, flag_mtd; /* flag_mtd > 0: goals near the robot (ant_flagrun_env.py:80-89), kept in items[0..1] */
     int flag_max_targets, flag_timeout, flag_switch;
     int obs_dim, act_dim;
 };
@@ -1059,6 +1059,20 @@ HRL_DEV void flag_goal(const DevCfg &c, uint32_t ep, uint32_t k, float *gx, floa
     }
 }
 
+/* ant_flagrun_env.py:80-89 `create_close_target` with counter-based draws (max_target_dist mode): the k-th goal of episode
+ * `ep` of env `env`, per axis +-U(tol, max_target_dist / 2) around the robot's xy, redrawn until strictly inside the
+ * arena; one Philox block per attempt (two uniforms, two sign bits), at most 64 attempts, the last one kept */
+HRL_DEV void flag_close_goal(const DevCfg &c, long long env, uint32_t ep, uint32_t k, float rx, float ry, float *gx, float *gy) {
+    const float wb = c.flag_size / 2.f, half = c.flag_mtd / 2.f;
+    for (uint32_t a = 0; a < 64; ++a) {
+        uint32_t r[4];
+        philox4x32(c, env, ep, (5u << 16) | (k & 0xffffu), a, r);
+        *gx = (c.tol + (half - c.tol) * u01(r[0])) * ((r[2] & 1u) ? 1.f : -1.f) + rx;
+        *gy = (c.tol + (half - c.tol) * u01(r[1])) * ((r[3] & 1u) ? 1.f : -1.f) + ry;
+        if (-wb < *gx && *gx < wb && -wb < *gy && *gy < wb) break;
+    }
+}
+
 /* sizeable_enclosed_scene.py:63-97 `sense_walls`, one bin: the ray and all 7 maze lines are INFINITE lines
  * (intersection_utils.py:74-90), filtered by range and quadrant */
 HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, int i, bool arena) {
@@ -1094,7 +1108,10 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
     float rpy[3];
     quat_to_rpy(qp + 3, rpy);
     float tx = c.walk_tx, ty = c.walk_ty;
-    if (KIND == 5) flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &tx, &ty);
+    if (KIND == 5) { /* the goal being chased: from the shared list, or (max_target_dist mode) the one kept in items[0..1] */
+        if (c.flag_mtd > 0.f) { tx = L.items[0]; ty = L.items[1]; }
+        else flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &tx, &ty);
+    }
     if (KIND == 2 || KIND == 4) { /* maze kinds: the episode's target */
         const int ti = L.aux[3];
         tx = c.targets[0][0]; ty = c.targets[0][1];
@@ -1333,6 +1350,12 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
                 if (i < c.n_food + c.n_poison) respawn_item(c, env, ep, 1u, i, 0.f, 0.f, &px, &py);
                 L.items[2 * i] = px; L.items[2 * i + 1] = py;
             }
+        } else if (KIND == 5) {
+            if (c.flag_mtd > 0.f && lane < 48) { /* lanes 32..47: the items record = the current goal, zeros */
+                float px = 0.f, py = 0.f; /* reset -> next_target -> create_close_target around the start pose, new episode's stream */
+                if (lane == 32) flag_close_goal(c, env, ep + 1u, 1u, c.start_pos[0], c.start_pos[1], &px, &py);
+                L.items[2 * (lane - 32)] = px; L.items[2 * (lane - 32) + 1] = py;
+            }
         }
         if (lane < 16) L.u[lane] = 0.f;
         if (lane < 8) L.tau[lane] = 0.f;
@@ -1443,18 +1466,19 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             const float wtd = L.scal[3], pot = -wtd / c.dt, progress = pot - L.st[31];
             L.red[0] = pot;
             int steps = ((L.aux[3] >> 16) & 0x7fff) + 1, rewarded = (L.aux[3] >> 31) & 1, cur = L.aux[3] & 0xffff, retarget = 0;
+            const bool more_goals = c.flag_mtd > 0.f; /* max_target_dist mode never runs out of goals (:111-112) */
             rew = (alive + progress) * 1.f;
             done = idone;
             if (wtd < c.tol) {
                 if (!rewarded) { rew += 5000.f; rewarded = 1; }
                 if (c.flag_switch) {
-                    if (cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
+                    if (more_goals || cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
                 }
             }
             if (c.flag_timeout > 0 && c.flag_timeout <= steps) {
-                if (cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
+                if (more_goals || cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
             }
-            L.flags[4] = (int)((uint32_t)cur | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
+            L.flags[4] = (int)(((uint32_t)cur & 0xffffu) | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
             L.flags[3] = retarget;
         } else if (KIND == 4) { /* MjAnt.py:36-97, then ant_maze_mj_env.py:66-78 */
             const float alive = L.st[2] > 0.26f ? 1.f : -1.f;
@@ -1494,6 +1518,11 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
         if (lane == 8 && KIND == 5) L.aux[3] = L.flags[4];
+        if (lane == 9 && KIND == 5 && c.flag_mtd > 0.f && L.flags[3]) { /* set_target(*create_close_target()) around the robot's xy */
+            float gx, gy;
+            flag_close_goal(c, env, (uint32_t)L.aux[2], (uint32_t)L.flags[4] & 0xffffu, L.st[0], L.st[1], &gx, &gy);
+            L.items[0] = gx; L.items[1] = gy;
+        }
         if (lane >= 4 && lane < 8) {
             const int k = lane - 4;
             b.info[(size_t)e * 4 + k] = k == 0 ? L.scal[1] : (k == 1 ? L.scal[2] : (k == 2 ? L.red[1] : L.red[2]));

@@ -19,15 +19,17 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
                  num_envs=1, device='cuda:0'):
         assert (max_target_dist == 0 and max_targets > 0) or (max_targets <= 0 and max_target_dist > 0), \
             'cannot have both max_targets and max_target_dist set at the same time'  # ant_flagrun_env.py:17-18
-        if max_target_dist != 0 or manual_goal_creation:
-            raise NotImplementedError('max_target_dist / manual_goal_creation goal modes (ant_flagrun_env.py:80-99) are not '
+        if manual_goal_creation:
+            raise NotImplementedError('manual_goal_creation (goals pushed from outside, ant_flagrun_env.py:91-99,149-152) is not '
                                       'implemented on the device path')
         cfg = _lib.default_config(K.HRL_ANT_FLAGRUN, flag_size=float(size), tol=float(tolerance), flag_max_targets=int(max_targets),
+                                  flag_max_target_dist=float(max_target_dist),
                                   flag_timeout=int(timeout), flag_enclosed=int(bool(enclosed)), use_sensor=int(bool(use_sensor)),
                                   n_bins=int(sensor_bins), sensor_span=float(sensor_span), sensor_range=float(sensor_range),
                                   flag_switch_on_collision=int(bool(switch_flag_on_collision)),
                                   world_size=(float(size) + 2, float(size) + 2))
         cfg.centroid_static_sum[0] = -(float(size) + 2) / 2
         self.size, self.tol, self.max_targets, self.timeout, self.enclosed = size, tolerance, max_targets, timeout, enclosed
+        self.max_target_dist = max_target_dist
         self.use_sensor, self.n_bins, self.sensor_span, self.sensor_range, self.debug = use_sensor, sensor_bins, sensor_span, sensor_range, debug
         self._finish_init(cfg, num_envs, device, seed)

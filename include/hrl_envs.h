@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HRL_ABI_VERSION 2
+#define HRL_ABI_VERSION 3
 
 /* env kinds */
 #define HRL_ANT_FLAT 0     /* AntMjEnv: flat ground, obs 29 (envs/MjAnt.py:31-97)                        */
@@ -106,9 +106,13 @@ typedef struct hrl_config {
     float walk_target[2];      /* flat: (1e3, 0) upstream default; maze: overwritten by the episode's target */
     /* flagrun task (ant_flagrun_env.py:14-16); tolerance -> tol, sensor_bins -> n_bins, use_sensor/sensor_* shared */
     float flag_size;           /* 10: targets ~ U(-size/2, size/2)^2, arena (size+2)^2 */
-    int32_t flag_max_targets;  /* 100 goals per episode; the episode ends when they run out */
+    int32_t flag_max_targets;  /* 100 goals per episode; the episode ends when they run out (<= 0 with flag_max_target_dist > 0) */
     int32_t flag_timeout;      /* 200 steps without reaching the goal -> next goal */
     int32_t flag_switch_on_collision, flag_enclosed;
+    /* > 0 (with flag_max_targets <= 0): every goal is drawn near the robot, per axis +-U(tol, max_target_dist / 2) around
+     * its position, redrawn until it lies inside the arena (ant_flagrun_env.py:80-89); the episode then never runs out
+     * of goals.  The current goal is kept in items[0..1], so `items` must be provided. */
+    float flag_max_target_dist;
     hrl_model model;
 } hrl_config;
 

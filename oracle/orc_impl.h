@@ -413,6 +413,19 @@ int FN(orc_flag_create_target)(REAL size, const REAL *draws, int n_draws, REAL *
     return -1;
 }
 
+/* ant_flagrun_env.py:80-89 `create_close_target`: per axis uniform(tol, max_target_dist / 2) * (randint(0, 2) * 2 - 1),
+ * added to the robot's xy, redrawn until strictly inside (-size/2, size/2)^2.  `u` = the uniforms in [0, 1) behind the
+ * uniform() calls and `b` = the randint results, two of each per attempt, in call order; returns the attempts used or -1. */
+int FN(orc_flag_create_close_target)(REAL size, REAL tol, REAL mtd, const REAL *robot_xy, const REAL *u, const int *b, int n_attempts, REAL *goal) {
+    REAL wb = size / 2;
+    for (int k = 0; k < n_attempts; ++k) {
+        REAL gx = (tol + (mtd / 2 - tol) * u[2 * k]) * R_(b[2 * k] * 2 - 1) + robot_xy[0];
+        REAL gy = (tol + (mtd / 2 - tol) * u[2 * k + 1]) * R_(b[2 * k + 1] * 2 - 1) + robot_xy[1];
+        if (-wb < gx && gx < wb && -wb < gy && gy < wb) { goal[0] = gx; goal[1] = gy; return k + 1; }
+    }
+    return -1;
+}
+
 /* ant_flagrun_env.py:162-204 `step` after `super().step(a)`: goal reward, retargeting, timeout, running out of goals.
  * io: steps (steps_since_goal_change), rewarded, goals_left.  *retarget = 1 when next_target() succeeded. */
 void FN(orc_flagrun_task)(const hrl_config *cfg, REAL inner_rew, int inner_done, REAL walk_target_dist, int *steps,
@@ -1062,6 +1075,24 @@ static void FN(flag_goal)(const hrl_config *cfg, uint32_t ep, uint32_t k, REAL *
     }
 }
 void FN(orc_flag_goal)(const hrl_config *cfg, int ep, int k, REAL *g) { FN(flag_goal)(cfg, (uint32_t)ep, (uint32_t)k, g); } /* tests */
+/* max_target_dist mode: the k-th goal of episode `ep` of env `env`, drawn around the robot's xy (create_close_target,
+ * ant_flagrun_env.py:80-89); one Philox block per attempt (two uniforms, two sign bits), at most 64 attempts, the last kept */
+static void FN(flag_close_goal)(const hrl_config *cfg, int64_t env, uint32_t ep, uint32_t k, const REAL *robot_xy, REAL *g) {
+    REAL wb = R_(cfg->flag_size) / 2, tol = R_(cfg->tol), half = R_(cfg->flag_max_target_dist) / 2;
+    for (uint32_t a = 0; a < 64; ++a) {
+        uint32_t r[4];
+        orc_philox4x32(cfg->seed, env, ep, (5u << 16) | (k & 0xffffu), a, r);
+        g[0] = (tol + (half - tol) * FN(u01)(r[0])) * ((r[2] & 1u) ? R_(1) : R_(-1)) + robot_xy[0];
+        g[1] = (tol + (half - tol) * FN(u01)(r[1])) * ((r[3] & 1u) ? R_(1) : R_(-1)) + robot_xy[1];
+        if (-wb < g[0] && g[0] < wb && -wb < g[1] && g[1] < wb) break;
+    }
+}
+void FN(orc_flag_close_goal)(const hrl_config *cfg, int64_t env, int ep, int k, const REAL *robot_xy, REAL *g) { FN(flag_close_goal)(cfg, env, (uint32_t)ep, (uint32_t)k, robot_xy, g); } /* tests */
+/* the goal the env is chasing: from the shared list, or (max_target_dist mode) the one kept in items[0..1] */
+static void FN(flag_current_goal)(const hrl_config *cfg, const REAL *items, const int32_t *aux, REAL *g) {
+    if (cfg->flag_max_target_dist > 0) { g[0] = items[0]; g[1] = items[1]; }
+    else FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)aux[3] & 0xffffu, g);
+}
 static const REAL FN(maze_lines)[7][4] = { /* MazeScene.bounds: maze_scene.py:15-21 + sizeable_enclosed_scene.py:28-34 */
     {5, 9, -5, 9}, {5, 9, 5, -9}, {-5, -9, -5, 9}, {-5, -9, 5, -9}, {1, 2, 1, -2}, {-5, -2, -5, 2}, {-5, -2, 1, -2}};
 
@@ -1091,7 +1122,7 @@ static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *item
     REAL s28[28], rpy[3], wtd, tgt[2] = {R_(cfg->walk_target[0]), R_(cfg->walk_target[1])};
     int nlim;
     if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { tgt[0] = R_(cfg->targets[aux[3]][0]); tgt[1] = R_(cfg->targets[aux[3]][1]); }
-    if (cfg->env_kind == HRL_ANT_FLAGRUN) FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)aux[3] & 0xffffu, tgt);
+    if (cfg->env_kind == HRL_ANT_FLAGRUN) FN(flag_current_goal)(cfg, items, aux, tgt);
     FN(orc_ant_calc_state)(cfg, &E->K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
     if (wtd_out) *wtd_out = wtd;
     if (nlim_out) *nlim_out = nlim;
@@ -1152,6 +1183,12 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
         for (int i = 0; i < cfg->n_food + cfg->n_poison; ++i) FN(respawn_item)(cfg, env, ep, 1, i, origin, items + 2 * i);
     }
     aux[0] = 0; aux[2] = (int32_t)(ep + 1); /* NB: the flagrun goal stream is keyed by the NEW episode index */
+    if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_max_target_dist > 0) { /* reset -> next_target -> create_close_target (:153, :111-112) */
+        REAL g2[2];
+        for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+        FN(flag_close_goal)(cfg, env, ep + 1, 1, st, g2);
+        items[0] = g2[0]; items[1] = g2[1];
+    }
     REAL feet[4] = {0, 0, 0, 0}, wtd = 0;
     FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0);
     /* upstream calc_potential = -dist/dt; only the flat and maze kinds use it */
@@ -1213,17 +1250,24 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
                                                      (ant_flagrun_env.py:133-135), then ant_flagrun_env.py:162-204 */
         REAL wtd, s28[28], rpy[3], tgt[2];
         int nlim, steps = (aux[3] >> 16) & 0x7fff, rewarded = (aux[3] >> 31) & 1, cur = aux[3] & 0xffff, retarget;
-        FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)cur, tgt);
+        const int close_mode = cfg->flag_max_target_dist > 0;
+        FN(flag_current_goal)(cfg, items, aux, tgt);
         FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
         REAL alive = (s28[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
         int idone = alive < 0;
         for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
         REAL pot = -wtd / (K->h * R_(K->nsub)), progress = pot - st[HRL_POTENTIAL_OFF];
         st[HRL_POTENTIAL_OFF] = pot; /* next_target() re-reads the same stale potential (:116), i.e. leaves it unchanged */
-        int goals_left = cfg->flag_max_targets - cur;
+        const int budget = close_mode ? (1 << 20) : cfg->flag_max_targets; /* max_target_dist mode never runs out (:111-112) */
+        int goals_left = budget - cur;
         FN(orc_flagrun_task)(cfg, alive + progress, idone, wtd, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
-        cur = cfg->flag_max_targets - goals_left;
-        aux[3] = (int32_t)((uint32_t)cur | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
+        cur = budget - goals_left;
+        if (close_mode && retarget) { /* set_target(*create_close_target()): around the robot's current xy (:80-89, :112) */
+            REAL g2[2];
+            FN(flag_close_goal)(cfg, env, (uint32_t)aux[2], (uint32_t)cur, st, g2);
+            items[0] = g2[0]; items[1] = g2[1];
+        }
+        aux[3] = (int32_t)(((uint32_t)cur & 0xffffu) | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
         FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0); /* calc_state w.r.t. the (possibly new) goal */
     } else if (cfg->env_kind == HRL_ANT_MAZE_MJ) { /* MjAnt.py:36-97 then ant_maze_mj_env.py:66-78 */
         REAL wtd, s28[28], rpy[3], inner, tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};

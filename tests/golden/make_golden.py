@@ -533,6 +533,54 @@ def main():
         ct.append({'size': self.size, 'draws': self.mpi_common_rand.log, 'goal': [float(g[0]), float(g[1])]})
     G['flagrun_create_target'] = ct
 
+    # create_close_target (ant_flagrun_env.py:80-89) with the [0, 1) uniforms and the randint results it consumed, and the
+    # step bookkeeping in max_target_dist mode (next_target -> create_close_target, :111-112: goals never run out)
+    class LogR:
+        def __init__(self, seed): self.rs = np.random.RandomState(seed); self.u = []; self.b = []
+        def uniform(self, lo, hi):  # numpy: lo + (hi - lo) * random_sample()
+            u01 = float(self.rs.random_sample()); self.u.append(u01); return lo + (hi - lo) * u01
+        def randint(self, lo, hi):
+            v = int(self.rs.randint(lo, hi)); self.b.append(v); return v
+    cc = []
+    for k in range(40):
+        lrs = np.random.RandomState(15000 + k)
+        size = 10.0 if k % 3 else 3.0
+        tol, mtd = 0.5, float(lrs.uniform(1.5, 6.0))
+        pos = lrs.uniform(-size / 2, size / 2, 3) * (0.98 if k % 2 else 0.5)   # odd cases hug the arena edge -> rejections
+        self = NS(size=size, tol=tol, max_target_dist=mtd, mpi_common_rand=LogR(15500 + k), robot=NS(body_real_xyz=pos))
+        g = AntFlagrunBulletEnv.create_close_target(self)
+        cc.append({'size': size, 'tol': tol, 'max_target_dist': mtd, 'robot_xy': [float(pos[0]), float(pos[1])],
+                   'u': self.mpi_common_rand.u, 'b': self.mpi_common_rand.b, 'goal': [float(g[0]), float(g[1])]})
+    G['flagrun_create_close_target'] = cc
+    fc = []
+    for k in range(30):
+        lrs = np.random.RandomState(16000 + k)
+        tol, timeout = 0.5, int(lrs.choice([5, 200]))
+        switch = bool(lrs.randint(0, 2)) if k % 4 == 0 else True
+        steps0 = int(lrs.randint(0, 7)); rewarded0 = bool(lrs.randint(0, 2)) if not switch else False
+        wtd = float(lrs.uniform(0.0, 1.0)) if k % 2 == 0 else float(lrs.uniform(0.5, 6.0))
+        inner_r = float(lrs.uniform(-2, 2)); inner_d = bool(lrs.randint(0, 8) == 0)
+        s_old = lrs.uniform(-1, 1, 28).astype(np.float32); s_new = lrs.uniform(-1, 1, 28).astype(np.float32)
+        pos = lrs.uniform(-4, 4, 3)
+        robot = NS(walk_target_dist=wtd, walk_target_x=0.0, walk_target_y=0.0, body_real_xyz=pos,
+                   robot_body=NS(get_position=lambda: pos), calc_potential=lambda: -wtd / 0.0165,
+                   calc_state=lambda: s_new.copy())
+        self = AntFlagrunBulletEnv.__new__(AntFlagrunBulletEnv)
+        rnd = LogR(16500 + k)
+        self.__dict__.update(dict(robot=robot, tol=tol, timeout=timeout, switch_flag_on_collision=switch, max_targets=0,
+                                  max_target_dist=3.0, size=10, mpi_common_rand=rnd,
+                                  goals=[], steps_since_goal_change=steps0, _rewarded=rewarded0, debug=False,
+                                  use_sensor=False, isRender=False, flag=None, walk_target_x=1.0, walk_target_y=2.0,
+                                  _sq_dist_goal=3.0, _goal_start_pos=np.array([0.5, 0.5]), potential=-77.0,
+                                  _super_step_result=(s_old.copy(), inner_r, inner_d, {})))
+        obs, r, d, info = AntFlagrunBulletEnv.step(self, np.zeros(8))
+        fc.append({'tol': tol, 'timeout': timeout, 'switch': switch, 'steps_before': steps0, 'rewarded_before': rewarded0,
+                   'walk_target_dist': wtd, 'inner_rew': inner_r, 'inner_done': inner_d, 'rew': float(r), 'done': bool(d),
+                   'steps_after': int(self.steps_since_goal_change), 'rewarded_after': bool(self._rewarded),
+                   'retargeted': bool('target' in info), 'robot_xy': [float(pos[0]), float(pos[1])], 'u': rnd.u, 'b': rnd.b,
+                   'target_after': [float(self.walk_target_x), float(self.walk_target_y)]})
+    G['flagrun_close_step'] = fc
+
     for name, val in G.items():
         with open(os.path.join(OUT_DIR, name + '.json'), 'w') as f:
             json.dump(val, f, allow_nan=True)

@@ -133,6 +133,41 @@ def test_flagrun_goals_rewards_and_exhaustion():
     assert o.obs.shape == (n, 36) and hits >= 4 * n and dones >= n
 
 
+def test_flagrun_close_goal_mode():
+    """max_target_dist mode (ant_flagrun_env.py:80-89,111-112): goals drawn around the robot, kept in items[0..1], never run out."""
+    n = 16
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=11, auto_reset=1, flag_max_targets=0, flag_max_target_dist=3.0,
+                             flag_timeout=7)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    assert np.array_equal(o.items, e.items) and np.array_equal(o.obs, e.obs)
+    g0 = o.items[:, 0:2].copy()
+    # first goal: per axis tol <= |offset from the start pose (0, 0)| <= max_target_dist / 2, inside the arena
+    assert np.all(np.abs(g0) >= 0.5 - 1e-6) and np.all(np.abs(g0) <= 1.5 + 1e-6) and len({tuple(r) for r in g0.tolist()}) > 1
+    rng = np.random.RandomState(5)
+    hits = retargets = 0
+    for t in range(40):
+        if t % 5 == 3:  # teleport onto the goal (walk_target_dist is measured from the parts centroid: 13 links + floor + wall at (-6, 0))
+            g = o.items[:, 0:2]
+            o.state[:, 0] = np.clip((15 * g[:, 0] + 6) / 13, -4.2, 4.2); o.state[:, 1] = np.clip(15 * g[:, 1] / 13, -4.2, 4.2)
+            o.state[:, 2] = 0.75; o.state[:, 3:7] = (0, 0, 0, 1); o.state[:, 7:29] = 0  # a clean drop pose, clear of ground and walls
+            e.state[...] = o.state
+        before = o.items[:, 0:2].copy()
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done'):
+            assert np.array_equal(getattr(o, name), getattr(e, name)), (t, name)
+        moved = np.any(o.items[:, 0:2] != before, axis=1) & ~o.done.astype(bool)
+        retargets += int(moved.sum()); hits += int((o.rew > 1000).sum())
+        # a fresh goal lies within max_target_dist / 2 per axis of the robot and strictly inside the arena
+        d = np.abs(o.items[moved, 0:2] - o.state[moved, 0:2])
+        assert np.all(d <= 1.5 + 1e-5) and np.all(d >= 0.5 - 1e-5) and np.all(np.abs(o.items[moved, 0:2]) < 5.0)
+    assert hits >= n and retargets >= 4 * n  # reached goals + 7-step timeouts; the episode never ends for lack of goals
+    bad = orc.default_config(K.HRL_ANT_FLAGRUN, flag_max_targets=5, flag_max_target_dist=2.0)
+    import ctypes as C
+    assert b'exactly one' in emu_env.lib().emu_validate(C.byref(bad))
+
+
 def test_validation_errors():
     import ctypes as C
     L = emu_env.lib()
@@ -161,6 +196,7 @@ def test_product_defaults_equal_oracle_defaults():
     (K.HRL_ANT_MAZE, 5, dict(target_encoding=1, sense_walls=0, tol=3.0, targ_dist_rew=1, max_steps=20, done_at_target=0)),
     (K.HRL_ANT_MAZE_MJ, 4, dict(inner_rew_weight=0.5, n_bins=6)),
     (K.HRL_ANT_GATHER, 3, dict(model_solver_iters=2, model_frame_skip=2, model_limit_margin=0.1)),
+    (K.HRL_ANT_FLAGRUN, 7, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
 ])
 def test_non_default_configs_bit_exact(kind, n, kw):
     cfg = orc.default_config(kind, num_envs=n, seed=17, auto_reset=1, max_episode_steps=25, **kw)

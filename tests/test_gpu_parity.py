@@ -213,6 +213,7 @@ CONFIG_MATRIX = [
     (K.HRL_ANT_MAZE, 31, dict(target_encoding=1, sense_walls=0, tol=3.0, targ_dist_rew=1, max_steps=20, done_at_target=0)),
     (K.HRL_ANT_MAZE_MJ, 40, dict(inner_rew_weight=0.5, n_bins=6)),
     (K.HRL_ANT_FLAGRUN, 48, dict(use_sensor=1, n_bins=8, flag_timeout=9, flag_max_targets=3)),
+    (K.HRL_ANT_FLAGRUN, 21, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
     (K.HRL_ANT_FLAT, 1, dict()),
     (K.HRL_ANT_GATHER, 3, dict(model_solver_iters=2, model_frame_skip=2, model_limit_margin=0.1)),
 ]

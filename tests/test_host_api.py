@@ -84,6 +84,7 @@ def test_env_classes_mirror_reference_constructor_api():
     assert H.AntFlagrunBulletEnv(use_sensor=True).observation_space.shape == (36,)
     with pytest.raises(AssertionError):
         H.AntFlagrunBulletEnv(max_targets=5, max_target_dist=3)                  # ant_flagrun_env.py:17-18
+    assert H.AntFlagrunBulletEnv(max_targets=0, max_target_dist=3)._cfg.flag_max_target_dist == 3.0   # :80-89 goals near the robot
     with pytest.raises(ValueError):
         H.AntMazeBulletEnv(target_encoding=5)                                    # PositionEncoding(5), utils.py:66-68
     assert isinstance(H.make('AntMazeBulletEnv-v0', tol=2.0), H.AntMazeBulletEnv)

@@ -245,3 +245,37 @@ def test_flagrun_step_bookkeeping_and_targets():
         assert used == len(c['draws'])
         np.testing.assert_allclose(g, c['goal'], atol=1e-12)
         assert np.linalg.norm(g) >= 0.5
+
+
+def test_flagrun_close_targets():
+    """ant_flagrun_env.py:80-89 `create_close_target` and the step bookkeeping in max_target_dist mode (:111-112)."""
+    def close_target(c, size, mtd):
+        g = np.zeros(2)
+        n = len(c['u']) // 2
+        used = orc.lib().orc_flag_create_close_target_f64(C.c_double(size), C.c_double(c['tol']), C.c_double(mtd), orc.ptr(arr(c['robot_xy'])),
+                                                          orc.ptr(arr(c['u'])), np.asarray(c['b'], np.int32).ctypes.data_as(C.c_void_p), n, orc.ptr(g))
+        assert used == n  # accepted exactly on the attempt the reference stopped at
+        return g
+    rejections = 0
+    for c in load('flagrun_create_close_target'):
+        g = close_target(c, c['size'], c['max_target_dist'])
+        np.testing.assert_allclose(g, c['goal'], atol=1e-12)
+        assert np.all(np.abs(g) < c['size'] / 2)
+        rejections += len(c['u']) // 2 - 1
+    assert rejections > 10  # the edge-hugging cases exercised the redraw loop
+    n_retarget = 0
+    for c in load('flagrun_close_step'):
+        cfg = orc.default_config(K.HRL_ANT_FLAGRUN, tol=c['tol'], flag_timeout=c['timeout'], flag_switch_on_collision=int(c['switch']),
+                                 flag_max_targets=0, flag_max_target_dist=3.0)
+        steps = C.c_int(c['steps_before']); rewarded = C.c_int(int(c['rewarded_before'])); left = C.c_int(1 << 20)
+        rew = C.c_double(); done = C.c_int(); retarget = C.c_int()
+        orc.lib().orc_flagrun_task_f64(C.byref(cfg), C.c_double(c['inner_rew']), int(c['inner_done']), C.c_double(c['walk_target_dist']),
+                                       C.byref(steps), C.byref(rewarded), C.byref(left), C.byref(rew), C.byref(done), C.byref(retarget))
+        assert rew.value == pytest.approx(c['rew'], abs=1e-9) and bool(done.value) == c['done'] == c['inner_done']  # never out of goals
+        assert steps.value == c['steps_after'] and bool(rewarded.value) == c['rewarded_after']
+        assert bool(retarget.value) == c['retargeted']
+        if c['retargeted']:
+            n_retarget += 1
+            np.testing.assert_allclose(close_target(c, 10.0, 3.0), c['target_after'], atol=1e-12)
+    assert n_retarget >= 8
+
