@@ -10,14 +10,15 @@
  *   raw-state obs + locomotion reward                             MjAnt.py:17-25,36-97, ant_maze_mj_env.py:57-78
  *   goal chasing (reward, retarget, timeout)                      ant_flagrun_env.py:162-204
  * written as a sequence of wave-wide PHASES.  A phase is a function of (lane, LDS); lanes communicate only
- * through the per-wave LDS record `WaveLds` between phases (plus three wave primitives supplied by the executor:
- * a ballot/prefix compaction, a lane broadcast and per-lane persistent registers).  The executor `X`
+ * through the per-wave LDS record `WaveLds` between phases (plus the wave primitives supplied by the executor:
+ * a ballot/prefix compaction, a solver-row lane broadcast, a lane shuffle and per-lane persistent registers).  The executor `X`
  * is the HIP wave (hrl_hip.hip: one 64-thread workgroup = one wavefront = one env, phases separated by a
  * workgroup barrier); tests/emu provides a lock-step host executor so the same phases can be checked on a box
  * without a GPU -- that executor is test infrastructure and is never used by the product.
  *
  * Lane maps used by the phases:
- *   leg map : leg = lane >> 4 (four 16-lane rows, one per leg; the 16 lanes of a row compute the same values)
+ *   body map: lane >> 2 = rigid body (0-3 feet, 4-7 aux bodies, 8.. torso): phases K1, K2, B; the lanes of a group compute the same values
+ *   leg map : leg = lane >> 4 (four 16-lane rows, one per leg)
  *   dof map : dof = lane & 15 (0-2 omega, 3-5 v, 6-13 joint rates, 14-15 zero padding)
  *   sphere map: lane = contact sphere x lateral surface (ballot-compacted into contacts)
  *   row map : lane = constraint row (limits, contact normals, friction pairs; <= 44 rows), its solver state in registers
