@@ -43,7 +43,11 @@ class BatchedEnv:
             _lib.lib().hrl_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
