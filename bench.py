@@ -174,7 +174,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': profiled_traffic(args.kind, n), 'kernel': 'k_step', 'kernel_avg_us': launch_s * 1e6,
                          'algorithmic_bytes_per_launch': ALG_BYTES[args.kind] * n,
-                         'note': 'latency/VALU-bound by construction (~1.4e5 flop per env-step, ~240 flop/B): see DESIGN.md 5'},
+                         'note': 'VALU-issue/latency-bound by construction (~9.4e3 VALU wave-instructions, ~1e5 flop per env-step, ~170 flop/B): see DESIGN.md 5'},
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.kind)
