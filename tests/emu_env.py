@@ -27,9 +27,9 @@ def ptr(a):
 
 
 class EmuEnv:
-    def __init__(self, cfg, reverse=False):
-        self.cfg, self.reverse = cfg, int(reverse)
-        L = lib()
+    def __init__(self, cfg, reverse=False, asan=False):
+        self.cfg, self.reverse, self.asan = cfg, int(reverse), asan
+        L = lib(asan)
         n = cfg.num_envs
         self.N, self.od, self.ad = n, L.emu_obs_dim(C.byref(cfg)), L.emu_act_dim(C.byref(cfg))
         f = np.float32
@@ -49,13 +49,13 @@ class EmuEnv:
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         b = self._bufs()
-        rc = lib().emu_reset(C.byref(self.cfg), C.byref(b), ptr(m), self.reverse)
-        assert rc == 0, lib().emu_validate(C.byref(self.cfg))
+        rc = lib(self.asan).emu_reset(C.byref(self.cfg), C.byref(b), ptr(m), self.reverse)
+        assert rc == 0, lib(self.asan).emu_validate(C.byref(self.cfg))
         return self.obs
 
     def step(self, actions):
         self.act[...] = np.asarray(actions, np.float32).reshape(self.N, self.ad)
         b = self._bufs()
-        rc = lib().emu_step(C.byref(self.cfg), C.byref(b), self.reverse)
+        rc = lib(self.asan).emu_step(C.byref(self.cfg), C.byref(b), self.reverse)
         assert rc == 0
         return self.obs, self.rew, self.done, self.info
