@@ -59,3 +59,46 @@ def test_native_library_is_loaded_not_a_fallback():
     assert _lib.lib().hrl_backend() == b'hip-gfx950'
     maps = open('/proc/self/maps').read()
     assert 'libhrl_envs_hip.so' in maps
+
+
+def test_c_abi_error_paths():
+    """The boundary fails loudly and names the cause: null buffers, a missing items record, bad configs."""
+    import ctypes as C
+    from hrl_pybullet_envs_amd import _lib
+    L = _lib.lib()
+    n = 8
+    for kind, kw in ((K.HRL_ANT_GATHER, {}), (K.HRL_ANT_FLAGRUN, dict(flag_max_targets=0, flag_max_target_dist=3.0))):
+        cfg = _lib.default_config(kind, num_envs=n, seed=0, **kw)
+        h = C.c_void_p()
+        assert L.hrl_create(C.byref(cfg), C.byref(h)) == K.HRL_OK
+        od, ad = L.hrl_obs_dim(C.byref(cfg)), L.hrl_act_dim(C.byref(cfg))
+        st = torch.zeros(n, 32, device='cuda'); it = torch.zeros(n, 32, device='cuda'); aux = torch.zeros(n, 4, dtype=torch.int32, device='cuda')
+        obs = torch.zeros(n, od, device='cuda'); act = torch.zeros(n, ad, device='cuda'); rew = torch.zeros(n, device='cuda')
+        done = torch.zeros(n, dtype=torch.uint8, device='cuda'); info = torch.zeros(n, 4, device='cuda')
+        no_items = K.hrl_buffers(st.data_ptr(), None, aux.data_ptr(), act.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr())
+        assert L.hrl_reset(h, C.byref(no_items), None, None) == K.HRL_ERR_BAD_ARG and b'items' in L.hrl_last_error()
+        assert L.hrl_step(h, C.byref(no_items), None) == K.HRL_ERR_BAD_ARG and b'items' in L.hrl_last_error()
+        ok = K.hrl_buffers(st.data_ptr(), it.data_ptr(), aux.data_ptr(), None, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr())
+        assert L.hrl_reset(h, C.byref(ok), None, None) == K.HRL_OK
+        assert L.hrl_step(h, C.byref(ok), None) == K.HRL_ERR_BAD_ARG  # no actions
+        torch.cuda.synchronize()
+        assert L.hrl_destroy(h) == K.HRL_OK
+    bad = _lib.default_config(K.HRL_ANT_FLAGRUN, flag_max_targets=5, flag_max_target_dist=2.0)
+    h = C.c_void_p()
+    assert L.hrl_create(C.byref(bad), C.byref(h)) == K.HRL_ERR_BAD_ARG and b'exactly one' in L.hrl_last_error()
+
+
+def test_flagrun_close_goal_class():
+    """AntFlagrunBulletEnv(max_targets=0, max_target_dist=d): goals around the robot (ant_flagrun_env.py:80-89), never out of goals."""
+    import hrl_pybullet_envs_amd as H
+    env = H.AntFlagrunBulletEnv(max_targets=0, max_target_dist=3, timeout=10, num_envs=64, seed=2)
+    ob = env.reset()
+    assert ob.shape == (64, 28)
+    goals = set()
+    for t in range(60):
+        ob, rew, done, info = env.step(torch.rand(64, 8, device='cuda') * 2 - 1)
+        g = env._env.items[:, 0:2].cpu().numpy(); xy = env._env.state[:, 0:2].cpu().numpy()
+        assert np.all(np.abs(g) < 5.0) and bool(torch.isfinite(ob).all())
+        goals.add(tuple(np.round(g[0], 4)))
+    assert len(goals) >= 4  # the 10-step timeout moved env 0's goal several times
+    env.close()
