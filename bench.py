@@ -6,7 +6,7 @@ A "step" is one hrl_step() over the shard's envs: one HIP kernel launch that adv
 configs[2], the config the metric is quoted on); weak scaling: every rank owns 4096 envs, RNG keyed by global id.
 Inputs (state, items, pre-generated U(-1,1) actions) are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--kind gather|flat|maze|point]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--kind gather|flat|maze|point|maze_mj|flagrun]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
@@ -28,11 +28,13 @@ from hrl_pybullet_envs_amd import _lib  # noqa: E402
 from hrl_pybullet_envs_amd.dist import ReturnGatherer, init_distributed  # noqa: E402
 from hrl_pybullet_envs_amd.vec_env import BatchedEnv  # noqa: E402
 
-KINDS = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER}
+KINDS = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER,
+         'maze_mj': K.HRL_ANT_MAZE_MJ, 'flagrun': K.HRL_ANT_FLAGRUN}
 NAMES = {'flat': 'AntMjEnv (flat ground)', 'gather': 'AntGatherBulletEnv-v0', 'maze': 'AntMazeBulletEnv-v0',
-         'point': 'PointGatherBulletEnv-v0'}
+         'point': 'PointGatherBulletEnv-v0', 'maze_mj': 'AntMazeMjEnv-v0', 'flagrun': 'AntFlagrunBulletEnv-v0'}
 # algorithmic HBM bytes per env-step, fp32, state read once + written once (SURVEY.md 8d / BASELINE.md 4)
-ALG_BYTES = {'gather': 581, 'flat': 385, 'maze': 429, 'point': 317}
+ALG_BYTES = {'gather': 581, 'flat': 385, 'maze': 429, 'point': 317,
+             'maze_mj': 148 + 8 + 116 + 240 + 5, 'flagrun': 148 + 4 + 116 + 112 + 5}  # same accounting: read state+act(+target/goal index), write state+obs+rew+done
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
