@@ -167,7 +167,7 @@ HRL_DEV float dot6(const float *a, const float *b) {
 /* sin and cos for the dynamics (joint rotations, quaternion increment), specified operation by operation so that
  * every fp32 implementation of the step produces the same bits: quadrant k = rint(x * 2/pi), three-term
  * Cody-Waite reduction r = x - k*pi/2, then the classic single-precision minimax polynomials on [-pi/4, pi/4].
- * Accurate to ~1.5 ulp for |x| < 100; the library sinf/cosf are only used for observations. */
+ * Accurate to ~1.5 ulp for |x| < 100. */
 HRL_DEV void sincos_spec(float x, float *sn, float *cs) {
     const float k = rintf(x * 0.636619772367581343f);
     float r = fma_(-k, 1.5703125f, x);
@@ -185,6 +185,29 @@ HRL_DEV void sincos_spec(float x, float *sn, float *cs) {
     *sn = (q & 2) ? -s1 : s1;
     *cs = ((q + 1) & 2) ? -c1 : c1;
 }
+HRL_DEV float sin_spec(float x) { float s, c; sincos_spec(x, &s, &c); return s; }
+HRL_DEV float cos_spec(float x) { float s, c; sincos_spec(x, &s, &c); return c; }
+/* atan2 and asin of the observation pipeline, specified like sincos_spec so that observations, too, are the same bits
+ * on every fp32 implementation: a = min(|x|,|y|) / max(|x|,|y|) in [0, 1]; above tan(pi/8) reduced once more by
+ * atan(a) = pi/4 + atan((a-1)/(a+1)); degree-9 odd minimax polynomial on [-tan(pi/8), tan(pi/8)]; then the octant,
+ * half-plane and sign.  Max error 2.8e-7 rad.  atan2(0, 0) = 0. */
+HRL_DEV float atan2_spec(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax < ay ? ax : ay;
+    const float a = mx == 0.0f ? 0.0f : mn / mx;
+    const bool big = a > 0.4142135679721832275390625f;
+    const float t = big ? (a - 1.0f) / (a + 1.0f) : a;
+    const float z = t * t;
+    float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fma_(p, z, 1.99777106478e-1f);
+    p = fma_(p, z, -3.33329491539e-1f);
+    float r = fma_(p * z, t, t);
+    if (big) r = 0.785398185253143310546875f + r;
+    if (ay > ax) r = 1.57079637050628662109375f - r;
+    if (x < 0.0f) r = 3.1415927410125732421875f - r;
+    return y < 0.0f ? -r : r;
+}
+HRL_DEV float asin_spec(float x) { return atan2_spec(x, sqrtf((1.0f - x) * (1.0f + x))); }
 /* columns of the rotation matrix of the unit quaternion (x, y, z, w) */
 HRL_DEV void quat_axes(float x, float y, float z, float w, float *X, float *Y, float *Z) {
     X[0] = fma_(-2.f, fma_(y, y, z * z), 1.f); X[1] = 2.f * fma_(x, y, w * z); X[2] = 2.f * fma_(x, z, -(w * y));
@@ -984,13 +1007,13 @@ HRL_DEV void quat_to_rpy(const float *qq, float *rpy) {
     float x = qq[0], y = qq[1], z = qq[2], w = qq[3];
     float sarg = -2.f * (x * z - w * y);
     const float hp = 1.5707963267948966f;
-    if (sarg <= -0.99999f) { rpy[0] = 0.f; rpy[1] = -hp; rpy[2] = 2.f * atan2f(x, -y); }
-    else if (sarg >= 0.99999f) { rpy[0] = 0.f; rpy[1] = hp; rpy[2] = 2.f * atan2f(-x, y); }
+    if (sarg <= -0.99999f) { rpy[0] = 0.f; rpy[1] = -hp; rpy[2] = 2.f * atan2_spec(x, -y); }
+    else if (sarg >= 0.99999f) { rpy[0] = 0.f; rpy[1] = hp; rpy[2] = 2.f * atan2_spec(-x, y); }
     else {
         float sqx = x * x, sqy = y * y, sqz = z * z, sqw = w * w;
-        rpy[0] = atan2f(2.f * (y * z + w * x), ((sqw - sqx) - sqy) + sqz);
-        rpy[1] = asinf(sarg);
-        rpy[2] = atan2f(2.f * (x * y + w * z), ((sqw + sqx) - sqy) - sqz);
+        rpy[0] = atan2_spec(2.f * (y * z + w * x), ((sqw - sqx) - sqy) + sqz);
+        rpy[1] = asin_spec(sarg);
+        rpy[2] = atan2_spec(2.f * (x * y + w * z), ((sqw + sqx) - sqy) - sqz);
     }
 }
 /* ant_gather_env.py:148-155: python `%` then fold to (-pi, pi] */
@@ -1081,7 +1104,7 @@ HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, in
     float phi;
     if (c.span_is_2pi) phi = half_pi + yaw + ((float)(i + 1) / (float)c.n_bins) * c.sensor_span;
     else phi = half_pi + yaw + ((float)i / (float)(c.n_bins - 1)) * c.sensor_span;
-    const float svx = rx + c.sensor_range * cosf(phi), svy = ry + c.sensor_range * sinf(phi);
+    const float svx = rx + c.sensor_range * cos_spec(phi), svy = ry + c.sensor_range * sin_spec(phi);
     const int sq = quadrant(svx - rx, svy - ry);
     float best = 0.f;
     for (int l = 0; l < (arena ? 4 : 7); ++l) {
@@ -1136,10 +1159,10 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
      * distance: skip their transcendental work there */
     float sin_ang = 0.f, cos_ang = 0.f, wtd = 0.f;
     if (KIND != 1) {
-        const float theta = atan2f(dy, dx), ang = theta - rpy[2];
-        wtd = sqrtf(dy * dy + dx * dx); sin_ang = sinf(ang); cos_ang = cosf(ang);
+        const float theta = atan2_spec(dy, dx), ang = theta - rpy[2];
+        wtd = sqrtf(dy * dy + dx * dx); sin_ang = sin_spec(ang); cos_ang = cos_spec(ang);
     }
-    const float cs = cosf(-rpy[2]), sn = sinf(-rpy[2]);
+    const float cs = cos_spec(-rpy[2]), sn = sin_spec(-rpy[2]);
     const float vx = cs * qv[0] - sn * qv[1], vy = sn * qv[0] + cs * qv[1], vz = qv[2];
     int nlim = 0;
     float mine = 0.f;
@@ -1198,7 +1221,7 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
         if (!c.use_sensor) inten = d2; /* get_abs_pos (ant_gather_env.py:179-196) sorts by squared distance */
         else if (!(d2 > c.sensor_range)) {
             const float half_span = c.sensor_span * 0.5f, bin_res = c.sensor_span / (float)c.n_bins;
-            const float angle = wrap_angle(atan2f(iy - ry, ix - rx) - yaw);
+            const float angle = wrap_angle(atan2_spec(iy - ry, ix - rx) - yaw);
             if (fabsf(angle) <= half_span) {
                 int b = (int)((angle + half_span) / bin_res);
                 if (b >= c.n_bins) b = c.n_bins - 1;
@@ -1258,13 +1281,13 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
             if (!c.sense_target) { /* ant_maze_bullet_env.py:123-133 */
                 const float vx = tx - rx, vy = ty - ry;
                 if (c.target_encoding == 0) { const float n = sqrtf(vx * vx + vy * vy); v = i == 0 ? vx / n : vy / n; }
-                else { const float a = atan2f(vy, vx) - yaw; v = i == 0 ? sinf(a) : cosf(a); }
+                else { const float a = atan2_spec(vy, vx) - yaw; v = i == 0 ? sin_spec(a) : cos_spec(a); }
             } else { /* ant_maze_bullet_env.py:135-178 */
                 const float wtd = L.scal[3];
                 bool vis = !(wtd > c.sensor_range);
                 for (int l = 4; l < 7 && vis; ++l) { float a[4]; maze_line(l, a); if (segment_intersection(rx, ry, tx, ty, a[0], a[1], a[2], a[3])) vis = false; }
                 if (vis) {
-                    const float angle = wrap_angle(atan2f(ty - ry, tx - rx) - yaw), half_span = c.sensor_span * 0.5f;
+                    const float angle = wrap_angle(atan2_spec(ty - ry, tx - rx) - yaw), half_span = c.sensor_span * 0.5f;
                     if (fabsf(angle) <= half_span) {
                         int b = (int)((angle + half_span) / (c.sensor_span / (float)c.n_bins));
                         if (b >= c.n_bins) b = c.n_bins - 1;
@@ -1283,12 +1306,12 @@ HRL_DEV void phase_point_state(const DevCfg &c, WaveLds &L, int lane) {
     const float *qp = L.st, *qv = L.st + 15;
     float rpy[3];
     quat_to_rpy(qp + 3, rpy);
-    const float theta = atan2f(0.f - qp[1], 0.f - qp[0]), a = theta - rpy[2];
-    const float cs = cosf(-rpy[2]), sn = sinf(-rpy[2]);
+    const float theta = atan2_spec(0.f - qp[1], 0.f - qp[0]), a = theta - rpy[2];
+    const float cs = cos_spec(-rpy[2]), sn = sin_spec(-rpy[2]);
     const float vx = cs * qv[0] - sn * qv[1], vy = sn * qv[0] + cs * qv[1], vz = qv[2];
     float mine = qp[2] - 1.f;
-    mine = (lane == 1) ? sinf(a) : mine;
-    mine = (lane == 2) ? cosf(a) : mine;
+    mine = (lane == 1) ? sin_spec(a) : mine;
+    mine = (lane == 2) ? cos_spec(a) : mine;
     mine = (lane == 3) ? 0.3f * vx : mine;
     mine = (lane == 4) ? 0.3f * vy : mine;
     mine = (lane == 5) ? 0.3f * vz : mine;

@@ -40,10 +40,13 @@ static inline REAL FN(dot6)(const REAL *a, const REAL *b) {
 }
 #if REAL_IS_FLOAT
 #define RSQRT(x) sqrtf(x)
-#define RSIN(x) sinf(x)
-#define RCOS(x) cosf(x)
-#define RATAN2(y, x) atan2f(y, x)
-#define RASIN(x) asinf(x)
+/* fp32 instantiation: sin / cos / atan2 / asin follow the operation-by-operation specification of DESIGN.md 3.7 (defined
+ * below), so that the fp32 oracle and the device agree bit for bit on observations too; the fp64 instantiation, which the
+ * golden vectors pin against the reference's numpy results, uses libm */
+#define RSIN(x) orc_sin_spec_f32(x)
+#define RCOS(x) orc_cos_spec_f32(x)
+#define RATAN2(y, x) orc_atan2_spec_f32(y, x)
+#define RASIN(x) orc_asin_spec_f32(x)
 #define RFABS(x) fabsf(x)
 #define RFMOD(x, y) fmodf(x, y)
 #else
@@ -78,6 +81,30 @@ static inline void FN(dyn_sincos)(REAL x, REAL *sn, REAL *cs) {
     *sn = sin(x); *cs = cos(x);
 #endif
 }
+#if REAL_IS_FLOAT
+static inline float orc_sin_spec_f32(float x) { float s, c; FN(dyn_sincos)(x, &s, &c); return s; }
+static inline float orc_cos_spec_f32(float x) { float s, c; FN(dyn_sincos)(x, &s, &c); return c; }
+/* atan2: a = min(|x|,|y|) / max(|x|,|y|) in [0, 1]; above tan(pi/8) reduced once more by atan(a) = pi/4 + atan((a-1)/(a+1));
+ * degree-9 odd minimax polynomial on [-tan(pi/8), tan(pi/8)] (the classic single-precision coefficients); then the octant,
+ * half-plane and sign.  Max error 2.8e-7 rad.  atan2(0, 0) = 0. */
+static inline float orc_atan2_spec_f32(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay, mn = ax < ay ? ax : ay;
+    float a = mx == 0.0f ? 0.0f : mn / mx;
+    int big = a > 0.4142135679721832275390625f;
+    float t = big ? (a - 1.0f) / (a + 1.0f) : a;
+    float z = t * t;
+    float p = FMA_(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = FMA_(p, z, 1.99777106478e-1f);
+    p = FMA_(p, z, -3.33329491539e-1f);
+    float r = FMA_(p * z, t, t);
+    if (big) r = 0.785398185253143310546875f + r;
+    if (ay > ax) r = 1.57079637050628662109375f - r;
+    if (x < 0.0f) r = 3.1415927410125732421875f - r;
+    return y < 0.0f ? -r : r;
+}
+static inline float orc_asin_spec_f32(float x) { return orc_atan2_spec_f32(x, sqrtf((1.0f - x) * (1.0f + x))); }
+#endif
 static inline REAL FN(clampr)(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
 /* Solver clamp = median of three with the semantics of gfx950's v_med3_f32: any NaN operand -> minimum
  * of the non-NaN operands; zeros ordered -0 < +0. */

@@ -104,3 +104,9 @@ extern "C" void emu_dyn_dump(const hrl_config *cfg, const float *q, const float 
     for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[o++] = a > b ? L.Lb[tl(a, b)] : (a == b ? L.idb[a] : 0.f);
     for (int k = 0; k < 6; ++k) out[o++] = L.a0[k];
 }
+
+/* the product's specified fp32 transcendental functions on arrays: which = 0 sin, 1 cos, 2 atan2(a, b), 3 asin */
+extern "C" void emu_spec_math(int which, const float *a, const float *b, float *out, int n) {
+    for (int i = 0; i < n; ++i)
+        out[i] = which == 0 ? sin_spec(a[i]) : which == 1 ? cos_spec(a[i]) : which == 2 ? atan2_spec(a[i], b[i]) : asin_spec(a[i]);
+}

@@ -208,3 +208,27 @@ def test_non_default_configs_bit_exact(kind, n, kw):
         o.step(a); e.step(a)
         for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
             assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, name)
+
+
+def test_specified_transcendentals_accuracy_and_agreement():
+    """sin / cos / atan2 / asin of DESIGN.md 3.7: the product's and the oracle's implementations agree bit for bit, and both are
+    within a few 1e-7 of the exact functions (what the fp32 observations inherit)."""
+    import ctypes as C
+    rng = np.random.RandomState(0)
+    n = 400000
+    def run(which, a, b=None):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(a if b is None else b, np.float32)
+        o1 = np.zeros(len(a), np.float32); o2 = np.zeros(len(a), np.float32)
+        orc.lib().orc_spec_math_f32(which, orc.ptr(a), orc.ptr(b), orc.ptr(o1), len(a))
+        emu_env.lib().emu_spec_math(which, orc.ptr(a), orc.ptr(b), orc.ptr(o2), len(a))
+        assert np.array_equal(o1, o2, equal_nan=True)
+        return o1.astype(np.float64)
+    x = rng.uniform(-20, 20, n)
+    assert np.abs(run(0, x) - np.sin(x.astype(np.float32).astype(np.float64))).max() < 2e-7
+    assert np.abs(run(1, x) - np.cos(x.astype(np.float32).astype(np.float64))).max() < 2e-7
+    yy = np.concatenate([rng.normal(size=n), 10.0 ** rng.uniform(-6, 6, n) * rng.choice([-1, 1], n), [0, 0, 1, -1, 0.0, 3, -3]]).astype(np.float32)
+    xx = np.concatenate([rng.normal(size=n), 10.0 ** rng.uniform(-6, 6, n) * rng.choice([-1, 1], n), [0, 1, 0, 0, -1.0, 3, -3]]).astype(np.float32)
+    assert np.abs(run(2, yy, xx) - np.arctan2(yy.astype(np.float64), xx.astype(np.float64))).max() < 3.5e-7
+    s = rng.uniform(-0.99999, 0.99999, n).astype(np.float32)
+    assert np.abs(run(3, s) - np.arcsin(s.astype(np.float64))).max() < 3e-7
+    run(2, np.array([np.nan, 1, np.inf, -np.inf, np.inf], np.float32), np.array([1, np.nan, 1, np.inf, np.inf], np.float32))  # same bits, whatever they are

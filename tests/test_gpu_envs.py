@@ -18,14 +18,14 @@ def test_readme_loop_single_env():
     assert isinstance(ob, np.ndarray) and ob.shape == (46,) and ob.dtype == np.float64
     o = orc.OracleEnv(orc.default_config(K.HRL_ANT_GATHER, num_envs=1, seed=0), np.float32)
     o.reset()
-    assert np.allclose(ob, o.obs[0], atol=2e-6)
+    assert np.array_equal(ob.astype(np.float32), o.obs[0])
     rng = np.random.RandomState(0)
     for t in range(300):
         a = rng.uniform(-1, 1, 8)
         ob, rew, done, info = env.step(a)
         o.step(a.astype(np.float32)[None])
         assert isinstance(rew, float) and isinstance(done, bool) and set(info) >= {'food_rew', 'dead_rew'}
-        assert rew == float(o.rew[0]) and done == bool(o.done[0]) and np.allclose(ob, o.obs[0], atol=2e-6)
+        assert rew == float(o.rew[0]) and done == bool(o.done[0]) and np.array_equal(ob.astype(np.float32), o.obs[0])
         if done:
             break
     env.close()
