@@ -34,6 +34,13 @@ struct GpuExec {
      * lane-derived value of the unrolled solver (44 `lane == r` masks, LDS addresses, ...) is loop-invariant, gets
      * hoisted to the top of the kernel and is spilled to scratch for the whole substep loop. */
     __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(lane), "+v"(r.fn)); }
+    /* 1.0 on lane r (wave-uniform), 0.0 elsewhere: one v_cndmask on a scalar lane mask */
+    __device__ __forceinline__ float lane_one(int, int r) {
+        float d;
+        const unsigned long long m = 1ull << r;
+        asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(d) : "s"(m));
+        return d;
+    }
     /* same for a wave-uniform value: comparisons against it are redone (one s_cmp each) after this point */
     __device__ __forceinline__ void refresh_uniform(int &v) { asm volatile("" : "+s"(v)); }
 #ifdef HRL_STAMPS

@@ -146,8 +146,8 @@ struct LaneRegs {
     float rI[21], rp[6];             /* body map (phases K1 -> K2 -> B): the lane's rigid-body spatial inertia and bias force */
     float Jb[6], Jh, Ja;             /* row map: the row's Jacobian, sparse: torso twist part + the hip / ankle entries */
     int jslot;                       /* row map: dof slot of Jh (Ja is the next slot): 6 + 2 * leg                   */
-    float An[MAXB], Af[MAXF];        /* row map: the row's line of A = J M^-1 J^T: limit/normal columns, friction columns */
-    float w, lam, bias, invd, lo, hi; /* row map: constraint velocity (bias included), impulse, bias, 1/A_ii, bounds */
+    float An[MAXB], Af[MAXF];        /* row map: the row's line of C = I - D^-1 A (A = J M^-1 J^T): limit/normal columns, friction columns */
+    float c, lam, bias, lo, hi;      /* row map: unclamped impulse candidate lam - w / A_ii, impulse, bias, bounds */
     int fn;                          /* row map: friction rows: index of their normal row, else -1 */
 };
 struct F2b { float ln, dl; }; /* a row's candidate impulse and its change; the change of the row being solved is broadcast */
@@ -688,12 +688,13 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
     g.bias = bias; g.fn = active ? frn : -1; g.lam = 0.f; g.lo = 0.f; g.hi = frn >= 0 ? 0.f : hi;
 }
 
-/* Phase R2 (row map): the row's line of A = J M^-1 J^T (A[i][r] = J_i . B_r), 1/A_ii and the initial constraint
- * velocity w_i = J_i . u* + bias_i.  Sequential fma chains over the 16 dof slots with their exact zeros left out (the
- * torso part, then the row's two joint slots in order); B_r and u* are LDS reads.
+/* Phase R2 (row map): the row's line of C = I - D^-1 A with A = J M^-1 J^T (A[i][r] = J_i . B_r, D = diag A), and the
+ * initial impulse candidate c_i = -(J_i . u* + bias_i) / A_ii.  Sequential fma chains over the 16 dof slots with their
+ * exact zeros left out (the torso part, then the row's two joint slots in order); B_r and u* are LDS reads.
  * The line is kept in two register arrays, split where the sweep order changes kind: An[r] for the limit and normal
  * rows r < nB, Af[k] for the friction rows nB + k.  Both are indexed by template parameters (pack expansion) so that
- * they stay in registers: a runtime index would push them out into scratch memory. */
+ * they stay in registers: a runtime index would push them out into scratch memory.
+ * `one(r)` is 1 on lane r and 0 elsewhere (the unit diagonal), supplied by the executor. */
 HRL_DEV float row_dot(const LaneRegs &g, const float *Brow) {
     float a = g.Jb[0] * Brow[0];
 #pragma unroll
@@ -703,35 +704,36 @@ HRL_DEV float row_dot(const LaneRegs &g, const float *Brow) {
 }
 /* columns 4G..4G+3 of a block behind one wave-uniform test (flat sequence of groups, no nesting).  Columns past the
  * block's end inside its last group are computed from whatever LDS holds and never read by the sweeps. */
-template <int G>
-HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB) {
+template <int G, class One>
+HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, One one) {
     if (4 * G < nB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = row_dot(g, L.Bt[4 * G + i]);
+        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot(g, L.Bt[4 * G + i]), one(4 * G + i));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.An[4 * G + i] = 0.f;
     }
 }
-template <int G>
-HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF) {
+template <int G, class One>
+HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one) {
     if (4 * G < nF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = row_dot(g, L.Bt[nB + 4 * G + i]);
+        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot(g, L.Bt[nB + 4 * G + i]), one(nB + 4 * G + i));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = 0.f;
     }
 }
-template <int... Gn, int... Gf>
-HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, std::integer_sequence<int, Gn...>, std::integer_sequence<int, Gf...>) {
-    (build_An_group<Gn>(L, g, nB), ...);
-    (build_Af_group<Gf>(L, g, nB, nF), ...);
+template <class One, int... Gn, int... Gf>
+HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, std::integer_sequence<int, Gn...>, std::integer_sequence<int, Gf...>) {
+    (build_An_group<Gn>(L, g, nB, ninvd, one), ...);
+    (build_Af_group<Gf>(L, g, nB, nF, ninvd, one), ...);
 }
-HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF) {
-    build_A_blocks(L, g, nB, nF, std::make_integer_sequence<int, MAXB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
-    g.invd = 1.f / row_dot(g, L.Bt[lane < nB + nF ? lane : 0]); /* A_ii; idle lanes carry row 0's registers */
-    g.w = row_dot(g, L.ustar) + g.bias;
+template <class One>
+HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
+    const float invd = 1.f / row_dot(g, L.Bt[lane < nB + nF ? lane : 0]); /* 1 / A_ii; idle lanes carry row 0's registers */
+    build_A_blocks(L, g, nB, nF, -invd, one, std::make_integer_sequence<int, MAXB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
+    g.c = -(invd * (row_dot(g, L.ustar) + g.bias));
 }
 
 /* Phase I (dof map): integrate positions; the joint rates were clamped by the caller.  Lane k < 16 produces element k
@@ -760,17 +762,17 @@ HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float 
     if (lane < 16) qn[lane] = mine;
 }
 
-/* Projected Gauss-Seidel in ROW SPACE: lane i owns solver row i -- its constraint velocity w_i (bias
- * included), impulse, bounds and its row of A -- all in registers.  Solving row r: every lane forms the candidate
- * impulse of its own row, lane r keeps its candidate, its change is broadcast with a lane read and every lane applies
- * w_i += A[i][r] * dl (one executor primitive, each_row).
+/* Projected Gauss-Seidel in ROW SPACE: lane i owns solver row i -- its unclamped impulse candidate
+ * c_i = lam_i - w_i / A_ii, impulse, bounds and its row of C = I - D^-1 A -- all in registers.  Solving row r: every lane
+ * clamps the candidate of its own row, lane r keeps the result, its change is broadcast with a lane read and every lane
+ * applies c_i += C[i][r] * dl (one executor primitive, each_row): four dependent instructions per row.
  * No LDS and no cross-lane reduction on the solver's dependent chain.  Rows run in order (limits, normals, then the
  * friction pairs); the friction rows take their bounds +-mu * (normal impulse) from their normal's lane once per
  * sweep, after the last normal row, which is exactly when a row-by-row update would have last changed them.
  * c.iters sweeps; the velocity is reconstructed once at the end from the impulses. */
 HRL_DEV F2b pgs_candidate(const LaneRegs &g) {
     F2b o;
-    o.ln = med3_spec(fma_(-g.w, g.invd, g.lam), g.lo, g.hi);
+    o.ln = med3_spec(g.c, g.lo, g.hi);
     o.dl = o.ln - g.lam;
     return o;
 }
@@ -778,14 +780,14 @@ template <int R, class X>
 HRL_DEV bool pgs_row_bounded(X &x, int nB) { /* limit or normal row R (compile-time index: An[R] is a register) */
     if (R >= nB) return false; /* wave-uniform: ends the block (the fold below short-circuits) */
     x.each_row(R, [&](int lane) { return pgs_candidate(x.reg(lane)); },
-               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.w = fma_(g.An[R], dl, g.w); });
+               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.An[R], dl, g.c); });
     return true;
 }
 template <int K, class X>
 HRL_DEV bool pgs_row_friction(X &x, int nB, int nF) { /* friction row nB + K */
     if (K >= nF) return false;
     x.each_row(nB + K, [&](int lane) { return pgs_candidate(x.reg(lane)); },
-               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.w = fma_(g.Af[K], dl, g.w); });
+               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.Af[K], dl, g.c); });
     return true;
 }
 template <class X, int... Rs, int... Ks>
@@ -806,7 +808,7 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
     WaveLds &L = x.lds();
     const int nB = ant ? nL + nC : nC, nF = 2 * nC, nR = nB + nF;
     if (nR <= 0) return;
-    x.each([&](int lane) { phase_build_A(L, x.reg(lane), lane, nB, nF); });
+    x.each([&](int lane) { phase_build_A(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
     x.stamp(8);
     float mu = c.mu;
     const int iters = c.iters;

@@ -765,34 +765,38 @@ static void FN(tangent_basis)(const REAL *n, REAL *t1, REAL *t2) {
 }
 
 /* Projected Gauss-Seidel in ROW SPACE.  With A = J M^-1 J^T (row i of A is computed from row i's own
- * Jacobian: A[i][r] = J_i . B_r, a sequential fma chain over the 16 dof slots) every row keeps its constraint
- * velocity w_i = J_i . u; updating row r by dl changes every w_i by A[i][r] * dl.  Rows are visited in order
- * (limits, normals, friction pairs) `iters` times; a friction row's bounds are +-mu * (current impulse of its normal
- * row).  The generalized velocity is reconstructed once at the end: u += sum_r B_r * lambda_r. */
+ * Jacobian: A[i][r] = J_i . B_r, a sequential fma chain over the 16 dof slots) and w_i = J_i . u + b_i, every row keeps
+ * its unclamped impulse candidate  c_i = lambda_i - w_i / A_ii  up to date: updating row r by dl changes w_i by
+ * A[i][r] * dl and lambda_r by dl, i.e. c_i by C[i][r] * dl with C = I - D^-1 A (scaled, with the unit diagonal folded
+ * in), so a row update is  ln = clamp(c_r), dl = ln - lambda_r, c_i += C[i][r] * dl for all i.  Rows are visited in
+ * order (limits, normals, friction pairs) `iters` times; a friction row's bounds are +-mu * (current impulse of its
+ * normal row).  The generalized velocity is reconstructed once at the end: u += sum_r B_r * lambda_r. */
 #define ORC_MAXROWS 44
 static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, const REAL *hic, const int *frn, REAL mu,
                         int iters, REAL *un, REAL *lam) {
-    static _Thread_local REAL A[ORC_MAXROWS][ORC_MAXROWS];
-    REAL w[ORC_MAXROWS], invd[ORC_MAXROWS], lo[ORC_MAXROWS], hi[ORC_MAXROWS];
+    static _Thread_local REAL Cm[ORC_MAXROWS][ORC_MAXROWS];
+    REAL c[ORC_MAXROWS], lo[ORC_MAXROWS], hi[ORC_MAXROWS];
     for (int i = 0; i < nr; ++i) {
+        REAL Ai[ORC_MAXROWS];
         for (int r = 0; r < nr; ++r) {
             REAL a = J[i][0] * B[r][0];
             for (int d = 1; d < 16; ++d) a = FMA_(J[i][d], B[r][d], a);
-            A[i][r] = a;
+            Ai[r] = a;
         }
-        invd[i] = R_(1) / A[i][i];
+        REAL invd = R_(1) / Ai[i];
+        for (int r = 0; r < nr; ++r) Cm[i][r] = FMA_(-invd, Ai[r], r == i ? R_(1) : R_(0));
         REAL wi = J[i][0] * un[0];
         for (int d = 1; d < 16; ++d) wi = FMA_(J[i][d], un[d], wi);
-        w[i] = wi + bias[i]; /* w carries the row's bias: w_i = J_i u + b_i, the quantity the row drives to >= 0 */
+        c[i] = -(invd * (wi + bias[i])); /* lambda_i = 0 */
         lam[i] = 0; lo[i] = 0; hi[i] = frn[i] >= 0 ? R_(0) : hic[i];
     }
     for (int it = 0; it < iters; ++it)
         for (int r = 0; r < nr; ++r) {
-            REAL ln = FN(med3)(FMA_(-w[r], invd[r], lam[r]), lo[r], hi[r]);
+            REAL ln = FN(med3)(c[r], lo[r], hi[r]);
             REAL dl = ln - lam[r];
             lam[r] = ln;
             for (int i = 0; i < nr; ++i) {
-                w[i] = FMA_(A[i][r], dl, w[i]);
+                c[i] = FMA_(Cm[i][r], dl, c[i]);
                 if (frn[i] == r) { hi[i] = mu * ln; lo[i] = -hi[i]; }
             }
         }

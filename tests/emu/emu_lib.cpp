@@ -22,6 +22,7 @@ struct CpuExec {
     int uniform(int v) { return v; }
     void refresh() {}
     void refresh_uniform(int &) {}
+    float lane_one(int lane, int r) { return lane == r ? 1.f : 0.f; }
     void stamp(int) {}
     void flush_stamps(const DevBufs &) {}
     template <class F> void each(F f) {
