@@ -6,8 +6,14 @@ A "step" is one hrl_step() over the shard's envs: one HIP kernel launch that adv
 configs[2], the config the metric is quoted on); weak scaling: every rank owns 4096 envs, RNG keyed by global id.
 Inputs (state, items, pre-generated U(-1,1) actions) are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--kind gather|flat|maze|point|maze_mj|flagrun]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096]
+                    [--kind gather|flat|maze|point|maze_mj|flagrun|mixed] [--backend nccl|gloo]
+
+`--kind mixed` is BASELINE.json configs[4] per GPU: the first half of the shard AntGather, the second half PointGather
+(two hrl_step launches per step on two HIP streams, so the kernels overlap on the chip), one JSON line.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE anything touches
+the GPU, passes their output through and exits with their status.  Under torch.distributed.run it is a rank.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -15,37 +21,71 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hrl_pybullet_envs_amd import _capi as K  # noqa: E402
-from hrl_pybullet_envs_amd import _lib  # noqa: E402
-from hrl_pybullet_envs_amd.dist import ReturnGatherer, init_distributed  # noqa: E402
-from hrl_pybullet_envs_amd.vec_env import BatchedEnv  # noqa: E402
-
-KINDS = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER,
-         'maze_mj': K.HRL_ANT_MAZE_MJ, 'flagrun': K.HRL_ANT_FLAGRUN}
+KIND_NAMES = ['flat', 'gather', 'maze', 'point', 'maze_mj', 'flagrun', 'mixed']
 NAMES = {'flat': 'AntMjEnv (flat ground)', 'gather': 'AntGatherBulletEnv-v0', 'maze': 'AntMazeBulletEnv-v0',
-         'point': 'PointGatherBulletEnv-v0', 'maze_mj': 'AntMazeMjEnv-v0', 'flagrun': 'AntFlagrunBulletEnv-v0'}
+         'point': 'PointGatherBulletEnv-v0', 'maze_mj': 'AntMazeMjEnv-v0', 'flagrun': 'AntFlagrunBulletEnv-v0',
+         'mixed': 'AntGatherBulletEnv-v0 + PointGatherBulletEnv-v0 mixed batch'}
 # algorithmic HBM bytes per env-step, fp32, state read once + written once (SURVEY.md 8d / BASELINE.md 4)
 ALG_BYTES = {'gather': 581, 'flat': 385, 'maze': 429, 'point': 317,
              'maze_mj': 148 + 8 + 116 + 240 + 5, 'flagrun': 148 + 4 + 116 + 112 + 5}  # same accounting: read state+act(+target/goal index), write state+obs+rew+done
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MAX_CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md chip table
+N_SIMD = 256 * 4        # 256 CUs x 4 SIMD-32
+VALU_ISSUE_CYCLES = 2   # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
+    ap.add_argument('--kind', default='gather', choices=sorted(KIND_NAMES))
+    ap.add_argument('--gather-every', type=int, default=100, help='all-gather episode returns every K steps (N>1)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo only to rehearse N>1 on a box with fewer GPUs')
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """Parent of an N-rank run: nothing in this process has touched the GPU (no HIP call, no torch.cuda.*), so the
+    ranks are plain child processes; the parent never re-executes itself."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(kind, seconds_budget=15.0):
     """Times the CPU oracle (a port: the pybullet reference is not installable here) on ONE host core, N = 1 env,
     the like-for-like of the reference's single-process loop (README.md:29-34).  Bounded sample."""
+    from hrl_pybullet_envs_amd import _capi as K
+    kinds = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER,
+             'maze_mj': K.HRL_ANT_MAZE_MJ, 'flagrun': K.HRL_ANT_FLAGRUN}
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import orc
     L = orc.lib()
     L.orc_bench_f32.restype = C.c_double
-    cfg = orc.default_config(KINDS[kind], num_envs=1, seed=0, auto_reset=1)
+    if kind == 'mixed':  # half the sample on each env type; value = env-steps of both / time of both
+        a, p = cpu_baseline('gather', seconds_budget / 2), cpu_baseline('point', seconds_budget / 2)
+        va, vp = a['value'], p['value']
+        out = {'value': 2.0 / (1.0 / va + 1.0 / vp), 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+               'sample': 'equal numbers of AntGather and PointGather env-steps, one after the other on 1 thread: ' + a['sample'] + ' | ' + p['sample'],
+               'all_cores': {'value': 2.0 / (1.0 / a['all_cores']['value'] + 1.0 / p['all_cores']['value']), 'cores': a['all_cores']['cores'],
+                             'sample': a['all_cores']['sample'] + ' | ' + p['all_cores']['sample']},
+               'reference': a['reference']}
+        return out
+    cfg = orc.default_config(kinds[kind], num_envs=1, seed=0, auto_reset=1)
     cs = C.c_double()
     dt = L.orc_bench_f32(C.byref(cfg), 2000, 1, C.byref(cs))  # calibrate
     steps = max(2000, int(2000 / dt * seconds_budget))
@@ -58,10 +98,10 @@ def cpu_baseline(kind, seconds_budget=15.0):
     except AttributeError:
         ncpu = os.cpu_count() or 1
     ncpu = max(1, min(ncpu, 16))  # the GPU box gives one GPU's job a 16-core share
-    cfg_n = orc.default_config(KINDS[kind], num_envs=4096, seed=0, auto_reset=1)
+    cfg_n = orc.default_config(kinds[kind], num_envs=4096, seed=0, auto_reset=1)
     L.orc_bench_f32(C.byref(cfg_n), 2, ncpu, C.byref(cs))  # start the OpenMP team
     dtn = L.orc_bench_f32(C.byref(cfg_n), 40, ncpu, C.byref(cs))  # calibrate
-    nsteps = max(40, int(40 / dtn * 6.0))
+    nsteps = max(40, int(40 / dtn * seconds_budget * 0.4))
     dtn = L.orc_bench_f32(C.byref(cfg_n), nsteps, ncpu, C.byref(cs))
     out['all_cores'] = {'value': 4096 * nsteps / dtn, 'cores': ncpu,
                         'sample': f'same oracle, 4096 envs x {nsteps} steps, OpenMP over {ncpu} threads, {dtn:.1f} s'}
@@ -91,29 +131,56 @@ def reference_probe():
     return {'value': n / (time.perf_counter() - t0), 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference'}  # pragma: no cover
 
 
-def profiled_traffic(kind, n):
-    """HBM bytes per launch of k_step from the committed rocprofv3 PMC summary (profiles/), scaled to n envs.
-    bench.py cannot collect counters itself; None when no summary for this kernel is committed."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+def pmc_summary(kind):
+    """Committed rocprofv3 PMC summary of k_step<kind> (profiles/pmc_summary.json, tools/summarize_profile.py).
+    bench.py cannot collect counters itself; {} when no summary for this kernel is committed."""
     try:
-        with open(path) as f:
-            d = json.load(f)[kind]
-        return (d['fetch_bytes_per_env'] + d['write_bytes_per_env']) * n
+        with open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')) as f:
+            return json.load(f).get(kind, {})
     except Exception:
-        return None
+        return {}
+
+
+def roofline(kind, n, launch_s):
+    """HBM roofline (the contractual one) + the VALU-issue roofline (the one that binds), SURVEY 8d "report both".
+
+    hbm:  achieved = algorithmic bytes per launch / measured launch time, against 8 TB/s.
+    valu: a wave64 VALU instruction holds its SIMD-32 for 2 cycles, so a launch needs at least
+          insts_per_env x envs / 1024 SIMDs x 2 cycles of VALU issue per SIMD; frac = that / (launch time x 2.4 GHz),
+          i.e. the fraction of the chip's peak VALU issue rate the launch used.  insts_per_env, wave cycles and the
+          clock the chip held come from the committed PMC pass of the same kernel (profiles/)."""
+    s = pmc_summary(kind)
+    alg = ALG_BYTES[kind] * n
+    achieved = alg / launch_s / 1e9
+    traffic = (s['fetch_bytes_per_env'] + s['write_bytes_per_env']) * n if 'fetch_bytes_per_env' in s else None
+    out = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+           'traffic': traffic, 'kernel': f'k_step<{kind}>', 'kernel_avg_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg,
+           'note': 'the path is VALU-issue/latency bound (~170 flop/B, serial recursion): `valu` is the roofline that binds, DESIGN.md 5'}
+    if 'valu_insts_per_env' in s:
+        per_simd = s['valu_insts_per_env'] * n / N_SIMD * VALU_ISSUE_CYCLES
+        v = {'insts_per_env': s['valu_insts_per_env'], 'issue_cycles_per_simd': per_simd,
+             'frac': per_simd / (launch_s * MAX_CLOCK_GHZ * 1e9), 'peak': 'one wave64 VALU instruction per 2 cycles per SIMD-32 at 2.4 GHz',
+             'source': f"profiles/{s.get('tag', '?')}_pmc.json (SQ_INSTS_VALU per wave)"}
+        if 'wave_cycles_per_env' in s and 'kernel_us_profiled' in s:
+            v['held_clock_ghz'] = s['wave_cycles_per_env'] / (s['kernel_us_profiled'] * 1e3)  # lower bound: a wave lives at most the launch
+            v['frac_at_held_clock'] = per_simd / (launch_s * v['held_clock_ghz'] * 1e9)
+        out['valu'] = v
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=200)
-    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
-    ap.add_argument('--kind', default='gather', choices=sorted(KINDS))
-    ap.add_argument('--gather-every', type=int, default=100, help='all-gather episode returns every K steps (N>1)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo only to rehearse N>1 on a box with fewer GPUs')
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import torch
+
+    from hrl_pybullet_envs_amd import _capi as K
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.dist import ReturnGatherer, init_distributed
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+    kinds = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER,
+             'maze_mj': K.HRL_ANT_MAZE_MJ, 'flagrun': K.HRL_ANT_FLAGRUN}
 
     rank, world, local_rank = init_distributed(args.gpus, backend=args.backend)
     if args.backend == 'gloo':
@@ -121,18 +188,29 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     n = args.envs
-    cfg = _lib.default_config(KINDS[args.kind], num_envs=n, seed=0, auto_reset=1, env_id_offset=rank * n)
-    env = BatchedEnv(cfg, dev)
-    env.reset()
-    # pre-generated actions, resident in HBM: [T, N, A] ~ U(-1, 1), seed 0 (+rank)
-    T = 256
+    T = 256  # pre-generated actions, resident in HBM: [T, N, A] ~ U(-1, 1), seed = rank
     gen = torch.Generator(device=dev).manual_seed(rank)
-    actions = torch.rand(T, n, env.act_dim, device=dev, generator=gen) * 2 - 1
-    gatherer = ReturnGatherer(env, world) if world > 1 else None
+    main_stream = torch.cuda.current_stream(dev)
+    if args.kind == 'mixed':  # BASELINE.json configs[4]: first half of the shard AntGather, second half PointGather
+        assert n % 2 == 0, '--envs must be even for --kind mixed'
+        parts = [('gather', n // 2, rank * n), ('point', n // 2, rank * n + n // 2)]
+    else:
+        parts = [(args.kind, n, rank * n)]
+    envs = []
+    for kname, cnt, off in parts:
+        env = BatchedEnv(_lib.default_config(kinds[kname], num_envs=cnt, seed=0, auto_reset=1, env_id_offset=off), dev)
+        env.reset()
+        acts = torch.rand(T, cnt, env.act_dim, device=dev, generator=gen) * 2 - 1
+        stream = main_stream if len(parts) == 1 else torch.cuda.Stream(device=dev)  # one HIP stream per sub-shard: the launches overlap
+        envs.append((kname, env, acts, stream))
+    torch.cuda.synchronize(dev)
+    gatherer = ReturnGatherer([(e, s) for _, e, _, s in envs], world) if world > 1 else None
 
     def run(k0, k):
         for t in range(k0, k0 + k):
-            env.step(actions[t % T])
+            for _, env, acts, stream in envs:
+                with torch.cuda.stream(stream):
+                    env.step(acts[t % T])
             if gatherer is not None and (t + 1) % args.gather_every == 0:
                 gatherer.launch()
 
@@ -140,44 +218,64 @@ def main():
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()  # the kernels are launched on torch's current stream, which is where these events are recorded
+    ev = []
+    for _, _, _, stream in envs:  # HIP events on the stream each kernel is launched on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        ev.append((e0, e1))
     run(args.warmup, args.steps)
-    ev1.record()
+    for (e0, e1), (_, _, _, stream) in zip(ev, envs):
+        e1.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     if world > 1:
         tt = torch.tensor([wall], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         wall = float(tt.item())
-    assert bool(torch.isfinite(env.state).all()), 'non-finite state after the timed region'
+    for _, env, _, _ in envs:
+        assert bool(torch.isfinite(env.state).all()), 'non-finite state after the timed region'
+    gathered_ok = None
+    if gatherer is not None:
+        g = gatherer.latest()
+        gathered_ok = bool(g.numel() == world * n and torch.isfinite(g).all())
     if world > 1:  # all collectives are done: leave the group before rank 0 spends ~25 s of host time on the CPU baseline
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
     if rank == 0:
         total_steps = world * n * args.steps
-        launch_s = dev_ms / 1e3 / args.steps  # one kernel per step: HIP-event time / launches
-        achieved = ALG_BYTES[args.kind] * n / launch_s / 1e9
+        # dominant kernel: the ant step (for mixed: k_step<gather> over its half of the shard, overlapped with the point kernel)
+        dom = 0
+        dom_kind, dom_env = envs[dom][0], envs[dom][1]
+        launch_s = dev_ms[dom] / 1e3 / args.steps  # one kernel per step per stream: HIP-event time on that stream / launches
+        if args.kind == 'gather' and n == 4096:
+            metric = 'env-steps/sec, AntGatherBulletEnv-v0 @4096 envs, 1/2/4/8 MI355X'
+        elif args.kind == 'mixed':
+            metric = f'env-steps/sec, AntGatherBulletEnv-v0 + PointGatherBulletEnv-v0 mixed batch @{n} envs/GPU'
+        else:
+            metric = f'env-steps/sec, {NAMES[args.kind]} @{n} envs/GPU'
+        shard = f'{NAMES[args.kind]}, {n} envs per GPU'
+        if args.kind == 'mixed':
+            shard += f' ({n // 2} AntGather + {n // 2} PointGather, two launches per step on two HIP streams)'
         out = {
-            'metric': 'env-steps/sec, AntGatherBulletEnv-v0 @4096 envs, 1/2/4/8 MI355X' if args.kind == 'gather' and n == 4096
-            else f'env-steps/sec, {NAMES[args.kind]} @{n} envs/GPU',
+            'metric': metric,
             'value': total_steps / wall, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{NAMES[args.kind]}, {n} envs per GPU, U(-1,1) actions pre-generated on device, auto-reset, '
-                                   f'max_episode_steps 2000', 'envs_per_gpu': n, 'global_envs': world * n,
+            'config': {'workload': f'{shard}, U(-1,1) actions pre-generated on device, auto-reset, max_episode_steps 2000',
+                       'envs_per_gpu': n, 'global_envs': world * n,
                        'substeps_per_step': 4, 'parallelism': f'env-sharded x{world}, no data-path collective; '
                                                               f'RCCL all-gather of episode returns every {args.gather_every} steps'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': profiled_traffic(args.kind, n), 'kernel': 'k_step', 'kernel_avg_us': launch_s * 1e6,
-                         'algorithmic_bytes_per_launch': ALG_BYTES[args.kind] * n,
-                         'note': 'VALU-issue/latency-bound by construction (~9.4e3 VALU wave-instructions, ~1e5 flop per env-step, ~170 flop/B): see DESIGN.md 5'},
+            'roofline': roofline(dom_kind, dom_env.num_envs, launch_s),
         }
+        if args.kind == 'mixed':
+            out['roofline']['streams_ms_per_step'] = {k: ms / args.steps for (k, _, _, _), ms in zip(envs, dev_ms)}
+        if gathered_ok is not None:
+            out['config']['returns_gathered_ok'] = gathered_ok
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.kind)
         print(json.dumps(out), flush=True)

@@ -50,7 +50,11 @@ def check(rc):
 def default_config(kind, **over):
     cfg = K.hrl_config()
     check(lib().hrl_default_config(kind, C.byref(cfg)))
+    names = {f[0] for f in K.hrl_config._fields_}
+    mnames = {f[0] for f in K.hrl_model._fields_}
     for k, v in over.items():
+        if (k[6:] not in mnames) if k.startswith('model_') else (k not in names):
+            raise TypeError(f'hrl_config has no field {k!r}')  # a ctypes Structure would silently grow an attribute
         if k.startswith('model_'):
             setattr(cfg.model, k[6:], v)
         elif k in ('world_size', 'start_pos', 'walk_target', 'centroid_static_sum'):

@@ -32,7 +32,8 @@ def _worker(rank, world, port, total, steps, out_dir):
     acts = np.random.RandomState(0).uniform(-1, 1, (steps, total, 8)).astype(np.float32)
     for t in range(steps):
         env.step(acts[t, off:off + cnt])
-    gathered = all_gather_returns(torch.from_numpy(env.info[:, 2].copy()), w)
+    counts = [shard_range(total, k, w)[1] for k in range(w)]  # uneven when total % world != 0: padded inside
+    gathered = all_gather_returns(torch.from_numpy(env.info[:, 2].copy()), w, counts=counts)
     dist.barrier()
     if r == 0:
         np.save(os.path.join(out_dir, 'gathered.npy'), gathered.numpy())
@@ -40,8 +41,12 @@ def _worker(rank, world, port, total, steps, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_matches_single_process(tmp_path):
-    total, steps, world = 12, 30, 2
+import pytest
+
+
+@pytest.mark.parametrize('total', [12, 13])  # 13: uneven shards (7 + 6), the gather pads to the largest
+def test_two_rank_sharding_matches_single_process(tmp_path, total):
+    steps, world = 30, 2
     mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import emu_env

@@ -102,3 +102,37 @@ def test_flagrun_close_goal_class():
         goals.add(tuple(np.round(g[0], 4)))
     assert len(goals) >= 4  # the 10-step timeout moved env 0's goal several times
     env.close()
+
+
+def _bench_line(args, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_mixed_kind_one_gpu():
+    """BASELINE.json configs[4] per GPU through bench.py: one JSON line, both sub-shards stepped on their own streams."""
+    out = _bench_line(['--kind', 'mixed', '--envs', '4096', '--steps', '30', '--warmup', '5', '--no-cpu-baseline'])
+    assert 'mixed batch' in out['metric'] and out['n_gpus'] == 1 and out['config']['envs_per_gpu'] == 4096
+    assert out['value'] > 1e6 and out['roofline']['kernel'] == 'k_step<gather>'
+    assert set(out['roofline']['streams_ms_per_step']) == {'gather', 'point'}
+
+
+def test_bench_starts_two_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it: the parent spawns the ranks (gloo here: the
+    box has one GPU, both ranks share it; on a node the same path runs RCCL), weak scaling doubles the env count, the
+    side-stream all-gather of episode returns ran."""
+    out = _bench_line(['--gpus', '2', '--backend', 'gloo', '--envs', '512', '--steps', '40', '--warmup', '5',
+                       '--gather-every', '10', '--no-cpu-baseline'])
+    assert out['n_gpus'] == 2 and out['config']['global_envs'] == 1024 and out['scaling'] == 'weak'
+    assert out['config']['returns_gathered_ok'] is True and out['value'] > 0

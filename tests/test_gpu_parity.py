@@ -112,43 +112,101 @@ def test_pickups_and_respawn_match():
     assert picked > 400
 
 
-@pytest.mark.parametrize('kind,n', [(K.HRL_ANT_GATHER, 4096), (K.HRL_ANT_FLAT, 4096), (K.HRL_ANT_MAZE, 8192)])
+def sampled_row_parity(kind, g, rows, st, it, au, a_np, rew, done, seed, **kw):
+    """Re-runs the sampled rows of one full-size launch on the oracle from the device's own pre-step state.  The oracle
+    keys its RNG by global env id, so every sampled row runs as its own 1-env shard at that id."""
+    gs, gi, ga, go = g.state.cpu().numpy(), g.items.cpu().numpy(), g.aux.cpu().numpy(), g.obs.cpu().numpy()
+    rew, done = rew.cpu().numpy(), done.cpu().numpy()
+    off = int(g.cfg.env_id_offset)
+    for r in rows:
+        o = orc.OracleEnv(orc.default_config(kind, num_envs=1, seed=seed, auto_reset=1, env_id_offset=off + int(r), **kw), np.float32)
+        o.state[0] = st[r]; o.items[0] = it[r]; o.aux[0] = au[r]
+        o.step(a_np[r:r + 1])
+        assert np.array_equal(gs[r], o.state[0], equal_nan=True), r
+        assert np.array_equal(gi[r], o.items[0]) and np.array_equal(ga[r], o.aux[0]), r
+        assert np.array_equal(go[r], o.obs[0], equal_nan=True), r
+        assert float(rew[r]) == float(o.rew[0]) and int(done[r]) == int(o.done[0]), r
+
+
+FULL_SIZE = [(K.HRL_ANT_GATHER, 4096), (K.HRL_ANT_FLAT, 4096), (K.HRL_ANT_MAZE, 8192), (K.HRL_POINT_GATHER, 4096),
+             (K.HRL_ANT_MAZE_MJ, 4096), (K.HRL_ANT_FLAGRUN, 4096)]
+
+
+@pytest.mark.parametrize('kind,n', FULL_SIZE)
 def test_full_size_properties(kind, n):
-    """BASELINE.json sizes: size-independent properties + oracle parity on a sampled subset of rows."""
-    g, _ = make(kind, n, seed=21)
+    """BASELINE.json sizes: size-independent properties + oracle parity on 256 sampled rows (state, items, counters,
+    observation, reward, done: bit-exact)."""
+    g, o0 = make(kind, n, seed=21)
     g.reset()
     gen = torch.Generator(device='cuda').manual_seed(0)
-    acts = torch.rand(60, n, 8, device='cuda', generator=gen) * 2 - 1
+    acts = torch.rand(60, n, o0.ad, device='cuda', generator=gen) * 2 - 1
     for t in range(59):
         g.step(acts[t])
-    # sampled-row parity at full size: 256 random rows re-run on the oracle from the device's own state
     rows = np.random.RandomState(3).choice(n, 256, replace=False)
     st, it, au = g.state.cpu().numpy(), g.items.cpu().numpy(), g.aux.cpu().numpy()
     obs, rew, done, _ = g.step(acts[59])
     torch.cuda.synchronize()
-    a_np = acts[59].cpu().numpy()
-    for r in rows[:64]:  # the oracle keys RNG by global id: run each sampled row as its own 1-env shard
-        o = orc.OracleEnv(orc.default_config(kind, num_envs=1, seed=21, auto_reset=1, env_id_offset=int(r)), np.float32)
-        o.state[0] = st[r]; o.items[0] = it[r]; o.aux[0] = au[r]
-        o.step(a_np[r:r + 1])
-        assert np.array_equal(g.state[r].cpu().numpy(), o.state[0]), r
-        assert float(rew[r]) == float(o.rew[0]) and int(done[r]) == int(o.done[0])
+    sampled_row_parity(kind, g, rows, st, it, au, acts[59].cpu().numpy(), rew, done, seed=21)
     s = g.state.cpu().numpy()
     assert np.isfinite(s).all()
     assert np.abs(np.linalg.norm(s[:, 3:7], axis=1) - 1).max() < 1e-5          # unit quaternions
     assert np.all(np.abs(s[:, 21:29]) <= 100.0)                                 # joint-rate clamp
     ob = obs.cpu().numpy()
     assert np.isfinite(ob).all()
-    if kind == K.HRL_ANT_GATHER:
+    if kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER):
+        nb = 26 if kind == K.HRL_ANT_GATHER else 8
         itf = g.items.cpu().numpy().reshape(n, 16, 2)
         assert np.all(np.abs(itf) <= 7.0)                                       # gather_scene.py:52-62
-        assert np.all(ob[:, 26:] >= 0) and np.all(ob[:, 26:] <= 1)             # sensor intensities
+        assert np.all(ob[:, nb:] >= 0) and np.all(ob[:, nb:] <= 1)             # sensor intensities
+        assert np.all(np.abs(s[:, 0:2]) < 7.6)                                  # walls hold the robot in the arena
+    if kind == K.HRL_ANT_GATHER:
         assert np.all(np.abs(ob[:, :26]) <= 5)                                  # upstream clip
-        assert np.all(np.abs(s[:, 0:2]) < 7.6)                                  # walls hold the ant in the arena
     if kind == K.HRL_ANT_MAZE:
         assert np.all(ob[:, 28:] >= 0) and np.all(ob[:, 28:] <= 1)
         assert np.allclose(np.linalg.norm(ob[:, 26:28], axis=1), 1, atol=1e-5)  # normed target vector
+    if kind in (K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ):
         assert np.all(np.abs(s[:, 0]) < 5.1) and np.all(np.abs(s[:, 1]) < 9.1)
+    if kind == K.HRL_ANT_MAZE_MJ:
+        assert np.all(ob[:, 29:39] >= 0) and np.all(ob[:, 29:39] <= 1) and np.all(ob[:, 39:59] == 0)  # walls | pit, moveable zeros
+    if kind == K.HRL_ANT_FLAGRUN:
+        assert np.all(np.abs(ob[:, :28]) <= 5) and np.all(np.abs(s[:, 0:2]) < 6.1)
+
+
+def test_mixed_shard_full_size_two_streams():
+    """BASELINE.json configs[4] per GPU at full size: 2048 AntGather + 2048 PointGather (global ids 0..4095), the two
+    hrl_step launches of a step issued on two HIP streams as bench.py --kind mixed does; 256 sampled rows of each half
+    re-run on the oracle bit for bit, and the overlapped run equals a serialized run of the same shard."""
+    n = 2048
+    ant, _ = make(K.HRL_ANT_GATHER, n, seed=31)
+    pt, _ = make(K.HRL_POINT_GATHER, n, seed=31, env_id_offset=n)
+    ant_s, _ = make(K.HRL_ANT_GATHER, n, seed=31)
+    pt_s, _ = make(K.HRL_POINT_GATHER, n, seed=31, env_id_offset=n)
+    for e in (ant, pt, ant_s, pt_s):
+        e.reset()
+    torch.cuda.synchronize()
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    a8 = torch.rand(41, n, 8, device='cuda', generator=gen) * 2 - 1
+    a2 = torch.rand(41, n, 2, device='cuda', generator=gen) * 2 - 1
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for t in range(40):
+        with torch.cuda.stream(s1):
+            ant.step(a8[t])
+        with torch.cuda.stream(s2):
+            pt.step(a2[t])
+        ant_s.step(a8[t]); pt_s.step(a2[t])
+    torch.cuda.synchronize()
+    assert torch.equal(ant.state, ant_s.state) and torch.equal(pt.state, pt_s.state) and torch.equal(pt.items, pt_s.items)
+    rows = np.random.RandomState(4).choice(n, 256, replace=False)
+    pre = [(e.state.cpu().numpy(), e.items.cpu().numpy(), e.aux.cpu().numpy()) for e in (ant, pt)]
+    with torch.cuda.stream(s1):
+        _, ra, da, _ = ant.step(a8[40])
+    with torch.cuda.stream(s2):
+        _, rp, dp, _ = pt.step(a2[40])
+    torch.cuda.synchronize()
+    sampled_row_parity(K.HRL_ANT_GATHER, ant, rows, *pre[0], a8[40].cpu().numpy(), ra, da, seed=31)
+    sampled_row_parity(K.HRL_POINT_GATHER, pt, rows, *pre[1], a2[40].cpu().numpy(), rp, dp, seed=31)
+    returns = torch.cat([ant.info[:, 2], pt.info[:, 2]])  # what the all-gather of a mixed shard carries
+    assert returns.shape == (2 * n,) and bool(torch.isfinite(returns).all())
 
 
 def test_batch_composition_invariance():

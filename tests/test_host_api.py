@@ -3,6 +3,7 @@ mirror matches the C structs, the env classes mirror the reference's constructor
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -138,3 +139,44 @@ def test_gymnasium_adapter_five_tuple():
     o = [gb.step(None) for _ in range(5)]
     assert o[1][2].tolist() == [False, True] and o[1][3].tolist() == [False, False]   # env 1 terminated at t=2
     assert o[4][2].tolist() == [False, False] and o[4][3].tolist() == [True, False]   # env 0 truncated at the limit
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """bench.py --gpus N without WORLD_SIZE starts the N ranks itself (torch.distributed.run on 127.0.0.1) before it
+    imports anything that could touch the GPU, and hands back their exit status."""
+    import importlib
+    import bench
+    importlib.reload(bench)
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls['cmd'], calls['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--kind', 'mixed'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = calls['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=4' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '4', '--steps', '3', '--kind', 'mixed']
+    assert calls['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert 'torch' not in bench.__dict__  # the parent's module level never imports torch
+
+
+def test_bench_roofline_reports_hbm_and_valu():
+    import bench
+    r = bench.roofline('gather', 4096, 70e-6)
+    assert r['bound'] == 'hbm' and abs(r['achieved'] - 581 * 4096 / 70e-6 / 1e9) < 1e-9 and r['peak'] == 8000.0
+    v = r['valu']
+    assert v['issue_cycles_per_simd'] == v['insts_per_env'] * 4096 / 1024 * 2
+    assert 0 < v['frac'] < v['frac_at_held_clock'] < 1
+
+
+def test_default_config_rejects_unknown_fields():
+    from hrl_pybullet_envs_amd import _lib
+    with pytest.raises(TypeError):
+        _lib.default_config(K.HRL_ANT_GATHER, n_foods=3)
+    with pytest.raises(TypeError):
+        _lib.default_config(K.HRL_ANT_GATHER, model_gravty=3.0)

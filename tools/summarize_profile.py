@@ -20,8 +20,12 @@ def main():
     out_dir = os.path.join(ROOT, 'profiles')
     os.makedirs(out_dir, exist_ok=True)
     stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
+    kernel_us = None
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
+        for r in rows:
+            if 'k_step' in r['Name']:
+                kernel_us = float(r['AverageNs']) / 1e3
         with open(os.path.join(out_dir, f'{tag}_kernel_stats.csv'), 'w') as f:
             w = csv.writer(f)
             w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
@@ -47,8 +51,15 @@ def main():
     if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
         path = os.path.join(out_dir, 'pmc_summary.json')
         summ = json.load(open(path)) if os.path.exists(path) else {}
-        summ[kind] = {'tag': tag, 'fetch_bytes_per_env': counters['FETCH_SIZE']['mean_per_launch'] * 1024 / n_envs,
+        summ[kind] = {'tag': tag, 'envs_per_launch': n_envs,
+                      'fetch_bytes_per_env': counters['FETCH_SIZE']['mean_per_launch'] * 1024 / n_envs,
                       'write_bytes_per_env': counters['WRITE_SIZE']['mean_per_launch'] * 1024 / n_envs}
+        if 'SQ_INSTS_VALU' in counters:  # one wave per env: per-wave counters are per-env counters
+            summ[kind]['valu_insts_per_env'] = counters['SQ_INSTS_VALU']['mean_per_wave']
+        if 'SQ_WAVE_CYCLES' in counters:  # quad-cycles -> cycles (MI355X_MICROARCH.md, cycle constants)
+            summ[kind]['wave_cycles_per_env'] = counters['SQ_WAVE_CYCLES']['mean_per_wave'] * 4
+        if kernel_us is not None:
+            summ[kind]['kernel_us_profiled'] = kernel_us
         json.dump(summ, open(path, 'w'), indent=1)
     print(json.dumps({k: round(v['mean_per_wave'], 1) for k, v in counters.items()}))
 
