@@ -1440,6 +1440,13 @@ void FN(orc_ant_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *t
     if (info3) { info3[0] = dbg.n_rows; info3[1] = dbg.n_limits; info3[2] = dbg.n_contacts; }
 }
 
+/* n point-bot substeps on q[7] (x,y,z,quat xyzw) and u[6] (omega, v) under a constant world-frame force (tests) */
+void FN(orc_point_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *force, int n) {
+    FN(orc_env) E;
+    FN(orc_env_init)(cfg, &E);
+    for (int s = 0; s < n; ++s) FN(orc_point_substep)(&E.K, &E.W, q, u, force);
+}
+
 #undef NJ
 #undef NBODY
 #undef NDOF

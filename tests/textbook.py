@@ -1,0 +1,103 @@
+"""ctypes binding of oracle/libtextbook.so (the frozen fp64 textbook reference).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAXC, MAXR, MAXBOX = 12, 44, 20
+_LIB = None
+
+
+class tb_params(C.Structure):
+    _fields_ = [('density', C.c_double), ('gravity', C.c_double), ('h', C.c_double), ('erp_c', C.c_double), ('erp_l', C.c_double),
+                ('mu', C.c_double), ('mu_self', C.c_double), ('cdist', C.c_double), ('lmargin', C.c_double), ('vmax', C.c_double),
+                ('limp_max', C.c_double), ('ground_z', C.c_double),
+                ('iters', C.c_int32), ('self_collision', C.c_int32), ('n_planes', C.c_int32), ('n_boxes', C.c_int32),
+                ('plane_n', (C.c_double * 3) * 4), ('plane_d', C.c_double * 4),
+                ('box_lo', (C.c_double * 3) * MAXBOX), ('box_hi', (C.c_double * 3) * MAXBOX)]
+
+
+class tb_out(C.Structure):
+    _fields_ = [('n_limits', C.c_int32), ('n_contacts', C.c_int32), ('n_rows', C.c_int32), ('n_candidates', C.c_int32),
+                ('row_kind', C.c_int32 * MAXR), ('row_normal', C.c_int32 * MAXR), ('contact_surface', C.c_int32 * MAXC),
+                ('contact_dist', C.c_double * MAXC), ('lambda_', C.c_double * MAXR), ('w_final', C.c_double * MAXR),
+                ('total_mass', C.c_double)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, 'oracle', 'libtextbook.so')
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'libtextbook.so'])
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def params(cfg, items=None, self_collision=None):
+    """tb_params for an hrl_config: the static world is built here, independently of the oracle's orc_world_init
+    (walls 0.1 thick centred on +-size/2: sizeable_enclosed_scene.py:46-57, wall.xml:19; maze box: box.xml:19,
+    maze_scene.py:12-13; item cubes 0.25 m at z = 0.1: food.xml:12, gather_scene.py:62)."""
+    from hrl_pybullet_envs_amd import _capi as K
+    m = cfg.model
+    p = tb_params()
+    p.density, p.gravity, p.h, p.erp_c, p.erp_l = m.density, m.gravity, m.timestep, m.contact_erp, m.limit_erp
+    p.mu, p.mu_self = float(np.float32(m.friction_ground) * np.float32(m.friction_robot)), float(np.float32(m.friction_robot) * np.float32(m.friction_robot))
+    p.cdist, p.lmargin, p.vmax, p.limp_max, p.ground_z = m.contact_dist, m.limit_margin, m.max_joint_vel, m.limit_max_impulse, m.ground_z
+    p.iters = m.solver_iters
+    p.self_collision = int(getattr(m, 'self_collision', 0)) if self_collision is None else int(self_collision)
+    kind = cfg.env_kind
+    hx = hy = 0.0
+    if kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) or (kind == K.HRL_ANT_FLAGRUN and (cfg.flag_enclosed or cfg.use_sensor)):
+        hx, hy = cfg.world_size[0] / 2, cfg.world_size[1] / 2
+    if kind in (K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ):
+        hx, hy = 5.0, 9.0
+    if hx > 0:
+        p.n_planes = 4
+        for i, (n, d) in enumerate([((-1, 0, 0), -(hx - 0.05)), ((1, 0, 0), -(hx - 0.05)), ((0, -1, 0), -(hy - 0.05)), ((0, 1, 0), -(hy - 0.05))]):
+            p.plane_n[i][0], p.plane_n[i][1], p.plane_n[i][2] = n
+            p.plane_d[i] = d
+    boxes = []
+    if kind in (K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ):
+        boxes.append(((-5, -2, 0), (1, 2, 2)))
+    if items is not None:
+        he = 0.125
+        for x, y in np.asarray(items, float).reshape(-1, 2):
+            boxes.append(((x - he, y - he, 0.1 - he), (x + he, y + he, 0.1 + he)))
+    p.n_boxes = len(boxes)
+    for i, (lo, hi) in enumerate(boxes):
+        for k in range(3):
+            p.box_lo[i][k], p.box_hi[i][k] = lo[k], hi[k]
+    return p
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ant_substep(p, q, u, tau):
+    q, u, tau = np.array(q, np.float64), np.array(u, np.float64), np.ascontiguousarray(tau, np.float64)
+    out = tb_out()
+    lib().tb_ant_substep(C.byref(p), _p(q), _p(u), _p(tau), C.byref(out))
+    return q, u, out
+
+
+def point_substep(p, q, u, force):
+    q, u, force = np.array(q, np.float64), np.array(u, np.float64), np.ascontiguousarray(force, np.float64)
+    out = tb_out()
+    lib().tb_point_substep(C.byref(p), _p(q), _p(u), _p(force), C.byref(out))
+    return q, u, out
+
+
+def ant_dynamics(p, q, u, tau):
+    M, b, ud = np.zeros((14, 14)), np.zeros(14), np.zeros(14)
+    lib().tb_ant_dynamics(C.byref(p), _p(np.ascontiguousarray(q, np.float64)), _p(np.ascontiguousarray(u, np.float64)),
+                          _p(np.ascontiguousarray(tau, np.float64)), _p(M), _p(b), _p(ud))
+    return M, b, ud
+
+
+def ant_energy_momentum(p, q, u):
+    o = np.zeros(8)
+    lib().tb_ant_energy_momentum(C.byref(p), _p(np.ascontiguousarray(q, np.float64)), _p(np.ascontiguousarray(u, np.float64)), _p(o))
+    return o
