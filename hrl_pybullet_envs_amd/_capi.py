@@ -1,7 +1,7 @@
 """ctypes mirror of include/hrl_envs.h (structs + constants only; no library loading here)."""
 import ctypes as C
 
-HRL_ABI_VERSION = 3
+HRL_ABI_VERSION = 4
 HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER, HRL_ANT_MAZE_MJ, HRL_ANT_FLAGRUN = 0, 1, 2, 3, 4, 5
 HRL_STATE_STRIDE = 32
 HRL_QPOS_OFF, HRL_QVEL_OFF, HRL_EPRET_OFF, HRL_INITZ_OFF, HRL_POTENTIAL_OFF = 0, 15, 29, 30, 31
@@ -11,6 +11,7 @@ HRL_MAX_BINS = 16
 HRL_AUX_STRIDE = 4
 HRL_INFO_STRIDE = 4
 HRL_MAX_TARGETS = 8
+HRL_MAX_GOALS = 15
 HRL_OK, HRL_ERR_BAD_ARG, HRL_ERR_HIP, HRL_ERR_NO_DEVICE = 0, 1, 2, 3
 
 
@@ -20,7 +21,7 @@ class hrl_model(C.Structure):
                 ('contact_erp', C.c_float), ('limit_erp', C.c_float), ('friction_ground', C.c_float),
                 ('friction_robot', C.c_float), ('contact_dist', C.c_float), ('limit_margin', C.c_float),
                 ('max_joint_vel', C.c_float), ('limit_max_impulse', C.c_float), ('ground_z', C.c_float),
-                ('point_force', C.c_float)]
+                ('point_force', C.c_float), ('self_collision', C.c_int32), ('item_collision', C.c_int32)]
 
 
 class hrl_config(C.Structure):
@@ -42,6 +43,7 @@ class hrl_config(C.Structure):
                 ('walk_target', C.c_float * 2),
                 ('flag_size', C.c_float), ('flag_max_targets', C.c_int32), ('flag_timeout', C.c_int32),
                 ('flag_switch_on_collision', C.c_int32), ('flag_enclosed', C.c_int32), ('flag_max_target_dist', C.c_float),
+                ('flag_manual_goals', C.c_int32),
                 ('model', hrl_model)]
 
     def copy(self):

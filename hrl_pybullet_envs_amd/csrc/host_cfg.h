@@ -40,6 +40,9 @@ inline int default_config(int32_t kind, hrl_config *c) {
     m.contact_dist = 0.02f; m.limit_margin = 0.25f; m.max_joint_vel = 100.f; m.limit_max_impulse = 100.f;
     m.ground_z = 0.005f;  /* plane.xml:19 */
     m.point_force = 500.f; /* point_bot.py:29 */
+    m.self_collision = kind != HRL_POINT_GATHER; /* URDF_USE_SELF_COLLISION | ..._EXCLUDE_ALL_PARENTS */
+    m.item_collision = kind == HRL_ANT_GATHER || kind == HRL_POINT_GATHER; /* food.xml / poison.xml are collidable boxes */
+    if (kind != HRL_ANT_GATHER && kind != HRL_POINT_GATHER) c->walk_target[0] = 1000.f; /* upstream WalkerBase default walk target (1e3, 0) until the env sets one */
     if (kind == HRL_ANT_MAZE) {
         static const float t[4][2] = {{2, -3}, {2, 0}, {2, 3}, {-2, 4}}; /* ant_maze_bullet_env.py:13-14 */
         c->sensor_range = 5.f; c->sensor_span = 6.28318530717958647692f; c->n_targets = 4;
@@ -94,7 +97,7 @@ inline std::string validate(const hrl_config *c) {
     if (gather) {
         if (c->n_food < 0 || c->n_poison < 0 || c->n_food + c->n_poison > HRL_MAX_ITEMS) return "n_food + n_poison must be within 0..16";
         if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
-        if (!(c->robot_coll_dist > 0)) return "robot_coll_dist <= 0 (contact based pickup, ant_gather_env.py:113-116) is not implemented";
+        if (!(c->robot_coll_dist > 0) && !c->model.item_collision) return "robot_coll_dist <= 0 (contact based pickup, ant_gather_env.py:113-116) needs model.item_collision";
         if (!(c->world_size[0] > 1 && c->world_size[1] > 1 && c->world_size[0] < 50 && c->world_size[1] < 50)) return "world_size must be within (1, 50)";
         if (!(c->sensor_range > 0) || !(c->sensor_span > 0)) return "sensor_range and sensor_span must be positive";
     }
@@ -102,18 +105,22 @@ inline std::string validate(const hrl_config *c) {
         if (c->n_targets < 1 || c->n_targets > HRL_MAX_TARGETS) return "n_targets must be within 1..8";
         if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
         if (c->target_encoding != 0 && c->target_encoding != 1) return "target_encoding must be 0 (normed_vec) or 1 (angle)"; /* utils.py:66-68 */
-        if (!c->sense_walls && !(c->sensor_span > 0)) return "sensor_span must be positive";
+        const bool walls = c->env_kind == HRL_ANT_MAZE_MJ || c->sense_walls; /* the Mj variant always senses walls (ant_maze_mj_env.py:58) */
+        if ((walls || c->sense_target) && !(c->sensor_span > 0)) return "sensor_span must be positive";
+        /* sizeable_enclosed_scene.py:68-71: a span other than 2 pi spaces the rays by i / (n_bins - 1) */
+        if (walls && c->n_bins < 2 && c->sensor_span != 6.28318530717958647692f) return "n_bins must be >= 2 unless sensor_span == 2 pi (the wall sensor divides by n_bins - 1)";
         if (!(c->sensor_range > 0)) return "sensor_range must be positive";
     }
     if (c->env_kind == HRL_ANT_FLAGRUN) {
         /* ant_flagrun_env.py:17-18: a goal list (max_targets > 0) or goals near the robot (max_target_dist > 0), never both */
         const bool list_mode = c->flag_max_target_dist == 0.f && c->flag_max_targets > 0, close_mode = c->flag_max_targets <= 0 && c->flag_max_target_dist > 0.f;
-        if (!list_mode && !close_mode) return "exactly one of flag_max_targets > 0 (with flag_max_target_dist == 0) and flag_max_target_dist > 0 (with flag_max_targets <= 0) must hold";
+        if (!list_mode && !close_mode && !c->flag_manual_goals) return "exactly one of flag_max_targets > 0 (with flag_max_target_dist == 0) and flag_max_target_dist > 0 (with flag_max_targets <= 0) must hold";
         if (list_mode && c->flag_max_targets > 65535) return "flag_max_targets must be <= 65535";
         if (close_mode && !(c->flag_max_target_dist / 2 > c->tol)) return "flag_max_target_dist / 2 must exceed tol (the per-axis offset is drawn from U(tol, max_target_dist / 2))";
         if (c->flag_timeout > 32767) return "flag_timeout must be <= 32767";
         if (!(c->flag_size > 1.0f)) return "flag_size must exceed 1 (targets are rejected within 0.5 of the origin)";
-        if (c->use_sensor && (c->n_bins < 2 || c->n_bins > HRL_MAX_BINS)) return "sensor_bins must be within 2..16";
+        if (c->use_sensor && (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS)) return "sensor_bins must be within 1..16";
+        if (c->use_sensor && c->n_bins < 2 && c->sensor_span != 6.28318530717958647692f) return "sensor_bins must be >= 2 unless sensor_span == 2 pi (the wall sensor divides by n_bins - 1)";
     }
     if (obs_dim(c) > 64) { snprintf(buf, sizeof buf, "observation width %d exceeds 64", obs_dim(c)); return buf; }
     const hrl_model &m = c->model;
@@ -182,7 +189,8 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     }
     if (maze_world) { d.n_boxes = 1; d.box_lo[0] = -5; d.box_lo[1] = -2; d.box_lo[2] = 0; d.box_hi[0] = 1; d.box_hi[1] = 2; d.box_hi[2] = 2; }
     d.flag_size = c.flag_size; d.flag_max_targets = c.flag_max_targets; d.flag_timeout = c.flag_timeout;
-    d.flag_switch = c.flag_switch_on_collision; d.flag_mtd = c.flag_max_target_dist;
+    d.flag_switch = c.flag_switch_on_collision; d.flag_mtd = c.flag_max_target_dist; d.flag_manual = c.flag_manual_goals;
+    d.self_collision = m.self_collision; d.item_collision = m.item_collision; d.mu_self = m.friction_robot * m.friction_robot;
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
 }
 

@@ -78,6 +78,9 @@ struct GpuExec {
         __syncthreads();
         return __popcll(m);
     }
+    /* lane mask of a predicate (v_cmp into an SGPR pair) */
+    template <class P>
+    __device__ __forceinline__ unsigned long long each_ballot(P pred) { return __ballot(pred(lane)); }
     /* solver row `src` (wave-uniform): every lane produces the candidate {impulse, change} of its own row; lane `src`
      * keeps its candidate impulse (v_cndmask on a scalar lane mask) and its change is broadcast to the wave
      * (v_readlane_b32) for every lane to apply */
@@ -113,6 +116,12 @@ __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__rest
     LaneRegs regs;
     GpuExec x{L, regs, (int)threadIdx.x};
     reset_entry<KIND>(x, b, *cp, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(64, 4) void k_set_goals(DevBufs b, const DevCfg *__restrict__ cp, const float *goals_xy, int n_goals) {
+    __shared__ WaveLds L;
+    LaneRegs regs;
+    GpuExec x{L, regs, (int)threadIdx.x};
+    set_goals_entry(x, b, *cp, (int)blockIdx.x, goals_xy, n_goals);
 }
 using kernel_fn = void (*)(DevBufs, const DevCfg *);
 kernel_fn step_kernel(int kind) {
@@ -212,12 +221,12 @@ int hrl_destroy(hrl_handle *h) {
 }
 
 static bool needs_items(const DevCfg &dc) {
-    return dc.kind == HRL_ANT_GATHER || dc.kind == HRL_POINT_GATHER || (dc.kind == HRL_ANT_FLAGRUN && dc.flag_mtd > 0.f);
+    return dc.kind == HRL_ANT_GATHER || dc.kind == HRL_POINT_GATHER || (dc.kind == HRL_ANT_FLAGRUN && (dc.flag_mtd > 0.f || dc.flag_manual));
 }
 
 int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *stream) {
     if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_reset: null handle or buffer");
-    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist)");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist or manual goals)");
     hipLaunchKernelGGL(reset_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_reset launch");
@@ -226,7 +235,7 @@ int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *st
 int hrl_step(hrl_handle *h, const hrl_buffers *b, void *stream) {
     if (!h || !b || !b->state || !b->aux || !b->obs || !b->actions || !b->reward || !b->done || !b->info)
         return fail(HRL_ERR_BAD_ARG, "hrl_step: null handle or buffer");
-    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist)");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist or manual goals)");
     hipLaunchKernelGGL(step_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_step launch");
@@ -245,6 +254,15 @@ int hrl_set_state(hrl_handle *h, const hrl_buffers *b, const float *qpos, const 
     hipLaunchKernelGGL(k_set_state, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->state, qpos, qvel, n);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_set_state launch");
+}
+
+int hrl_set_goals(hrl_handle *h, const hrl_buffers *b, const float *goals_xy, int32_t n_goals, const uint8_t *mask, void *stream) {
+    if (!h || !b || !b->state || !b->aux || !b->obs || !b->items || !goals_xy) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: null handle or buffer");
+    if (h->dc.kind != HRL_ANT_FLAGRUN || !h->dc.flag_manual) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: only for AntFlagrun with flag_manual_goals (manual_goal_creation, ant_flagrun_env.py:24)");
+    if (n_goals < 1 || n_goals > HRL_MAX_GOALS) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: n_goals must be within 1..15");
+    hipLaunchKernelGGL(k_set_goals, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc, goals_xy, (int)n_goals);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_set_goals launch");
 }
 
 const char *hrl_last_error(void) { return g_err.c_str(); }

@@ -77,7 +77,9 @@ struct DevCfg {
     int n_boxes;
     float box_lo[3], box_hi[3];
     float flag_size, flag_mtd; /* flag_mtd > 0: goals near the robot (ant_flagrun_env.py:80-89), kept in items[0..1] */
-    int flag_max_targets, flag_timeout, flag_switch;
+    int flag_max_targets, flag_timeout, flag_switch, flag_manual;
+    int self_collision, item_collision;
+    float mu_self; /* friction between two ant links */
     int obs_dim, act_dim;
 };
 
@@ -111,7 +113,7 @@ struct alignas(16) WaveLds {
             float irew[16];      /* per item: pickup reward */
             float red[16];
             int flags[8];        /* 0: non-finite obs seen, 1: done, 3: flagrun retarget, 4: flagrun packed goal state */
-            float scal[8];       /* 0: reward, 1: food_rew, 2: dead_rew, 3: walk_target_dist, 4: yaw, 5: joints_at_limit */
+            float scal[8];       /* 0: reward, 1: food_rew, 2: dead_rew, 3: walk_target_dist, 4: yaw, 5: joints_at_limit, 6-7: parts centroid xy */
         };
     };
     float legI[4][28];   /* per leg, handed to the base: articulated inertia [0..20] (upper triangle), bias force [21..26] */
@@ -133,7 +135,11 @@ struct alignas(16) WaveLds {
     float cr[MAXC][4];       /* contact point relative to O */
     float cdir[3][MAXC][4];  /* contact frame: normal, tangent 1, tangent 2 (tangent_basis of the normal) */
     float cdist_[MAXC];
+    float cmu[MAXC];     /* friction coefficient of the contact (ground/walls/cubes: mu, link against link: mu_self) */
     int clink[MAXC];     /* level | leg << 2 */
+    int clink2[MAXC];    /* self contacts: level | leg << 2 of the second body (leg2 > leg), else -1 */
+    int csurf[MAXC];     /* what the contact is with: SURF_* codes */
+    float J2[MAXR][2];   /* self-contact rows: the (negated) hip / ankle entries of the second body's leg (substeps with a self contact only) */
     int ljoint[NJ];
     float lsign[NJ], ldist[NJ];
     int gtouch[16];
@@ -145,7 +151,8 @@ struct LaneRegs {
     float ud;                        /* dof map: the lane's velocity component */
     float rI[21], rp[6];             /* body map (phases K1 -> K2 -> B): the lane's rigid-body spatial inertia and bias force */
     float Jb[6], Jh, Ja;             /* row map: the row's Jacobian, sparse: torso twist part + the hip / ankle entries */
-    int jslot;                       /* row map: dof slot of Jh (Ja is the next slot): 6 + 2 * leg                   */
+    int jslot;                       /* row map: dof slot of Jh (Ja is the next slot): 6 + 2 * leg, | (6 + 2 * leg2) << 8 for WaveLds::J2 */
+    float mu;                        /* row map: friction rows: friction coefficient of their contact */
     float An[MAXB], Af[MAXF];        /* row map: the row's line of C = I - D^-1 A (A = J M^-1 J^T): limit/normal columns, friction columns */
     float c, lam, bias, lo, hi;      /* row map: unclamped impulse candidate lam - w / A_ii, impulse, bias, bounds */
     int fn;                          /* row map: friction rows: index of their normal row, else -1 */
@@ -582,57 +589,117 @@ HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, fl
     du[14] = 0.f; du[15] = 0.f;
 }
 
-struct Hit { bool ok; float dist, n[3], c[3], rad; int link; };
+/* what a contact is with (WaveLds::csurf; the oracle's ORC_SURF_* codes) */
+constexpr int SURF_BOX = 8, SURF_ITEM = 16, SURF_SELF = 64;
+constexpr float ITEM_HALF = 0.125f, ITEM_Z = 0.1f; /* assets/food.xml:12,19 (box size 0.25), gather_scene.py:62 */
 
-/* Phase C helper: signed distance of contact sphere `lane` (0 torso, 1+3l hip, 2+3l ankle, 3+3l tip; -1 = idle lane)
- * to surface f (0 ground, 1..n_planes lateral half-spaces, then boxes) */
-HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q, int lane, int f) {
+/* r = contact point relative to O, n = normal towards the body `link`; link2 >= 0: against that ant body (self contact) */
+struct Hit { bool ok; float dist, n[3], r[3], mu; int link, link2, surf; };
+
+/* signed distance of a sphere (centre p, radius rad) to the axis-aligned box [lo, hi]; n = unit normal towards the sphere */
+HRL_DEV float sphere_vs_box(const float *p, float rad, const float *lo, const float *hi, float *n) {
+    float d[3], d2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { float cp = clampf(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 = fma_(d[k], d[k], d2); }
+    if (d2 > 0.f) {
+        float len = sqrtf(d2);
+        n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len;
+        return len - rad;
+    }
+    if (!(d2 == 0.f)) { n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; return 1e30f; } /* non-finite centre: no contact */
+    /* centre inside the box: leave through the nearest face */
+    int best = 0; float bd = 1e30f, sgn = 1.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float dl = p[k] - lo[k], dh = hi[k] - p[k];
+        if (dl < bd) { bd = dl; best = k; sgn = -1.f; }
+        if (dh < bd) { bd = dh; best = k; sgn = 1.f; }
+    }
+    n[0] = best == 0 ? sgn : 0.f; n[1] = best == 1 ? sgn : 0.f; n[2] = best == 2 ? sgn : 0.f;
+    return -bd - rad;
+}
+
+/* Phase C helper: signed distance of contact sphere `sph` (0 torso, 1+3l hip, 2+3l ankle, 3+3l tip; -1 = idle lane)
+ * to surface f: 0 ground, 1..n_planes lateral half-spaces, n_planes+1.. world boxes; item >= 0: the item cube `item` */
+HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q, int sph, int f, int item) {
     Hit h;
-    h.ok = false; h.dist = 0.f; h.rad = 0.f; h.link = 0;
-    h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f;
-    if (lane < 0 || lane >= 13) return h;
+    h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu;
+    h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.r[0] = h.r[1] = h.r[2] = 0.f;
+    if (sph < 0 || sph >= 13) return h;
     int level = 0, leg = 0;
-    h.rad = c.r_torso;
-    if (lane > 0) {
-        leg = (lane - 1) / 3; level = (lane - 1) % 3;
+    float rad = c.r_torso, ctr[3] = {0.f, 0.f, 0.f};
+    if (sph > 0) {
+        leg = (sph - 1) / 3; level = (sph - 1) % 3;
         const float *src = level == 0 ? L.ph[leg] : (level == 1 ? L.pa[leg] : L.tip[leg]);
-        h.c[0] = src[0]; h.c[1] = src[1]; h.c[2] = src[2];
-        h.rad = c.r_caps;
+        ctr[0] = src[0]; ctr[1] = src[1]; ctr[2] = src[2];
+        rad = c.r_caps;
     }
     h.link = level | (leg << 2);
-    float p[3] = {q[0] + h.c[0], q[1] + h.c[1], q[2] + h.c[2]};
-    if (f == 0) h.dist = (p[2] - c.ground_z) - h.rad;
+    float p[3] = {q[0] + ctr[0], q[1] + ctr[1], q[2] + ctr[2]};
+    if (item >= 0) {
+        const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
+        const float lo[3] = {ix - ITEM_HALF, iy - ITEM_HALF, ITEM_Z - ITEM_HALF}, hi[3] = {ix + ITEM_HALF, iy + ITEM_HALF, ITEM_Z + ITEM_HALF};
+        h.dist = sphere_vs_box(p, rad, lo, hi, h.n); h.surf = SURF_ITEM + item;
+    } else if (f == 0) h.dist = (p[2] - c.ground_z) - rad;
     else if (f <= c.n_planes) {
         h.n[0] = c.plane_n[f - 1][0]; h.n[1] = c.plane_n[f - 1][1]; h.n[2] = c.plane_n[f - 1][2];
-        h.dist = (dot3(h.n, p) - c.plane_d[f - 1]) - h.rad;
-    } else {
-        float d[3], d2 = 0.f;
+        h.dist = (dot3(h.n, p) - c.plane_d[f - 1]) - rad; h.surf = f;
+    } else { h.dist = sphere_vs_box(p, rad, c.box_lo, c.box_hi, h.n); h.surf = SURF_BOX + (f - 1 - c.n_planes); }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { float cp = clampf(p[k], c.box_lo[k], c.box_hi[k]); d[k] = p[k] - cp; d2 = fma_(d[k], d[k], d2); }
-        if (d2 > 0.f) {
-            float len = sqrtf(d2);
-            h.n[0] = d[0] / len; h.n[1] = d[1] / len; h.n[2] = d[2] / len;
-            h.dist = len - h.rad;
-        } else { /* centre inside the box: leave through the nearest face */
-            int best = 0; float bd = 1e30f, sgn = 1.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float dl = p[k] - c.box_lo[k], dh = c.box_hi[k] - p[k];
-                if (dl < bd) { bd = dl; best = k; sgn = -1.f; }
-                if (dh < bd) { bd = dh; best = k; sgn = 1.f; }
-            }
-            h.n[0] = best == 0 ? sgn : 0.f; h.n[1] = best == 1 ? sgn : 0.f; h.n[2] = best == 2 ? sgn : 0.f;
-            h.dist = -bd - h.rad;
-        }
-    }
+    for (int k = 0; k < 3; ++k) h.r[k] = fma_(-rad, h.n[k], ctr[k]);
     h.ok = h.dist < c.cdist;
+    return h;
+}
+
+/* Phase C helper, self-collision: capsule pair `id` = 8 * legpair + 3 * segA + segB - 1 (legpair (0,1),(0,2),(0,3),(1,2),
+ * (1,3),(2,3); seg 0 = the jointless leg capsule O -> hip point (torso body), 1 = aux, 2 = foot; (0,0) skipped).
+ * Closest points of the two capsule axes (Ericson, Real-Time Collision Detection 5.1.9) with the fixed squared segment
+ * lengths 0.08 / 0.32 and their exact reciprocals 12.5 / 3.125; contact point = midway between the two surface points. */
+HRL_DEV Hit capsule_pair(const DevCfg &c, const WaveLds &L, int id) {
+    Hit h;
+    h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu_self;
+    h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.r[0] = h.r[1] = h.r[2] = 0.f;
+    if (id < 0 || id >= 48) return h;
+    const int pp = id >> 3, k = (id & 7) + 1, a = k / 3, b = k - 3 * a;
+    const int i = pp < 3 ? 0 : (pp < 5 ? 1 : 2), j = pp < 3 ? pp + 1 : (pp < 5 ? pp - 1 : 3);
+    float p1[3], q1[3], p2[3], q2[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        p1[t] = a == 0 ? 0.f : (a == 1 ? L.ph[i][t] : L.pa[i][t]); q1[t] = a == 0 ? L.ph[i][t] : (a == 1 ? L.pa[i][t] : L.tip[i][t]);
+        p2[t] = b == 0 ? 0.f : (b == 1 ? L.ph[j][t] : L.pa[j][t]); q2[t] = b == 0 ? L.ph[j][t] : (b == 1 ? L.pa[j][t] : L.tip[j][t]);
+    }
+    const float aa = a == 2 ? 0.32f : 0.08f, ia = a == 2 ? 3.125f : 12.5f, ee = b == 2 ? 0.32f : 0.08f, ie = b == 2 ? 3.125f : 12.5f;
+    float d1[3], d2[3], r[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { d1[t] = q1[t] - p1[t]; d2[t] = q2[t] - p2[t]; r[t] = p1[t] - p2[t]; }
+    const float f = dot3(d2, r), cc = dot3(d1, r), bb = dot3(d1, d2);
+    const float denom = fma_(aa, ee, -(bb * bb));
+    float sp = 0.f, tp;
+    if (denom > 1e-9f) sp = clampf(fma_(bb, f, -(cc * ee)) / denom, 0.f, 1.f);
+    tp = fma_(bb, sp, f) * ie;
+    if (tp < 0.f) { tp = 0.f; sp = clampf(-cc * ia, 0.f, 1.f); }
+    else if (tp > 1.f) { tp = 1.f; sp = clampf((bb - cc) * ia, 0.f, 1.f); }
+    float c1[3], c2[3], dv[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { c1[t] = fma_(d1[t], sp, p1[t]); c2[t] = fma_(d2[t], tp, p2[t]); dv[t] = c1[t] - c2[t]; }
+    const float d2n = dot3(dv, dv), thr = (c.r_caps + c.r_caps) + c.cdist;
+    h.ok = d2n < thr * thr;
+    h.link = a | (i << 2); h.link2 = b | (j << 2); h.surf = SURF_SELF + id;
+    if (h.ok) {
+        const float len = sqrtf(d2n);
+        h.dist = len - (c.r_caps + c.r_caps);
+        if (len > 0.f) { h.n[0] = dv[0] / len; h.n[1] = dv[1] / len; h.n[2] = dv[2] / len; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) h.r[t] = 0.5f * (c1[t] + c2[t]);
+    }
     return h;
 }
 
 struct LimitHit { bool ok; float sgn, dist; };
 
 /* Phase R1 (row map): Jacobian row and its velocity response B = M^-1 J^T.  J, bias and bounds stay in the lane's
- * registers, B goes to LDS (every row needs every B to build its row of A). */
+ * registers, B goes to LDS (every row needs every B to build its row of A).  Contacts between two ant bodies get the
+ * first body's part here and the second body's in phase_self_rows. */
 HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane, int nL, int nC) {
     const int nR = nL + 3 * nC;
     /* Lanes beyond the last row recompute row 0 and discard it: every lane then (re)defines all of its solver
@@ -640,12 +707,12 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
      * would, and the 60 of them would be spilled in the register-hungry leg phases). */
     const bool active = lane < nR;
     const int row_id = active ? lane : 0;
-    float B[16], bias, hi = 0.f, Jh = 0.f, Ja = 0.f;
+    float B[16], bias, hi = 0.f, Jh = 0.f, Ja = 0.f, mu = 0.f;
     int frn = -1;
     if (nR == 0) { /* no rows this substep (wave-uniform): still define every register */
 #pragma unroll
         for (int k = 0; k < 6; ++k) g.Jb[k] = 0.f;
-        g.Jh = 0.f; g.Ja = 0.f; g.jslot = 6;
+        g.Jh = 0.f; g.Ja = 0.f; g.jslot = 6 | (6 << 8); g.mu = 0.f;
         g.bias = 0.f; g.fn = -1; g.lam = 0.f; g.lo = 0.f; g.hi = 0.f;
         return;
     }
@@ -675,17 +742,48 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
             const float dist = L.cdist_[ci];
             bias = (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h;
             hi = 1e30f;
-        } else { bias = 0.f; frn = nL + ci; }
+        } else { bias = 0.f; frn = nL + ci; mu = L.cmu[ci]; }
     }
     response(L, phi, level, leg, th, ta, B);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) g.Jb[k] = phi[k]; /* zero for limit rows */
-    g.Jh = Jh; g.Ja = Ja; g.jslot = 6 + 2 * leg;
     if (active) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) L.Bt[lane][k] = B[k];
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g.Jb[k] = phi[k]; /* zero for limit rows */
+    g.Jh = Jh; g.Ja = Ja; g.jslot = (6 + 2 * leg) | ((6 + 2 * leg) << 8); g.mu = mu;
     g.bias = bias; g.fn = active ? frn : -1; g.lam = 0.f; g.lo = 0.f; g.hi = frn >= 0 ? 0.f : hi;
+}
+
+/* Phase R1b (row map; only substeps that kept a self contact run it): the rows of a contact between two ant bodies A (leg)
+ * and B (leg2 > leg) are J = J_A - J_B -- both bodies move with the torso, so its part cancels exactly and what is left are
+ * the hip / ankle entries of the two legs -- and B = B_A - B_B: phase R1 left the A parts, this phase subtracts the second
+ * impulse response in the row's own LDS record, zeroes the torso part of J and leaves the second leg's entries in L.J2. */
+HRL_DEV void phase_self_rows(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane, int nL, int nC) {
+    const int nR = nL + 3 * nC;
+    if (lane >= MAXR) return;
+    L.J2[lane][0] = 0.f; L.J2[lane][1] = 0.f;
+    if (lane < nL || lane >= nR) return;
+    const int row = lane - nL;
+    const int ci = row < nC ? row : (row - nC) >> 1, which = row < nC ? 0 : 1 + ((row - nC) & 1);
+    const int link2 = L.clink2[ci];
+    if (link2 < 0) return;
+    const int level2 = link2 & 3, leg2 = link2 >> 2;
+    const float r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
+    const float d[3] = {L.cdir[which][ci][0], L.cdir[which][ci][1], L.cdir[which][ci][2]};
+    float phi[6], B2[16];
+    cross3(phi, r, d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
+    response(L, phi, level2, leg2, 0.f, 0.f, B2);
+#pragma unroll
+    for (int k = 0; k < 14; ++k) L.Bt[lane][k] = L.Bt[lane][k] - B2[k];
+    const float jh2 = dot6(phi, L.S[2 * leg2]), ja2 = dot6(phi, L.S[2 * leg2 + 1]);
+    L.J2[lane][0] = level2 >= 1 ? -jh2 : 0.f; L.J2[lane][1] = level2 >= 2 ? -ja2 : 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g.Jb[k] = 0.f;
+    g.jslot = (g.jslot & 0xff) | ((6 + 2 * leg2) << 8);
+    (void)c;
 }
 
 /* Phase R2 (row map): the row's line of C = I - D^-1 A with A = J M^-1 J^T (A[i][r] = J_i . B_r, D = diag A), and the
@@ -695,45 +793,56 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
  * rows r < nB, Af[k] for the friction rows nB + k.  Both are indexed by template parameters (pack expansion) so that
  * they stay in registers: a runtime index would push them out into scratch memory.
  * `one(r)` is 1 on lane r and 0 elsewhere (the unit diagonal), supplied by the executor. */
-HRL_DEV float row_dot(const LaneRegs &g, const float *Brow) {
+struct J2pair { float h, a; }; /* self-contact rows: the second leg's entries of the lane's row (from WaveLds::J2) */
+template <bool SELF>
+HRL_DEV float row_dot(const LaneRegs &g, const float *Brow, const J2pair &j2) {
     float a = g.Jb[0] * Brow[0];
 #pragma unroll
     for (int d = 1; d < 6; ++d) a = fma_(g.Jb[d], Brow[d], a);
-    a = fma_(g.Jh, Brow[g.jslot], a);
-    return fma_(g.Ja, Brow[g.jslot + 1], a);
+    const int s1 = g.jslot & 0xff;
+    a = fma_(g.Jh, Brow[s1], a);
+    a = fma_(g.Ja, Brow[s1 + 1], a);
+    if (SELF) { /* substeps with a self contact: the entries of the second body's leg, next in slot order (leg2 > leg) */
+        const int s2 = g.jslot >> 8;
+        a = fma_(j2.h, Brow[s2], a);
+        a = fma_(j2.a, Brow[s2 + 1], a);
+    }
+    return a;
 }
 /* columns 4G..4G+3 of a block behind one wave-uniform test (flat sequence of groups, no nesting).  Columns past the
  * block's end inside its last group are computed from whatever LDS holds and never read by the sweeps. */
-template <int G, class One>
-HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, One one) {
+template <bool SELF, int G, class One>
+HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, One one, const J2pair &j2) {
     if (4 * G < nB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot(g, L.Bt[4 * G + i]), one(4 * G + i));
+        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[4 * G + i], j2), one(4 * G + i));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.An[4 * G + i] = 0.f;
     }
 }
-template <int G, class One>
-HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one) {
+template <bool SELF, int G, class One>
+HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, const J2pair &j2) {
     if (4 * G < nF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot(g, L.Bt[nB + 4 * G + i]), one(nB + 4 * G + i));
+        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[nB + 4 * G + i], j2), one(nB + 4 * G + i));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = 0.f;
     }
 }
-template <class One, int... Gn, int... Gf>
-HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, std::integer_sequence<int, Gn...>, std::integer_sequence<int, Gf...>) {
-    (build_An_group<Gn>(L, g, nB, ninvd, one), ...);
-    (build_Af_group<Gf>(L, g, nB, nF, ninvd, one), ...);
+template <bool SELF, class One, int... Gn, int... Gf>
+HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, const J2pair &j2, std::integer_sequence<int, Gn...>, std::integer_sequence<int, Gf...>) {
+    (build_An_group<SELF, Gn>(L, g, nB, ninvd, one, j2), ...);
+    (build_Af_group<SELF, Gf>(L, g, nB, nF, ninvd, one, j2), ...);
 }
-template <class One>
+template <bool SELF, class One>
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
-    const float invd = 1.f / row_dot(g, L.Bt[lane < nB + nF ? lane : 0]); /* 1 / A_ii; idle lanes carry row 0's registers */
-    build_A_blocks(L, g, nB, nF, -invd, one, std::make_integer_sequence<int, MAXB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
-    g.c = -(invd * (row_dot(g, L.ustar) + g.bias));
+    J2pair j2{0.f, 0.f};
+    if (SELF && lane < MAXR) { j2.h = L.J2[lane][0]; j2.a = L.J2[lane][1]; }
+    const float invd = 1.f / row_dot<SELF>(g, L.Bt[lane < nB + nF ? lane : 0], j2); /* 1 / A_ii; idle lanes carry row 0's registers */
+    build_A_blocks<SELF>(L, g, nB, nF, -invd, one, j2, std::make_integer_sequence<int, MAXB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
+    g.c = -(invd * (row_dot<SELF>(g, L.ustar, j2) + g.bias));
 }
 
 /* Phase I (dof map): integrate positions; the joint rates were clamped by the caller.  Lane k < 16 produces element k
@@ -791,7 +900,7 @@ HRL_DEV bool pgs_row_friction(X &x, int nB, int nF) { /* friction row nB + K */
     return true;
 }
 template <class X, int... Rs, int... Ks>
-HRL_DEV void pgs_sweep(X &x, float mu, int nB, int nF, std::integer_sequence<int, Rs...>, std::integer_sequence<int, Ks...>) {
+HRL_DEV void pgs_sweep(X &x, int nB, int nF, std::integer_sequence<int, Rs...>, std::integer_sequence<int, Ks...>) {
     /* rows in order as flat sequences with one forward exit each (no nesting: nested wave-uniform ifs cost an SGPR pair each) */
     (void)(pgs_row_bounded<Rs>(x, nB) && ...);
     if (nF <= 0) return;
@@ -799,26 +908,25 @@ HRL_DEV void pgs_sweep(X &x, float mu, int nB, int nF, std::integer_sequence<int
                    [&](int lane) { const int fn = x.reg(lane).fn; return fn >= 0 ? fn : lane; },
                    [&](int lane, float ln) {
                        LaneRegs &g = x.reg(lane);
-                       if (g.fn >= 0) { g.hi = mu * ln; g.lo = -g.hi; }
+                       if (g.fn >= 0) { g.hi = g.mu * ln; g.lo = -g.hi; }
                    });
     (void)(pgs_row_friction<Ks>(x, nB, nF) && ...);
 }
 template <class X>
-HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
+HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool self) {
     WaveLds &L = x.lds();
     const int nB = ant ? nL + nC : nC, nF = 2 * nC, nR = nB + nF;
     if (nR <= 0) return;
-    x.each([&](int lane) { phase_build_A(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
+    if (self) x.each([&](int lane) { phase_build_A<true>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
+    else x.each([&](int lane) { phase_build_A<false>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
     x.stamp(8);
-    float mu = c.mu;
     const int iters = c.iters;
-    HRL_PIN_VGPR(mu);
     for (int it = 0; it < iters; ++it) {
         int nb = nB, nf = nF;
         x.refresh();
         x.refresh_uniform(nb); /* keeps the 44 row-count tests inside the sweep as scalar compares (hoisted out of */
         x.refresh_uniform(nf); /* the loop they become 44 live lane-mask pairs, most of them spilled)             */
-        pgs_sweep(x, mu, nb, nf, std::make_integer_sequence<int, MAXB>{}, std::make_integer_sequence<int, MAXF>{});
+        pgs_sweep(x, nb, nf, std::make_integer_sequence<int, MAXB>{}, std::make_integer_sequence<int, MAXF>{});
     }
     x.stamp(9);
     x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });
@@ -831,7 +939,7 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant) {
 
 /* One physics substep.  On entry L.q[qi] / L.u / L.tau hold the state; on exit L.q[qi ^ 1] / L.u are advanced by h. */
 template <class X>
-HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
+HRL_DEV int ant_substep(X &x, const DevCfg &c, int qi, bool items_on) {
     WaveLds &L = x.lds();
     const float *q = L.q[qi];
     float *qn = L.q[qi ^ 1];
@@ -847,8 +955,9 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
     x.each([&](int lane) { const float v = phase_forward_vel(c, L, lane); x.reg(lane).ud = v; if (lane < 16) L.ustar[lane] = v; });
     x.stamp(4);
     /* contacts in surface-major, sphere-minor order (ballot ranks follow lane order), at most MAXC kept:
-     * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = boxes */
-    int nC = 0;
+     * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = world boxes, then the item
+     * cubes near the robot (up to four cubes per pass, 13 lanes each), then the capsule pairs of different legs */
+    int nC = 0, nS = 0;
     /* Broad phase (wave-uniform): every contact sphere lies within 1.25 m of the torso centre (hip 0.283 + aux 0.283 +
      * foot 0.566 + radius 0.08 + contact_dist), so a lateral surface farther than that from the torso cannot produce a
      * contact and its pass is skipped.  Exactly the same contact list as testing every pair. */
@@ -861,29 +970,71 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
         for (int k = 0; k < 3; ++k) { const float cp = clampf(q[k], c.box_lo[k], c.box_hi[k]); d2 += (q[k] - cp) * (q[k] - cp); }
         near_box = d2 < reach * reach;
     }
+    auto keep = [&](int base) {
+        return [&L, base](int, int rank, const Hit &h) {
+            const int i = base + rank;
+            if (i < MAXC) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) L.cr[i][k] = h.r[k];
+                store_contact_frame(L, i, h.n);
+                L.cdist_[i] = h.dist; L.clink[i] = h.link; L.clink2[i] = h.link2; L.csurf[i] = h.surf; L.cmu[i] = h.mu;
+            }
+        };
+    };
     for (int pass = 0; pass < 3; ++pass) {
         const int nsurf = pass == 0 ? 1 : (pass == 1 ? c.n_planes : c.n_boxes);
         if (nsurf == 0) continue;
         if ((pass == 1 && !x.uniform(near_plane)) || (pass == 2 && !x.uniform(near_box))) continue;
         const int f0 = pass == 0 ? 0 : (pass == 1 ? 1 : 1 + c.n_planes);
-        const int base = nC;
         int cnt = x.each_compact(
             [&](int lane) {
                 const int fi = lane / 13, sph = lane - 13 * fi;
-                return sphere_vs_surface(c, L, q, fi < nsurf ? sph : -1, f0 + fi);
+                return sphere_vs_surface(c, L, q, fi < nsurf ? sph : -1, f0 + fi, -1);
             },
-            [&](int lane, int rank, const Hit &h) {
-                const int i = base + rank;
-                if (i < MAXC) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) L.cr[i][k] = fma_(-h.rad, h.n[k], h.c[k]);
-                    store_contact_frame(L, i, h.n);
-                    L.cdist_[i] = h.dist; L.clink[i] = h.link;
-                }
-            },
+            keep(nC),
             [&](int lane, const Hit &h) { if (pass == 0 && lane < 16) L.gtouch[lane] = h.ok ? 1 : 0; });
         nC += cnt;
         if (nC > MAXC) nC = MAXC;
+    }
+    if (items_on) { /* food / poison cubes: lane = item decides whether its cube is within reach of any sphere (the cube's
+                       half extent more than the planes' bound, per axis), then the near cubes are tested four at a time */
+        const float R = reach + ITEM_HALF;
+        unsigned long long near = x.each_ballot([&](int lane) {
+            return lane < c.n_food + c.n_poison && fabsf(q[0] - L.items[2 * (lane & 15)]) < R && fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R;
+        });
+        while (near) {
+            int it[4], n_it = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                it[k] = -1;
+                if (near) { it[k] = (int)__builtin_ctzll(near); near &= near - 1; ++n_it; }
+            }
+            int cnt = x.each_compact(
+                [&](int lane) {
+                    const int slot = lane / 13, sph = lane - 13 * slot;
+                    const int item = slot == 0 ? it[0] : (slot == 1 ? it[1] : (slot == 2 ? it[2] : (slot == 3 ? it[3] : -1)));
+                    return sphere_vs_surface(c, L, q, item >= 0 ? sph : -1, 0, item);
+                },
+                keep(nC), [&](int, const Hit &) {});
+            nC += cnt;
+            if (nC > MAXC) nC = MAXC;
+        }
+    }
+    if (c.self_collision) { /* Seen from above in the torso frame, leg l is the jointless capsule O -> hip point followed by the aux
+        and foot capsules, which both lie in the vertical plane through the hip point at 45 + 90 l degrees + hip angle: with
+        |ankle angle| <= 2 rad the foot folds back by at most 0.566 cos(2) = 0.24 m < the aux length, so everything past the
+        hip point projects onto the ray from it.  With every |hip angle| <= 0.75 rad those rays keep >= 0.2 m from the
+        coordinate axes (hence from the other legs' jointless capsules) and >= 0.4 m from one another, so no two capsule
+        axes of different legs come within 2 r + contact_dist < 0.2 m: the pair test is skipped -- the same contact list
+        as testing all 48 pairs (the joints' own limits are +-0.698 and +-1.745 rad). */
+        bool spread = (c.r_caps + c.r_caps) + c.cdist < 0.2f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) spread = spread && fabsf(q[7 + 2 * l]) <= 0.75f && fabsf(q[8 + 2 * l]) <= 2.0f;
+        if (!x.uniform(spread)) {
+            int cnt = x.each_compact([&](int lane) { return capsule_pair(c, L, lane < 48 ? lane : -1); }, keep(nC), [&](int, const Hit &) {});
+            nS = nC + cnt > MAXC ? MAXC - nC : cnt; /* self contacts among the kept ones: their rows take the two-body path */
+            nC += nS;
+        }
     }
     x.stamp(5);
     /* joint limits (lane = joint) */
@@ -901,8 +1052,9 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
         [&](int, const LimitHit &) {});
     x.stamp(6);
     x.each([&](int lane) { phase_build_row(c, L, x.reg(lane), lane, nL, nC); });
+    if (nS > 0) x.each([&](int lane) { phase_self_rows(c, L, x.reg(lane), lane, nL, nC); });
     x.stamp(7);
-    pgs_solve(x, c, nL, nC, true);
+    pgs_solve(x, c, nL, nC, true, nS > 0);
     x.each([&](int lane) {
         const int d = lane & 15;
         float v = x.reg(lane).ud;
@@ -910,16 +1062,17 @@ HRL_DEV void ant_substep(X &x, const DevCfg &c, int qi) {
         if (lane < 16) L.u[lane] = v;
     });
     x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });
+    return nC;
 }
 
 
 /* ================================================================================================= POINT SUBSTEP
  * point_bot.py:10-74 + assets/player_cube.xml:8: free 10 kg cube (half extent 0.35).  Solid-cube inertia is
  * isotropic, so M^-1 = diag(1/I,1/I,1/I,1/m,1/m,1/m) and there is no gyroscopic term. */
-struct CornerHit { bool ok; float dist, n[3], c[3]; };
+struct CornerHit { bool ok; float dist, n[3], c[3]; int surf; };
 
 template <class X>
-HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
+HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
     WaveLds &L = x.lds();
     const float *q = L.q[qi];
     float *qn = L.q[qi ^ 1];
@@ -939,36 +1092,64 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
         for (int k = 0; k < 3; ++k) { L.XYZ[k] = ax_[k]; L.XYZ[3 + k] = ay_[k]; L.XYZ[6 + k] = az_[k]; }
     });
     int nC = 0;
+    /* corner `lane & 7` against surface f (0 ground, 1.. lateral planes) or, item >= 0, against that item cube */
+    auto corner = [&](int lane, bool on, int f, int item) {
+        CornerHit h; h.ok = false; h.dist = 0.f; h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f; h.surf = f;
+        if (on) {
+            float sx = (lane & 1) ? he : -he, sy = (lane & 2) ? he : -he, sz = (lane & 4) ? he : -he;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) h.c[k] = fma_(sz, L.XYZ[6 + k], fma_(sy, L.XYZ[3 + k], sx * L.XYZ[k]));
+            const float p[3] = {q[0] + h.c[0], q[1] + h.c[1], q[2] + h.c[2]};
+            if (item >= 0) {
+                const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
+                const float lo[3] = {ix - ITEM_HALF, iy - ITEM_HALF, ITEM_Z - ITEM_HALF}, hi[3] = {ix + ITEM_HALF, iy + ITEM_HALF, ITEM_Z + ITEM_HALF};
+                h.dist = sphere_vs_box(p, 0.f, lo, hi, h.n); h.surf = SURF_ITEM + item;
+            } else if (f == 0) h.dist = p[2] - c.ground_z;
+            else {
+                h.n[0] = c.plane_n[f - 1][0]; h.n[1] = c.plane_n[f - 1][1]; h.n[2] = c.plane_n[f - 1][2];
+                h.dist = dot3(h.n, p) - c.plane_d[f - 1];
+            }
+            h.ok = h.dist < c.cdist;
+        }
+        return h;
+    };
+    auto keep = [&](int base) {
+        return [&L, base](int, int rank, const CornerHit &h) {
+            const int i = base + rank;
+            if (i < MAXC) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { L.cr[i][k] = h.c[k]; L.cdir[0][i][k] = h.n[k]; }
+                L.cdist_[i] = h.dist; L.csurf[i] = h.surf;
+            }
+        };
+    };
     for (int f = 0; f < 1 + c.n_planes; ++f) {
-        const int base = nC;
-        int cnt = x.each_compact(
-            [&](int lane) {
-                CornerHit h; h.ok = false; h.dist = 0.f; h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f;
-                if (lane < 8) {
-                    float sx = (lane & 1) ? he : -he, sy = (lane & 2) ? he : -he, sz = (lane & 4) ? he : -he;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) h.c[k] = fma_(sz, L.XYZ[6 + k], fma_(sy, L.XYZ[3 + k], sx * L.XYZ[k]));
-                    if (f == 0) h.dist = (q[2] + h.c[2]) - c.ground_z;
-                    else {
-                        float p[3] = {q[0] + h.c[0], q[1] + h.c[1], q[2] + h.c[2]};
-                        h.n[0] = c.plane_n[f - 1][0]; h.n[1] = c.plane_n[f - 1][1]; h.n[2] = c.plane_n[f - 1][2];
-                        h.dist = dot3(h.n, p) - c.plane_d[f - 1];
-                    }
-                    h.ok = h.dist < c.cdist;
-                }
-                return h;
-            },
-            [&](int, int rank, const CornerHit &h) {
-                const int i = base + rank;
-                if (i < MAXC) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { L.cr[i][k] = h.c[k]; L.cdir[0][i][k] = h.n[k]; }
-                    L.cdist_[i] = h.dist;
-                }
-            },
-            [&](int, const CornerHit &) {});
+        int cnt = x.each_compact([&](int lane) { return corner(lane, lane < 8, f, -1); }, keep(nC), [&](int, const CornerHit &) {});
         nC += cnt;
         if (nC > MAXC) nC = MAXC;
+    }
+    if (items_on) { /* cubes whose box comes within reach of a corner (half diagonal 0.35 sqrt 3 = 0.607), four per pass */
+        const float R = 0.35f * 1.7320508f + ITEM_HALF + c.cdist + 0.02f;
+        unsigned long long near = x.each_ballot([&](int lane) {
+            return lane < c.n_food + c.n_poison && fabsf(q[0] - L.items[2 * (lane & 15)]) < R && fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R;
+        });
+        while (near) {
+            int it[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                it[k] = -1;
+                if (near) { it[k] = (int)__builtin_ctzll(near); near &= near - 1; }
+            }
+            int cnt = x.each_compact(
+                [&](int lane) {
+                    const int slot = lane >> 3;
+                    const int item = slot == 0 ? it[0] : (slot == 1 ? it[1] : (slot == 2 ? it[2] : (slot == 3 ? it[3] : -1)));
+                    return corner(lane, item >= 0, 0, item);
+                },
+                keep(nC), [&](int, const CornerHit &) {});
+            nC += cnt;
+            if (nC > MAXC) nC = MAXC;
+        }
     }
     x.each([&](int lane) { /* contact map: tangents of the kept contacts */
         if (lane < nC) { const float n[3] = {L.cdir[0][lane][0], L.cdir[0][lane][1], L.cdir[0][lane][2]}; store_contact_frame(L, lane, n); }
@@ -989,17 +1170,18 @@ HRL_DEV void point_substep(X &x, const DevCfg &c, int qi) {
         const float dist = L.cdist_[ci];
 #pragma unroll
         for (int k = 0; k < 6; ++k) g.Jb[k] = J[k];
-        g.Jh = 0.f; g.Ja = 0.f; g.jslot = 6;
+        g.Jh = 0.f; g.Ja = 0.f; g.jslot = 6 | (6 << 8); g.mu = which == 0 ? 0.f : c.mu;
 #pragma unroll
         for (int k = 0; k < 16; ++k) L.Bt[lane][k] = B[k];
         g.bias = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h : 0.f;
         g.fn = which == 0 ? -1 : ci; g.lam = 0.f; g.lo = 0.f; g.hi = which == 0 ? 1e30f : 0.f;
     });
-    pgs_solve(x, c, 0, nC, false);
+    pgs_solve(x, c, 0, nC, false, false);
     x.each([&](int lane) { if (lane < 16) L.u[lane] = x.reg(lane).ud; });
     x.stamp(10);
     x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });
     x.stamp(11);
+    return nC;
 }
 
 /* ================================================================================================= OBSERVATIONS */
@@ -1135,7 +1317,7 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
     quat_to_rpy(qp + 3, rpy);
     float tx = c.walk_tx, ty = c.walk_ty;
     if (KIND == 5) { /* the goal being chased: from the shared list, or (max_target_dist mode) the one kept in items[0..1] */
-        if (c.flag_mtd > 0.f) { tx = L.items[0]; ty = L.items[1]; }
+        if (c.flag_mtd > 0.f || c.flag_manual) { tx = L.items[0]; ty = L.items[1]; }
         else flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &tx, &ty);
     }
     if (KIND == 2 || KIND == 4) { /* maze kinds: the episode's target */
@@ -1188,7 +1370,7 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
         mine = (use_feet && (L.gtouch[2 + 3 * l] || L.gtouch[3 + 3 * l])) ? 1.f : 0.f;
     }
     if (lane < 28) L.s28[lane] = clampf(mine, -5.f, 5.f);
-    L.scal[3] = wtd; L.scal[4] = rpy[2]; L.scal[5] = (float)nlim;
+    L.scal[3] = wtd; L.scal[4] = rpy[2]; L.scal[5] = (float)nlim; L.scal[6] = cx; L.scal[7] = cy;
 }
 
 /* gather_scene.py:52-62 with counter-based draws: at most 64 attempts, the last one is kept */
@@ -1204,8 +1386,10 @@ HRL_DEV void respawn_item(const DevCfg &c, long long env, uint32_t index, uint32
 }
 
 /* Phase O2 (item map): pickup + respawn (ant_gather_env.py:84-92, gather_scene.py:95-114) and the item's sensor
- * contribution (ant_gather_env.py:145-162). */
-HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, bool pickups) {
+ * contribution (ant_gather_env.py:145-162).  robot_coll_dist <= 0 (:113-116): +-1 per contact point between the robot and
+ * the item's cube among the `n_contacts` contacts of the step's last collision pass (L.csurf), the observation is taken
+ * BEFORE such an item is moved (:95-96 precede :113), and it is moved once. */
+HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, bool pickups, int n_contacts) {
     const int n = c.n_food + c.n_poison;
     if (lane >= 16) return;
     float rew = 0.f, bin = -1.f, inten = 0.f;
@@ -1228,6 +1412,16 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
                 int b = (int)((angle + half_span) / bin_res);
                 if (b >= c.n_bins) b = c.n_bins - 1;
                 bin = (float)b; inten = 1.0f - d2 / c.sensor_range;
+            }
+        }
+        if (pickups && !(c.coll_dist > 0.f)) {
+            int hits = 0;
+            for (int i = 0; i < n_contacts; ++i) hits += L.csurf[i] == SURF_ITEM + lane ? 1 : 0;
+            if (hits > 0) {
+                rew = (lane < c.n_food ? 1.f : -1.f) * (float)hits;
+                if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane, rx, ry, &ix, &iy);
+                else { ix = 100.f; iy = 0.f; }
+                L.items[2 * lane] = ix; L.items[2 * lane + 1] = iy;
             }
         }
     }
@@ -1326,7 +1520,7 @@ HRL_DEV void phase_point_state(const DevCfg &c, WaveLds &L, int lane) {
 
 /* Observation of the state in L.st / L.items / L.aux into L.obs (and L.scal).  Used by step and by reset. */
 template <int KIND, class X>
-HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
+HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode, int n_contacts = 0) {
     WaveLds &L = x.lds();
     const bool centroid = (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5);
     if (centroid) { /* link positions of the final pose for the parts centroid; its LDS hand-off area overlays the
@@ -1340,16 +1534,36 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode) {
         const bool feet = step_mode && (KIND == 2 || KIND == 5); /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
         x.each([&](int lane) { phase_calc_state<KIND>(c, L, lane, feet, centroid); });
     }
-    if (KIND == 1 || KIND == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode); });
+    if (KIND == 1 || KIND == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode, n_contacts); });
     x.each([&](int lane) { phase_pack_obs<KIND>(c, L, lane); });
 }
 
 /* ================================================================================================= RESET / STEP */
 
-/* Env.reset(): ant_gather_env.py:68-74, gather_scene.py:38-50, ant_maze_bullet_env.py:104-121, point_bot.py:12,25-26 */
+/* Env.reset(): ant_gather_env.py:68-74, gather_scene.py:38-50, ant_maze_bullet_env.py:104-121, point_bot.py:12,25-26.
+ * The potential a reset leaves behind is what upstream WalkerBaseBulletEnv.reset() computed BEFORE the in-tree reset code
+ * moved the robot / switched the target (oracle: orc_reset_potential): flagrun -- the new pose against the PREVIOUS goal
+ * (ant_flagrun_env.py:116 re-reads the walk_target_dist of :146); maze kinds -- the default pose (the start offset taken
+ * out of the 13 robot parts of the centroid) against the PREVIOUS target (ant_maze_bullet_env.py:111 precedes :114-119);
+ * before the first episode the walk target is upstream's default (1e3, 0). */
 template <int KIND, class X>
 HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
     WaveLds &L = x.lds();
+    float ptx = c.walk_tx, pty = c.walk_ty; /* what the robot was walking towards before this reset */
+    if (KIND == 2 || KIND == 4 || KIND == 5) {
+        if (x.uniform(L.aux[2]) > 0) {
+            if (KIND == 5) {
+                if (c.flag_mtd > 0.f || c.flag_manual) { ptx = L.items[0]; pty = L.items[1]; }
+                else flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &ptx, &pty);
+            } else {
+                const int ti = L.aux[3];
+                ptx = c.targets[0][0]; pty = c.targets[0][1];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) { ptx = (ti == i) ? c.targets[i][0] : ptx; pty = (ti == i) ? c.targets[i][1] : pty; }
+            }
+        }
+        x.each([](int) {}); /* the reads above precede the writes below */
+    }
     x.each([&](int lane) {
         const uint32_t ep = (uint32_t)L.aux[2];
         if (lane < 32) {
@@ -1377,7 +1591,9 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
                 L.items[2 * i] = px; L.items[2 * i + 1] = py;
             }
         } else if (KIND == 5) {
-            if (c.flag_mtd > 0.f && lane < 48) { /* lanes 32..47: the items record = the current goal, zeros */
+            if (c.flag_manual) { /* the walk target survives the reset, the pending goals do not (ant_flagrun_env.py:149-152) */
+                if (lane < 48) { L.items[2 * (lane - 32)] = lane == 32 ? ptx : 0.f; L.items[2 * (lane - 32) + 1] = lane == 32 ? pty : 0.f; }
+            } else if (c.flag_mtd > 0.f && lane < 48) { /* lanes 32..47: the items record = the current goal, zeros */
                 float px = 0.f, py = 0.f; /* reset -> next_target -> create_close_target around the start pose, new episode's stream */
                 if (lane == 32) flag_close_goal(c, env, ep + 1u, 1u, c.start_pos[0], c.start_pos[1], &px, &py);
                 L.items[2 * (lane - 32)] = px; L.items[2 * (lane - 32) + 1] = py;
@@ -1385,7 +1601,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
         }
         if (lane < 16) L.u[lane] = 0.f;
         if (lane < 8) L.tau[lane] = 0.f;
-        if (lane == 63 && KIND == 5) L.aux[3] = 1; /* first goal popped, steps_since_goal_change = 0, not rewarded */
+        if (lane == 63 && KIND == 5) L.aux[3] = c.flag_manual ? 0 : 1; /* first goal popped (manual: none pending), steps_since_goal_change = 0, not rewarded */
         if (lane == 63 && (KIND == 2 || KIND == 4)) {
             uint32_t r[4];
             philox4x32(c, env, ep, (3u << 16), 0u, r);
@@ -1394,7 +1610,18 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
     });
     x.each([&](int lane) { if (lane == 0) L.aux[0] = 0; if (lane == 2) L.aux[2] = L.aux[2] + 1; });
     compute_obs<KIND>(x, c, env, false);
-    x.each([&](int lane) { if (lane == 31) L.st[31] = (KIND == 1 || KIND == 3) ? 0.f : -L.scal[3] / c.dt; }); /* upstream calc_potential */
+    x.each([&](int lane) {
+        if (lane != 31) return;
+        float pot = 0.f;
+        if (KIND == 0) pot = -L.scal[3] / c.dt; /* upstream calc_potential at the reset pose */
+        if (KIND == 2 || KIND == 4 || KIND == 5) {
+            float cx = L.scal[6], cy = L.scal[7];
+            if (KIND != 5) { const float np_ = (float)(13 + c.centroid_n_static); cx = cx - (13.f * c.start_pos[0]) / np_; cy = cy - (13.f * c.start_pos[1]) / np_; }
+            const float dx = ptx - cx, dy = pty - cy;
+            pot = -sqrtf(dy * dy + dx * dx) / c.dt;
+        }
+        L.st[31] = pot;
+    });
 }
 
 template <class X>
@@ -1427,6 +1654,28 @@ HRL_DEV void reset_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     store_env(x, b, c, e);
 }
 
+/* hrl_set_goals for one env: `env.goals = [...]; env.next_target()` of a manual_goal_creation flagrun env
+ * (ant_flagrun_env.py:91-118): goal 0 becomes the current one, the others are stacked behind it so that they are popped in
+ * the given order; _rewarded is cleared, the potential is left alone, the observation is calc_state towards the new goal */
+template <class X>
+HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, const float *goals_xy, int n_goals) {
+    if (b.mask && !b.mask[e]) return;
+    WaveLds &L = x.lds();
+    load_env(x, b, c, e, false);
+    x.each([&](int lane) {
+        if (lane < 32) {
+            const int k = lane >> 1, comp = lane & 1; /* items word `lane`: goal slot k (0 current, 1.. pending stack) */
+            float v = 0.f;
+            if (k == 0) v = goals_xy[(size_t)e * n_goals * 2 + comp];
+            else if (k < n_goals) v = goals_xy[((size_t)e * n_goals + (n_goals - k)) * 2 + comp];
+            L.items[lane] = v;
+        }
+        if (lane == 63) L.aux[3] = (int)(((uint32_t)(n_goals - 1) & 0xffffu) | ((uint32_t)L.aux[3] & 0x7fff0000u));
+    });
+    compute_obs<5>(x, c, c.env_id_offset + e, false);
+    store_env(x, b, c, e);
+}
+
 /* hrl_step for one env (one wave) */
 template <int KIND, class X>
 HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
@@ -1449,11 +1698,12 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         }
     });
     x.stamp(12);
-    int qi = 0;
+    int qi = 0, n_contacts = 0; /* n_contacts: the contacts of the step's last collision pass (contact-based pickup) */
+    const bool items_on = (KIND == 1 || KIND == 3) && c.item_collision != 0;
     HRL_PIN_INT(qi);
 #pragma unroll 1
     for (int s = 0; s < c.nsub; ++s) { /* one copy of the substep body: it is the kernel's instruction-cache footprint */
-        if constexpr (KIND == 3) point_substep(x, c, qi); else ant_substep(x, c, qi);
+        if constexpr (KIND == 3) n_contacts = point_substep(x, c, qi, items_on); else n_contacts = ant_substep(x, c, qi, items_on);
         qi ^= 1;
         HRL_PIN_INT(qi); /* keep the ping-pong index a run-time value so the body is not cloned per parity */
     }
@@ -1465,7 +1715,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         }
     });
     x.stamp(13);
-    compute_obs<KIND>(x, c, env, true);
+    compute_obs<KIND>(x, c, env, true, n_contacts);
     x.stamp(14);
     /* reward / done (uniform values, every lane computes them; lane-selected stores) */
     x.each([&](int lane) {
@@ -1492,18 +1742,22 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             const float wtd = L.scal[3], pot = -wtd / c.dt, progress = pot - L.st[31];
             L.red[0] = pot;
             int steps = ((L.aux[3] >> 16) & 0x7fff) + 1, rewarded = (L.aux[3] >> 31) & 1, cur = L.aux[3] & 0xffff, retarget = 0;
-            const bool more_goals = c.flag_mtd > 0.f; /* max_target_dist mode never runs out of goals (:111-112) */
+            /* goals left: the shared list has flag_max_targets of them, max_target_dist mode never runs out (:111-112), manual
+             * mode counts its pending goals in `cur` (downwards) */
+            const int step_cur = c.flag_manual ? -1 : 1;
+            auto more = [&]() { return c.flag_manual ? cur > 0 : (c.flag_mtd > 0.f || cur < c.flag_max_targets); };
             rew = (alive + progress) * 1.f;
             done = idone;
             if (wtd < c.tol) {
                 if (!rewarded) { rew += 5000.f; rewarded = 1; }
                 if (c.flag_switch) {
-                    if (more_goals || cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
+                    if (more()) { cur += step_cur; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
                 }
             }
             if (c.flag_timeout > 0 && c.flag_timeout <= steps) {
-                if (more_goals || cur < c.flag_max_targets) { cur += 1; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
+                if (more()) { cur += step_cur; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
             }
+            if (steps > 0x7fff) steps = 0x7fff; /* saturates in its 15-bit field (only reachable with the timeout off) */
             L.flags[4] = (int)(((uint32_t)cur & 0xffffu) | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
             L.flags[3] = retarget;
         } else if (KIND == 4) { /* MjAnt.py:36-97, then ant_maze_mj_env.py:66-78 */
@@ -1544,7 +1798,12 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
         if (lane == 8 && KIND == 5) L.aux[3] = L.flags[4];
-        if (lane == 9 && KIND == 5 && c.flag_mtd > 0.f && L.flags[3]) { /* set_target(*create_close_target()) around the robot's xy */
+        if (lane == 9 && KIND == 5 && c.flag_manual && L.flags[3]) { /* goals.pop() (ant_flagrun_env.py:114): the top of the pending stack */
+            const int top = L.flags[4] & 0xffff;
+            const float gx = L.items[2 + 2 * top], gy = L.items[3 + 2 * top];
+            L.items[0] = gx; L.items[1] = gy;
+        }
+        if (lane == 9 && KIND == 5 && !c.flag_manual && c.flag_mtd > 0.f && L.flags[3]) { /* set_target(*create_close_target()) around the robot's xy */
             float gx, gy;
             flag_close_goal(c, env, (uint32_t)L.aux[2], (uint32_t)L.flags[4] & 0xffffu, L.st[0], L.st[1], &gx, &gy);
             L.items[0] = gx; L.items[1] = gy;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HRL_ABI_VERSION 3
+#define HRL_ABI_VERSION 4
 
 /* env kinds */
 #define HRL_ANT_FLAT 0     /* AntMjEnv: flat ground, obs 29 (envs/MjAnt.py:31-97)                        */
@@ -49,6 +49,7 @@ extern "C" {
 #define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
 #define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
 #define HRL_MAX_TARGETS 8
+#define HRL_MAX_GOALS 15    /* flagrun manual goals per hrl_set_goals call: items[0..1] current, items[2..31] pending */
 
 /* status codes */
 #define HRL_OK 0
@@ -78,6 +79,13 @@ typedef struct hrl_model {
     float limit_max_impulse; /* 100 */
     float ground_z;          /* 0.005 = top of the 50x50x0.01 plane box (assets/plane.xml:19) */
     float point_force;       /* 500 N (point_bot.py:29) */
+    /* 1: capsules of different legs collide (links that are not ancestors of one another: upstream loads the robot with
+     * URDF_USE_SELF_COLLISION | URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS); friction between two
+     * ant links = friction_robot^2.  Default 1 for the ant kinds. */
+    int32_t self_collision;
+    /* 1: the food / poison cubes are static colliders (assets/food.xml:12,19: 0.25 m boxes, centre z = 0.1,
+     * gather_scene.py:62).  Default 1 for the gather kinds. */
+    int32_t item_collision;
 } hrl_model;
 
 typedef struct hrl_config {
@@ -92,6 +100,9 @@ typedef struct hrl_config {
     int32_t n_food, n_poison, n_bins;
     int32_t use_sensor, respawn;
     float world_size[2];
+    /* robot_coll_dist > 0: pickup when the SQUARED planar distance is below it (ant_gather_env.py:88-92);
+     * <= 0: pickup by contact -- +-1 per contact point between the robot and an item cube in the step's last collision
+     * pass (ant_gather_env.py:113-116, gather_base.py:103-106; needs model.item_collision). */
     float sensor_range, sensor_span, robot_coll_dist, robot_object_spacing, dying_cost;
     /* maze task (ant_maze_bullet_env.py:23-25) */
     int32_t target_encoding, sense_target, sense_walls, done_at_target, max_steps, targ_dist_rew;
@@ -113,6 +124,10 @@ typedef struct hrl_config {
      * its position, redrawn until it lies inside the arena (ant_flagrun_env.py:80-89); the episode then never runs out
      * of goals.  The current goal is kept in items[0..1], so `items` must be provided. */
     float flag_max_target_dist;
+    /* manual_goal_creation (ant_flagrun_env.py:24,149-152): reset neither draws goals nor changes the current one; goals
+     * are pushed from outside with hrl_set_goals().  The current goal lives in items[0..1], the pending ones behind it,
+     * so `items` must be provided.  flag_max_targets / flag_max_target_dist are ignored. */
+    int32_t flag_manual_goals;
     hrl_model model;
 } hrl_config;
 
@@ -157,6 +172,13 @@ int hrl_step(hrl_handle *h, const hrl_buffers *bufs, void *stream);
  * get/resetJointState): copies between the packed state record and split qpos[N][15] / qvel[N][14]. */
 int hrl_get_state(hrl_handle *h, const hrl_buffers *bufs, float *qpos, float *qvel, void *stream);
 int hrl_set_state(hrl_handle *h, const hrl_buffers *bufs, const float *qpos, const float *qvel, void *stream);
+
+/* AntFlagrunBulletEnv with manual_goal_creation: replaces `env.goals = [...]; env.next_target()`
+ * (ant_flagrun_env.py:91-118): goals_xy[N][n_goals][2] (device), visited in the given order; goal 0 becomes the
+ * current target at once (set_target + calc_state: bufs->obs is refreshed, the potential is left as it is, :116),
+ * the others are taken one by one as goals are reached or time out; the episode ends when they run out (:193-194).
+ * 1 <= n_goals <= HRL_MAX_GOALS.  Envs with mask[i] == 0 are left alone (mask == NULL: all). */
+int hrl_set_goals(hrl_handle *h, const hrl_buffers *bufs, const float *goals_xy, int32_t n_goals, const uint8_t *mask, void *stream);
 
 /* Last error text of the calling thread ("" if none). */
 const char *hrl_last_error(void);

@@ -261,17 +261,46 @@ void FN(orc_abs_pos)(int n_bins, const REAL *items_xy, int n_food, int n_poison,
     }
 }
 
+/* Source of the uniform pairs `rs.rand(2)` consumes (gather_scene.py:58): the golden tests replay the logged draws of
+ * the reference's RandomState in order; the env-level step draws counter-based Philox pairs keyed by (item, attempt). */
+#ifndef ORC_DRAW_TYPES
+#define ORC_DRAW_TYPES
+typedef int (*orc_draw_fn)(void *ctx, int item, int attempt, double *pair); /* 0 = no more draws */
+typedef struct orc_draw_array { const void *draws; int n, used, is_float; } orc_draw_array;
+static int orc_draw_from_array(void *ctx, int item, int attempt, double *pair) {
+    orc_draw_array *a = (orc_draw_array *)ctx;
+    (void)item; (void)attempt;
+    if (a->used >= a->n) return 0;
+    if (a->is_float) { pair[0] = ((const float *)a->draws)[2 * a->used]; pair[1] = ((const float *)a->draws)[2 * a->used + 1]; }
+    else { pair[0] = ((const double *)a->draws)[2 * a->used]; pair[1] = ((const double *)a->draws)[2 * a->used + 1]; }
+    ++a->used;
+    return 1;
+}
+#endif
+
 /* gather_scene.py:52-62 `_random_on_plane`: pos = rand(2)*(size-1) - (size-1)/2, redrawn while |avoid-pos| < spacing.
- * Uniform pairs come from `draws` (consumed in order; returns the number consumed, or -1 if it ran out). */
+ * Returns the number of pairs consumed, or -1 if the source ran out; at most `max_attempts` draws, the last one kept
+ * (the reference loops until it succeeds). */
+static int FN(random_on_plane_src)(const REAL *world_size, const REAL *avoid_xy, REAL spacing, orc_draw_fn draw, void *ctx,
+                                   int item, int max_attempts, REAL *pos_out) {
+    REAL sx = world_size[0] - 1, sy = world_size[1] - 1;
+    for (int k = 0; k < max_attempts; ++k) {
+        double pr[2];
+        if (!draw(ctx, item, k, pr)) return -1;
+        REAL px = R_(pr[0]) * sx - sx / 2, py = R_(pr[1]) * sy - sy / 2;
+        REAL dx = avoid_xy[0] - px, dy = avoid_xy[1] - py;
+        pos_out[0] = px; pos_out[1] = py;
+        if (!(RSQRT(dx * dx + dy * dy) < spacing)) return k + 1;
+    }
+    return max_attempts;
+}
 int FN(orc_random_on_plane)(const REAL *world_size, const REAL *avoid_xy, REAL spacing, const REAL *draws, int n_draws,
                             REAL *pos_out) {
-    REAL sx = world_size[0] - 1, sy = world_size[1] - 1;
-    for (int k = 0; k < n_draws; ++k) {
-        REAL px = draws[2 * k] * sx - sx / 2, py = draws[2 * k + 1] * sy - sy / 2;
-        REAL dx = avoid_xy[0] - px, dy = avoid_xy[1] - py;
-        if (!(RSQRT(dx * dx + dy * dy) < spacing)) { pos_out[0] = px; pos_out[1] = py; return k + 1; }
-    }
-    return -1;
+    orc_draw_array a = {draws, n_draws, 0, REAL_IS_FLOAT};
+    REAL tmp[2];
+    int k = FN(random_on_plane_src)(world_size, avoid_xy, spacing, orc_draw_from_array, &a, 0, 1 << 30, tmp);
+    if (k > 0) { pos_out[0] = tmp[0]; pos_out[1] = tmp[1]; }
+    return k;
 }
 
 /* ant_maze_bullet_env.py:123-133 `get_target_vec_obs` (encoding 0 normed vector, 1 sin/cos of relative angle). */
@@ -320,12 +349,16 @@ void FN(orc_pointbot_state)(const REAL *xyz, const REAL *rpy, const REAL *speed,
 /* The task half of AntGatherBulletEnv.step / GatherBulletEnv.step given the post-physics robot state
  * (ant_gather_env.py:81-119, gather_base.py:80-109).
  *   base_state : robot.calc_state() (28 for the ant, 8 for the point bot), ant=1 drops elements 1:3 (:81)
- *   items_xy   : [n_food+n_poison][2] in/out (respawned in place); draws: uniform pairs for respawns
+ *   items_xy   : [n_food+n_poison][2] in/out (respawned in place); respawn draws from `draw`
  *   alive_z    : > 0 enables `alive = +1 if z > alive_z else -1` (ant); <= 0 means "can't die" (point_bot.py:73-74)
- * Returns number of uniform pairs consumed. */
-int FN(orc_gather_task)(const hrl_config *cfg, int ant, const REAL *base_state, int n_base, const REAL *torso_xyz,
-                        REAL yaw, REAL initial_z, REAL alive_z, REAL *items_xy, const REAL *draws, int n_draws,
-                        REAL *obs, REAL *rew, int *done, REAL *food_rew_out, REAL *dead_rew_out) {
+ *   contact_items : robot_coll_dist <= 0 branch (:113-116): cp[2] of every contact point the robot has, as an item
+ *                   index (food slots then poison slots) or -1 for anything else (ground, walls: reward_collision
+ *                   returns 0 for them, gather_scene.py:95-114); processed AFTER the observation was assembled (:95-96)
+ * Returns number of uniform pairs consumed (-1: the draw source ran out). */
+int FN(orc_gather_task_src)(const hrl_config *cfg, int ant, const REAL *base_state, int n_base, const REAL *torso_xyz,
+                            REAL yaw, REAL initial_z, REAL alive_z, REAL *items_xy, orc_draw_fn draw, void *ctx, int max_attempts,
+                            const int *contact_items, int n_contacts,
+                            REAL *obs, REAL *rew, int *done, REAL *food_rew_out, REAL *dead_rew_out) {
     int nf = cfg->n_food, np_ = cfg->n_poison, n = nf + np_, no = 0, used = 0;
     REAL d2[HRL_MAX_ITEMS];
     if (ant) { obs[no++] = base_state[0]; for (int i = 3; i < n_base; ++i) obs[no++] = base_state[i]; } /* :81 */
@@ -338,8 +371,7 @@ int FN(orc_gather_task)(const hrl_config *cfg, int ant, const REAL *base_state, 
             if (d2[i] < R_(cfg->robot_coll_dist)) { /* :90 -- squared distance vs linear threshold (SURVEY C-1) */
                 food_reward += (i < nf) ? 1 : -1;   /* gather_scene.py:95-112 */
                 if (cfg->respawn) {
-                    int k = FN(orc_random_on_plane)(ws, torso_xyz, R_(cfg->robot_object_spacing), draws + 2 * used,
-                                                    n_draws - used, items_xy + 2 * i);
+                    int k = FN(random_on_plane_src)(ws, torso_xyz, R_(cfg->robot_object_spacing), draw, ctx, i, max_attempts, items_xy + 2 * i);
                     if (k < 0) return -1;
                     used += k;
                 } else { items_xy[2 * i] = 100; items_xy[2 * i + 1] = 0; } /* gather_scene.py:13,100-102 */
@@ -364,9 +396,42 @@ int FN(orc_gather_task)(const hrl_config *cfg, int ant, const REAL *base_state, 
     if (alive_z > 0) alive = (obs[0] + initial_z > alive_z) ? R_(1) : R_(-1); /* :99 + upstream Ant.alive_bonus */
     int d = alive < 0;                                                         /* :100 */
     for (int i = 0; i < no; ++i) if (!isfinite(obs[i])) d = 1;                 /* :101-103 */
+    if (!(cfg->robot_coll_dist > 0)) { /* :113-116: one reward_collision() per contact point, in contact order.  An item touched
+                                         * by k contact points pays k times and is moved k times; the position it ends up at is
+                                         * one more independent draw of the same distribution, so it is drawn once here. */
+        int moved[HRL_MAX_ITEMS] = {0};
+        for (int c = 0; c < n_contacts; ++c) {
+            int i = contact_items[c];
+            if (i < 0 || i >= n) continue; /* not an item: reward_collision returns 0 */
+            food_reward += (i < nf) ? 1 : -1;
+            if (moved[i]) continue;
+            moved[i] = 1;
+            if (cfg->respawn) {
+                int k = FN(random_on_plane_src)(ws, torso_xyz, R_(cfg->robot_object_spacing), draw, ctx, i, max_attempts, items_xy + 2 * i);
+                if (k < 0) return -1;
+                used += k;
+            } else { items_xy[2 * i] = 100; items_xy[2 * i + 1] = 0; }
+        }
+    }
     REAL dead_rew = alive < 0 ? R_(cfg->dying_cost) : 0;                       /* :118 */
     *rew = food_reward + dead_rew; *done = d; *food_rew_out = food_reward; *dead_rew_out = dead_rew; /* :119 */
     return used;
+}
+/* the same with the uniform pairs replayed from an array (golden tests) */
+int FN(orc_gather_task)(const hrl_config *cfg, int ant, const REAL *base_state, int n_base, const REAL *torso_xyz,
+                        REAL yaw, REAL initial_z, REAL alive_z, REAL *items_xy, const REAL *draws, int n_draws,
+                        REAL *obs, REAL *rew, int *done, REAL *food_rew_out, REAL *dead_rew_out) {
+    orc_draw_array a = {draws, n_draws, 0, REAL_IS_FLOAT};
+    return FN(orc_gather_task_src)(cfg, ant, base_state, n_base, torso_xyz, yaw, initial_z, alive_z, items_xy, orc_draw_from_array, &a,
+                                   1 << 30, 0, 0, obs, rew, done, food_rew_out, dead_rew_out);
+}
+int FN(orc_gather_task_contacts)(const hrl_config *cfg, int ant, const REAL *base_state, int n_base, const REAL *torso_xyz,
+                                 REAL yaw, REAL initial_z, REAL alive_z, REAL *items_xy, const REAL *draws, int n_draws,
+                                 const int *contact_items, int n_contacts,
+                                 REAL *obs, REAL *rew, int *done, REAL *food_rew_out, REAL *dead_rew_out) {
+    orc_draw_array a = {draws, n_draws, 0, REAL_IS_FLOAT};
+    return FN(orc_gather_task_src)(cfg, ant, base_state, n_base, torso_xyz, yaw, initial_z, alive_z, items_xy, orc_draw_from_array, &a,
+                                   1 << 30, contact_items, n_contacts, obs, rew, done, food_rew_out, dead_rew_out);
 }
 
 /* The task half of AntMazeBulletEnv.step given the upstream WalkerBaseBulletEnv.step result
@@ -494,7 +559,8 @@ typedef struct FN(orc_consts) {
     REAL m1, a1, b1;      /* aux (short) capsule about its own COM: alpha*1 + beta*e e^T, e = capsule axis */
     REAL m2, a2, b2;      /* foot capsule                                                                */
     REAL lo[NJ], hi[NJ];  /* joint ranges, assets/ant.xml:18-54                                          */
-    int iters, nsub;
+    REAL mu_self;         /* friction between two ant links = friction_robot^2 (Bullet combines by product)       */
+    int iters, nsub, self_collision, item_collision;
 } FN(orc_consts);
 
 /* static collision world: ground plane + lateral half-spaces + axis-aligned boxes
@@ -533,6 +599,7 @@ void FN(orc_consts_init)(const hrl_model *M, FN(orc_consts) * K) {
     K->mu = R_(M->friction_ground * M->friction_robot); K->cdist = R_(M->contact_dist); K->lmargin = R_(M->limit_margin);
     K->vmax = R_(M->max_joint_vel); K->limp_max = R_(M->limit_max_impulse); K->ground_z = R_(M->ground_z);
     K->iters = M->solver_iters; K->nsub = M->frame_skip;
+    K->mu_self = R_(M->friction_robot * M->friction_robot); K->self_collision = M->self_collision; K->item_collision = M->item_collision;
     const double d2r = pi / 180.0;
     const double lo[NJ] = {-40, 30, -40, -100, -40, -100, -40, 30}, hi[NJ] = {40, 100, 40, -30, 40, -30, 40, 100};
     for (int j = 0; j < NJ; ++j) { K->lo[j] = R_(lo[j] * d2r); K->hi[j] = R_(hi[j] * d2r); }
@@ -772,7 +839,7 @@ static void FN(tangent_basis)(const REAL *n, REAL *t1, REAL *t2) {
  * order (limits, normals, friction pairs) `iters` times; a friction row's bounds are +-mu * (current impulse of its
  * normal row).  The generalized velocity is reconstructed once at the end: u += sum_r B_r * lambda_r. */
 #define ORC_MAXROWS 44
-static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, const REAL *hic, const int *frn, REAL mu,
+static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, const REAL *hic, const int *frn, const REAL *mu,
                         int iters, REAL *un, REAL *lam) {
     static _Thread_local REAL Cm[ORC_MAXROWS][ORC_MAXROWS];
     REAL c[ORC_MAXROWS], lo[ORC_MAXROWS], hi[ORC_MAXROWS];
@@ -797,14 +864,23 @@ static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, 
             lam[r] = ln;
             for (int i = 0; i < nr; ++i) {
                 c[i] = FMA_(Cm[i][r], dl, c[i]);
-                if (frn[i] == r) { hi[i] = mu * ln; lo[i] = -hi[i]; }
+                if (frn[i] == r) { hi[i] = mu[i] * ln; lo[i] = -hi[i]; }
             }
         }
     for (int d = 0; d < 16; ++d)
         for (int r = 0; r < nr; ++r) un[d] = FMA_(B[r][d], lam[r], un[d]);
 }
 
-typedef struct FN(orc_contact) { int level, leg, sphere; REAL r[3], n[3], dist; } FN(orc_contact);
+/* A contact: body A = (level, leg) of the ant against the static world (level2 < 0) or against another ant body
+ * B = (level2, leg2) (self-collision).  r = contact point relative to O, n = normal towards A, surface = what it is with:
+ * 0 ground, 1..n_planes lateral walls, 8 + b box b of the world, 16 + k item cube k, 64 + pair id self. */
+typedef struct FN(orc_contact) { int level, leg, level2, leg2, sphere, surface; REAL r[3], n[3], dist, mu; } FN(orc_contact);
+
+#define ORC_SURF_BOX 8
+#define ORC_SURF_ITEM 16
+#define ORC_SURF_SELF 64
+#define ORC_ITEM_HALF R_(0.125) /* assets/food.xml:12,19: box size 0.25 */
+#define ORC_ITEM_Z R_(0.1)      /* gather_scene.py:62 */
 
 /* sphere `s` (0 torso, 1+3l hip, 2+3l ankle, 3+3l tip): centre relative to O, radius, owning body */
 static void FN(sphere_info)(const FN(orc_consts) * K, const FN(orc_dyn) * D, int s, REAL *c, REAL *rad, int *level, int *leg) {
@@ -815,54 +891,119 @@ static void FN(sphere_info)(const FN(orc_consts) * K, const FN(orc_dyn) * D, int
     *rad = K->r_caps; *level = w; *leg = l;
 }
 
-/* Candidate order: surface-major (ground, planes..., boxes...), sphere-minor; at most MAXC contacts are kept. */
+/* signed distance of a sphere (centre p, radius rad) to the axis-aligned box [lo, hi]; n = unit normal towards the sphere */
+static REAL FN(sphere_vs_box)(const REAL *p, REAL rad, const REAL *lo, const REAL *hi, REAL *n) {
+    REAL d[3], d2 = 0;
+    for (int k = 0; k < 3; ++k) { REAL cp = FN(clampr)(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 = FMA_(d[k], d[k], d2); }
+    if (d2 > 0) { REAL len = RSQRT(d2); for (int k = 0; k < 3; ++k) n[k] = d[k] / len; return len - rad; }
+    if (!(d2 == 0)) { FN(v3set)(n, 0, 0, 1); return R_(1e30); } /* non-finite centre: no contact */
+    int best = 0; REAL bd = R_(1e30), sgn = 1; /* centre inside the box: exit through the nearest face */
+    for (int k = 0; k < 3; ++k) {
+        REAL dl = p[k] - lo[k], dh = hi[k] - p[k];
+        if (dl < bd) { bd = dl; best = k; sgn = -1; }
+        if (dh < bd) { bd = dh; best = k; sgn = 1; }
+    }
+    FN(v3set)(n, 0, 0, 0); n[best] = sgn;
+    return -bd - rad;
+}
+static void FN(item_box)(const REAL *item_xy, REAL *lo, REAL *hi) {
+    lo[0] = item_xy[0] - ORC_ITEM_HALF; lo[1] = item_xy[1] - ORC_ITEM_HALF; lo[2] = ORC_ITEM_Z - ORC_ITEM_HALF;
+    hi[0] = item_xy[0] + ORC_ITEM_HALF; hi[1] = item_xy[1] + ORC_ITEM_HALF; hi[2] = ORC_ITEM_Z + ORC_ITEM_HALF;
+}
+
+/* Closest points of the capsule axes P1Q1 and P2Q2 (Ericson, Real-Time Collision Detection 5.1.9), every operation
+ * pinned.  The segments have the fixed squared lengths a, e of the model (ia = 1/a, ie = 1/e are exact binary
+ * fractions: 12.5 and 3.125), so only the parallelism test divides. */
+static void FN(seg_seg)(const REAL *p1, const REAL *q1, REAL a, REAL ia, const REAL *p2, const REAL *q2, REAL e, REAL ie,
+                        REAL *c1, REAL *c2) {
+    REAL d1[3], d2[3], r[3];
+    for (int k = 0; k < 3; ++k) { d1[k] = q1[k] - p1[k]; d2[k] = q2[k] - p2[k]; r[k] = p1[k] - p2[k]; }
+    REAL f = FN(v3dot)(d2, r), c = FN(v3dot)(d1, r), b = FN(v3dot)(d1, d2);
+    REAL denom = FMA_(a, e, -(b * b)), sp = 0, t;
+    if (denom > R_(1e-9)) sp = FN(clampr)(FMA_(b, f, -(c * e)) / denom, 0, 1);
+    t = FMA_(b, sp, f) * ie;
+    if (t < 0) { t = 0; sp = FN(clampr)(-c * ia, 0, 1); }
+    else if (t > 1) { t = 1; sp = FN(clampr)((b - c) * ia, 0, 1); }
+    for (int k = 0; k < 3; ++k) { c1[k] = FMA_(d1[k], sp, p1[k]); c2[k] = FMA_(d2[k], t, p2[k]); }
+}
+
+/* Candidate order: surface-major (ground, lateral planes, world boxes, item cubes), sphere-minor; then the capsule
+ * pairs of different legs (pair id = 8 * legpair + 3 * segA + segB - 1; legpair (0,1),(0,2),(0,3),(1,2),(1,3),(2,3);
+ * seg 0 = the jointless leg capsule O -> hip point (torso body), 1 = aux capsule, 2 = foot capsule; (0,0) skipped: both
+ * rigid with the torso).  At most MAXC contacts are kept; *n_candidates counts them all. */
 static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, const FN(orc_dyn) * D, const REAL *pos,
-                          FN(orc_contact) * C, int *ground_touch /* [13] */) {
-    int nc = 0, nsurf = 1 + W->n_planes + W->n_boxes;
+                          const REAL *items_xy, int n_items, FN(orc_contact) * C, int *ground_touch /* [13] */, int *n_candidates) {
+    int nc = 0, ncand = 0;
+    const int use_items = (K->item_collision && items_xy) ? n_items : 0;
+    const int nsurf = 1 + W->n_planes + W->n_boxes + use_items;
     for (int s = 0; s < 13; ++s) ground_touch[s] = 0;
     for (int f = 0; f < nsurf; ++f)
         for (int s = 0; s < 13; ++s) {
             REAL c[3], rad, n[3], dist, p[3];
-            int level, leg;
+            int level, leg, surface;
             FN(sphere_info)(K, D, s, c, &rad, &level, &leg);
             for (int k = 0; k < 3; ++k) p[k] = pos[k] + c[k];
-            if (f == 0) { FN(v3set)(n, 0, 0, 1); dist = (p[2] - K->ground_z) - rad; }
+            if (f == 0) { FN(v3set)(n, 0, 0, 1); dist = (p[2] - K->ground_z) - rad; surface = 0; }
             else if (f <= W->n_planes) {
                 const REAL *pn = W->plane_n[f - 1];
                 FN(v3set)(n, pn[0], pn[1], pn[2]);
-                dist = (FN(v3dot)(n, p) - W->plane_d[f - 1]) - rad;
+                dist = (FN(v3dot)(n, p) - W->plane_d[f - 1]) - rad; surface = f;
+            } else if (f <= W->n_planes + W->n_boxes) {
+                const int b = f - 1 - W->n_planes;
+                dist = FN(sphere_vs_box)(p, rad, W->box_lo[b], W->box_hi[b], n); surface = ORC_SURF_BOX + b;
             } else {
-                const REAL *lo = W->box_lo[f - 1 - W->n_planes], *hi = W->box_hi[f - 1 - W->n_planes];
-                REAL d[3], d2 = 0;
-                for (int k = 0; k < 3; ++k) { REAL cp = FN(clampr)(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 = FMA_(d[k], d[k], d2); }
-                if (d2 > 0) { REAL len = RSQRT(d2); for (int k = 0; k < 3; ++k) n[k] = d[k] / len; dist = len - rad; }
-                else { /* centre inside the box: exit through the nearest face */
-                    int best = 0; REAL bd = R_(1e30), sgn = 1;
-                    for (int k = 0; k < 3; ++k) {
-                        REAL dl = p[k] - lo[k], dh = hi[k] - p[k];
-                        if (dl < bd) { bd = dl; best = k; sgn = -1; }
-                        if (dh < bd) { bd = dh; best = k; sgn = 1; }
-                    }
-                    FN(v3set)(n, 0, 0, 0); n[best] = sgn; dist = -bd - rad;
-                }
+                const int k = f - 1 - W->n_planes - W->n_boxes;
+                REAL lo[3], hi[3];
+                FN(item_box)(items_xy + 2 * k, lo, hi);
+                dist = FN(sphere_vs_box)(p, rad, lo, hi, n); surface = ORC_SURF_ITEM + k;
             }
             if (dist < K->cdist) {
                 if (f == 0) ground_touch[s] = 1;
+                ++ncand;
                 if (nc < MAXC) {
                     FN(orc_contact) *cc = &C[nc++];
-                    cc->level = level; cc->leg = leg; cc->sphere = s; cc->dist = dist;
+                    cc->level = level; cc->leg = leg; cc->level2 = -1; cc->leg2 = 0; cc->sphere = s; cc->dist = dist; cc->surface = surface; cc->mu = K->mu;
                     for (int k = 0; k < 3; ++k) { cc->n[k] = n[k]; cc->r[k] = FMA_(-rad, n[k], c[k]); }
                 }
             }
         }
+    if (K->self_collision) {
+        const REAL zero[3] = {0, 0, 0};
+        const REAL A0 = R_(0.08), A2 = R_(0.32), I0 = R_(12.5), I2 = R_(3.125); /* |(.2,.2)|^2, |(.4,.4)|^2 (ant.xml:16-22) and reciprocals */
+        const REAL thr = (K->r_caps + K->r_caps) + K->cdist;
+        int pair = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        if (a == 0 && b == 0) continue;
+                        const REAL *p1 = a == 0 ? zero : (a == 1 ? D->ph[i] : D->pa[i]), *q1 = a == 0 ? D->ph[i] : (a == 1 ? D->pa[i] : D->tip[i]);
+                        const REAL *p2 = b == 0 ? zero : (b == 1 ? D->ph[j] : D->pa[j]), *q2 = b == 0 ? D->ph[j] : (b == 1 ? D->pa[j] : D->tip[j]);
+                        REAL c1[3], c2[3], dv[3];
+                        FN(seg_seg)(p1, q1, a == 2 ? A2 : A0, a == 2 ? I2 : I0, p2, q2, b == 2 ? A2 : A0, b == 2 ? I2 : I0, c1, c2);
+                        for (int k = 0; k < 3; ++k) dv[k] = c1[k] - c2[k];
+                        const REAL d2n = FN(v3dot)(dv, dv);
+                        const int id = pair++;
+                        if (!(d2n < thr * thr)) continue;
+                        ++ncand;
+                        if (nc >= MAXC) continue;
+                        FN(orc_contact) *cc = &C[nc++];
+                        const REAL len = RSQRT(d2n);
+                        cc->level = a; cc->leg = i; cc->level2 = b; cc->leg2 = j; cc->sphere = -1; cc->surface = ORC_SURF_SELF + id; cc->mu = K->mu_self;
+                        cc->dist = len - (K->r_caps + K->r_caps);
+                        if (len > 0) for (int k = 0; k < 3; ++k) cc->n[k] = dv[k] / len; else FN(v3set)(cc->n, 0, 0, 1);
+                        for (int k = 0; k < 3; ++k) cc->r[k] = R_(0.5) * (c1[k] + c2[k]); /* equal radii: midway between the two surface points */
+                    }
+    }
+    if (n_candidates) *n_candidates = ncand;
     return nc;
 }
 
-typedef struct FN(orc_substep_dbg) { int n_rows, n_limits, n_contacts; REAL lambda[MAXR]; } FN(orc_substep_dbg);
+typedef struct FN(orc_substep_dbg) { int n_rows, n_limits, n_contacts, n_candidates, surface[MAXC]; REAL lambda[MAXR]; } FN(orc_substep_dbg);
 
 /* One physics substep on internal coordinates q[15] (x,y,z,qx,qy,qz,qw,joints) and u[14] (omega, v, joint rates). */
 void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL *q, REAL *u, const REAL *tau,
-                         int *ground_touch, FN(orc_substep_dbg) * dbg) {
+                         const REAL *items_xy, int n_items, int *ground_touch, FN(orc_substep_dbg) * dbg) {
     FN(orc_dyn) D;
     REAL h = K->h;
     FN(orc_dynamics)(K, q, u, tau, &D);
@@ -874,7 +1015,7 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
     for (int j = 0; j < NJ; ++j) un[6 + j] = FMA_(h, D.qdd[j], u[6 + j]);
     un[14] = un[15] = 0;
     /* (2) constraint rows: joint limits, contact normals, friction pairs */
-    REAL J[MAXR][16], B[MAXR][16], bias[MAXR], hi[MAXR], lam[MAXR]; /* hi: bound of non-friction rows */
+    REAL J[MAXR][16], B[MAXR][16], bias[MAXR], hi[MAXR], lam[MAXR], mu_row[MAXR]; /* hi: bound of non-friction rows */
     int fr_normal[MAXR];
     int nr = 0, nl = 0;
     REAL zero6[6] = {0, 0, 0, 0, 0, 0};
@@ -889,11 +1030,12 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         FN(orc_response)(&D, zero6, 0, j / 2, (j & 1) ? R_(0) : sgn, (j & 1) ? sgn : R_(0), B[nr]);
         B[nr][14] = B[nr][15] = 0;
         bias[nr] = (dist > 0 ? dist : K->erp_l * dist) * K->inv_h;
-        hi[nr] = K->limp_max; fr_normal[nr] = -1;
+        hi[nr] = K->limp_max; fr_normal[nr] = -1; mu_row[nr] = 0;
         ++nr; ++nl;
     }
     FN(orc_contact) C[MAXC];
-    int nc = FN(orc_detect)(K, W, &D, q, C, ground_touch);
+    int ncand = 0;
+    int nc = FN(orc_detect)(K, W, &D, q, items_xy, n_items, C, ground_touch, &ncand);
     /* rows nl..nl+nc-1: normals; then rows nl+nc+2c (t1), nl+nc+2c+1 (t2) */
     for (int row = 0; row < 3 * nc; ++row) {
         int c = row < nc ? row : (row - nc) / 2, which = row < nc ? 0 : 1 + ((row - nc) & 1);
@@ -903,19 +1045,27 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         FN(v3cross)(phi, C[c].r, d);
         for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
         memset(J[nr], 0, sizeof(J[nr]));
-        for (int k = 0; k < 6; ++k) J[nr][k] = phi[k];
         if (C[c].level >= 1) J[nr][6 + 2 * C[c].leg] = FN(dot6)(phi, D.S[2 * C[c].leg]);
         if (C[c].level >= 2) J[nr][7 + 2 * C[c].leg] = FN(dot6)(phi, D.S[2 * C[c].leg + 1]);
         FN(orc_response)(&D, phi, C[c].level, C[c].leg, 0, 0, B[nr]);
         B[nr][14] = B[nr][15] = 0;
+        if (C[c].level2 < 0) for (int k = 0; k < 6; ++k) J[nr][k] = phi[k];
+        else { /* self contact: J = J_A - J_B.  Both bodies move with the torso, so its part cancels exactly; what is left are
+                * the joints between the torso and A (leg) and, negated, between the torso and B (leg2 > leg).  B = B_A - B_B. */
+            REAL B2[16];
+            if (C[c].level2 >= 1) J[nr][6 + 2 * C[c].leg2] = -FN(dot6)(phi, D.S[2 * C[c].leg2]);
+            if (C[c].level2 >= 2) J[nr][7 + 2 * C[c].leg2] = -FN(dot6)(phi, D.S[2 * C[c].leg2 + 1]);
+            FN(orc_response)(&D, phi, C[c].level2, C[c].leg2, 0, 0, B2);
+            for (int k = 0; k < 14; ++k) B[nr][k] = B[nr][k] - B2[k];
+        }
         if (which == 0) {
             bias[nr] = (C[c].dist > 0 ? C[c].dist : K->erp_c * C[c].dist) * K->inv_h;
-            hi[nr] = R_(1e30); fr_normal[nr] = -1;
-        } else { bias[nr] = 0; hi[nr] = 0; fr_normal[nr] = nl + c; }
+            hi[nr] = R_(1e30); fr_normal[nr] = -1; mu_row[nr] = 0;
+        } else { bias[nr] = 0; hi[nr] = 0; fr_normal[nr] = nl + c; mu_row[nr] = C[c].mu; }
         ++nr;
     }
     /* (3) projected Gauss-Seidel in row space */
-    FN(orc_pgs)(nr, J, B, bias, hi, fr_normal, K->mu, K->iters, un, lam);
+    FN(orc_pgs)(nr, J, B, bias, hi, fr_normal, mu_row, K->iters, un, lam);
     /* (4) joint-rate clamp and position integration (semi-implicit Euler, exponential map for the quaternion) */
     for (int j = 0; j < NJ; ++j) un[6 + j] = FN(clampr)(un[6 + j], -K->vmax, K->vmax);
     for (int k = 0; k < NDOF; ++k) u[k] = un[k];
@@ -933,38 +1083,48 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
     }
     for (int j = 0; j < NJ; ++j) q[7 + j] = FMA_(h, u[6 + j], q[7 + j]);
-    if (dbg) { dbg->n_rows = nr; dbg->n_limits = nl; dbg->n_contacts = nc; for (int r = 0; r < nr; ++r) dbg->lambda[r] = lam[r]; }
+    if (dbg) { dbg->n_rows = nr; dbg->n_limits = nl; dbg->n_contacts = nc; dbg->n_candidates = ncand; for (int r = 0; r < nr; ++r) dbg->lambda[r] = lam[r]; for (int c = 0; c < nc; ++c) dbg->surface[c] = C[c].surface; }
 }
 
 /* ---------------------------------------------------------------------------------------------- point bot body
  * point_bot.py:10-74 + assets/player_cube.xml:8: free 10 kg cube, half extent 0.35, friction 0.1.  A solid cube's
  * inertia is isotropic (m s^2/6), so M^-1 is diagonal and omega x I omega = 0. */
-void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL *q, REAL *u, const REAL *force) {
+void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL *q, REAL *u, const REAL *force,
+                           const REAL *items_xy, int n_items, FN(orc_substep_dbg) * dbg) {
     const REAL m = 10, he = R_(0.35), I = m * (R_(0.7) * R_(0.7)) / 6, h = K->h;
     REAL x = q[3], y = q[4], z = q[5], w = q[6], X[3], Y[3], Z[3];
     FN(quat_axes)(x, y, z, w, X, Y, Z);
     REAL un[6];
     for (int k = 0; k < 3; ++k) un[k] = u[k];
     un[3] = FMA_(h, force[0] / m, u[3]); un[4] = FMA_(h, force[1] / m, u[4]); un[5] = FMA_(h, force[2] / m - K->g, u[5]);
-    /* contacts: 8 corners vs ground + lateral planes, surface-major order, at most MAXC */
-    REAL Jr[3 * MAXC][16], Br[3 * MAXC][16], bias[3 * MAXC], hic[3 * MAXC], lam[3 * MAXC];
-    int frn[3 * MAXC], nc = 0;
+    /* contacts: 8 corners vs ground, lateral planes and item cubes, surface-major order, at most MAXC */
+    REAL Jr[3 * MAXC][16], Br[3 * MAXC][16], bias[3 * MAXC], hic[3 * MAXC], lam[3 * MAXC], mu_row[3 * MAXC];
+    int frn[3 * MAXC], nc = 0, ncand = 0, csurf[MAXC];
     REAL cr[MAXC][3], cn[MAXC][3], cd[MAXC];
-    for (int f = 0; f < 1 + W->n_planes; ++f)
+    const int use_items = (K->item_collision && items_xy) ? n_items : 0;
+    for (int f = 0; f < 1 + W->n_planes + use_items; ++f)
         for (int s = 0; s < 8; ++s) {
             REAL c[3], n[3], dist;
             REAL sx = (s & 1) ? he : -he, sy = (s & 2) ? he : -he, sz = (s & 4) ? he : -he;
+            int surface = f;
             for (int k = 0; k < 3; ++k) c[k] = FMA_(sz, Z[k], FMA_(sy, Y[k], sx * X[k]));
-            if (f == 0) { FN(v3set)(n, 0, 0, 1); dist = (q[2] + c[2]) - K->ground_z; }
-            else {
+            REAL p[3] = {q[0] + c[0], q[1] + c[1], q[2] + c[2]};
+            if (f == 0) { FN(v3set)(n, 0, 0, 1); dist = p[2] - K->ground_z; }
+            else if (f <= W->n_planes) {
                 const REAL *pn = W->plane_n[f - 1];
-                REAL p[3] = {q[0] + c[0], q[1] + c[1], q[2] + c[2]};
                 FN(v3set)(n, pn[0], pn[1], pn[2]);
                 dist = FN(v3dot)(n, p) - W->plane_d[f - 1];
+            } else {
+                REAL lo[3], hi[3];
+                FN(item_box)(items_xy + 2 * (f - 1 - W->n_planes), lo, hi);
+                dist = FN(sphere_vs_box)(p, 0, lo, hi, n); surface = ORC_SURF_ITEM + (f - 1 - W->n_planes);
             }
-            if (dist < K->cdist && nc < MAXC) {
-                for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
-                cd[nc] = dist; ++nc;
+            if (dist < K->cdist) {
+                ++ncand;
+                if (nc < MAXC) {
+                    for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
+                    cd[nc] = dist; csurf[nc] = surface; ++nc;
+                }
             }
         }
     int nr = 0;
@@ -978,12 +1138,13 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
         for (int k = 0; k < 3; ++k) { Jr[nr][3 + k] = d[k]; Br[nr][k] = Jr[nr][k] / I; Br[nr][3 + k] = d[k] / m; }
         bias[nr] = which == 0 ? (cd[c] > 0 ? cd[c] : K->erp_c * cd[c]) * K->inv_h : R_(0);
         hic[nr] = which == 0 ? R_(1e30) : R_(0);
-        frn[nr] = which == 0 ? -1 : c;
+        frn[nr] = which == 0 ? -1 : c; mu_row[nr] = which == 0 ? R_(0) : K->mu;
         ++nr;
     }
     REAL un16[16] = {0};
     for (int k = 0; k < 6; ++k) un16[k] = un[k];
-    FN(orc_pgs)(nr, Jr, Br, bias, hic, frn, K->mu, K->iters, un16, lam);
+    FN(orc_pgs)(nr, Jr, Br, bias, hic, frn, mu_row, K->iters, un16, lam);
+    if (dbg) { dbg->n_rows = nr; dbg->n_limits = 0; dbg->n_contacts = nc; dbg->n_candidates = ncand; for (int r = 0; r < nr; ++r) dbg->lambda[r] = lam[r]; for (int c = 0; c < nc; ++c) dbg->surface[c] = csurf[c]; }
     for (int k = 0; k < 6; ++k) un[k] = un16[k];
     for (int k = 0; k < 6; ++k) u[k] = un[k];
     for (int k = 0; k < 3; ++k) q[k] = FMA_(h, u[3 + k], q[k]);
@@ -1023,7 +1184,7 @@ void FN(orc_quat_to_rpy)(const REAL *qq, REAL *rpy) {
  * Also returns joints_at_limit, walk_target_dist (centroid based) and yaw. */
 void FN(orc_ant_calc_state)(const hrl_config *cfg, const FN(orc_consts) * K, const REAL *qpos, const REAL *qvel,
                             REAL initial_z, const REAL *target, const REAL *feet_contact, REAL *out28,
-                            int *joints_at_limit, REAL *walk_target_dist, REAL *rpy_out) {
+                            int *joints_at_limit, REAL *walk_target_dist, REAL *rpy_out, REAL *centroid_out) {
     REAL rpy[3];
     FN(orc_quat_to_rpy)(qpos + 3, rpy);
     /* centroid over robot.parts: 13 link COMs + the scene statics */
@@ -1042,6 +1203,7 @@ void FN(orc_ant_calc_state)(const hrl_config *cfg, const FN(orc_consts) * K, con
     REAL cy = ((R_(13) * qpos[1] + sy) + R_(cfg->centroid_static_sum[1])) / np_;
     REAL dx = target[0] - cx, dy = target[1] - cy;
     REAL theta = RATAN2(dy, dx);
+    if (centroid_out) { centroid_out[0] = cx; centroid_out[1] = cy; }
     *walk_target_dist = RSQRT(dy * dy + dx * dx);
     REAL ang = theta - rpy[2];
     REAL c = RCOS(-rpy[2]), s = RSIN(-rpy[2]);
@@ -1070,16 +1232,20 @@ static void FN(draw_pair)(const hrl_config *cfg, int64_t env, uint32_t index, ui
     out[0] = FN(u01)(r[0]); out[1] = FN(u01)(r[1]);
 }
 
+/* counter-based source of respawn draws: Philox keyed by (env, index, purpose, item, attempt) */
+typedef struct FN(orc_philox_src) { const hrl_config *cfg; int64_t env; uint32_t index, purpose; } FN(orc_philox_src);
+static int FN(orc_draw_philox)(void *ctx, int item, int attempt, double *pair) {
+    FN(orc_philox_src) *p = (FN(orc_philox_src) *)ctx;
+    REAL d[2];
+    FN(draw_pair)(p->cfg, p->env, p->index, p->purpose, (uint32_t)item, (uint32_t)attempt, d);
+    pair[0] = d[0]; pair[1] = d[1];
+    return 1;
+}
 /* gather_scene.py:52-62 with Philox draws; at most 64 attempts (the last is kept) */
 static void FN(respawn_item)(const hrl_config *cfg, int64_t env, uint32_t index, uint32_t purpose, int item, const REAL *avoid, REAL *pos) {
-    REAL sxw = R_(cfg->world_size[0]) - 1, syw = R_(cfg->world_size[1]) - 1, sp = R_(cfg->robot_object_spacing);
-    for (uint32_t a = 0; a < 64; ++a) {
-        REAL d[2];
-        FN(draw_pair)(cfg, env, index, purpose, (uint32_t)item, a, d);
-        pos[0] = d[0] * sxw - sxw / 2; pos[1] = d[1] * syw - syw / 2;
-        REAL dx = avoid[0] - pos[0], dy = avoid[1] - pos[1];
-        if (!(RSQRT(dx * dx + dy * dy) < sp)) break;
-    }
+    REAL ws[2] = {R_(cfg->world_size[0]), R_(cfg->world_size[1])};
+    FN(orc_philox_src) src = {cfg, env, index, purpose};
+    FN(random_on_plane_src)(ws, avoid, R_(cfg->robot_object_spacing), FN(orc_draw_philox), &src, item, 64, pos);
 }
 
 static void FN(gather_obs_tail)(const hrl_config *cfg, const REAL *xy, REAL yaw, const REAL *items, REAL *obs) {
@@ -1119,13 +1285,26 @@ static void FN(flag_close_goal)(const hrl_config *cfg, int64_t env, uint32_t ep,
     }
 }
 void FN(orc_flag_close_goal)(const hrl_config *cfg, int64_t env, int ep, int k, const REAL *robot_xy, REAL *g) { FN(flag_close_goal)(cfg, env, (uint32_t)ep, (uint32_t)k, robot_xy, g); } /* tests */
-/* the goal the env is chasing: from the shared list, or (max_target_dist mode) the one kept in items[0..1] */
-static void FN(flag_current_goal)(const hrl_config *cfg, const REAL *items, const int32_t *aux, REAL *g) {
-    if (cfg->flag_max_target_dist > 0) { g[0] = items[0]; g[1] = items[1]; }
-    else FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)aux[3] & 0xffffu, g);
-}
 static const REAL FN(maze_lines)[7][4] = { /* MazeScene.bounds: maze_scene.py:15-21 + sizeable_enclosed_scene.py:28-34 */
     {5, 9, -5, 9}, {5, 9, 5, -9}, {-5, -9, -5, 9}, {-5, -9, 5, -9}, {1, 2, 1, -2}, {-5, -2, -5, 2}, {-5, -2, 1, -2}};
+
+/* The potential a reset leaves behind.  upstream WalkerBaseBulletEnv.reset() sets `self.potential = robot.calc_potential()`
+ * (= -walk_target_dist / dt) BEFORE the in-tree reset code moves the robot or switches the target:
+ *   - AntFlagrunBulletEnv.reset (ant_flagrun_env.py:132-155): super().reset(), teleport (:144), calc_state (:146, the walk
+ *     target is still the PREVIOUS goal), next_target(): set_target(new) then `self.potential = calc_potential()` (:116)
+ *     re-reads that walk_target_dist: the distance of the NEW pose to the PREVIOUS goal;
+ *   - AntMazeBulletEnv.reset (ant_maze_bullet_env.py:104-121), AntMazeMjEnv.reset (ant_maze_mj_env.py:85-104):
+ *     super().reset() (:111) computes it at the default pose (0, 0, 0.75) against the PREVIOUS target; the new target
+ *     (:114-115), the teleport (:117) and the calc_state (:119) do not touch it.
+ * `centroid` = parts centroid of the FINAL reset pose; for the maze kinds the robot's 13 parts stood start_xy away when the
+ * potential was taken (same joint angles here: the reference draws the joint noise twice, :111 and :118, this build once).
+ * Before the first episode the walk target is upstream's default (1e3, 0) = cfg->walk_target. */
+REAL FN(orc_reset_potential)(int maze_kind, const REAL *prev_target, const REAL *centroid, const REAL *start_xy, int n_parts, REAL dt) {
+    REAL cx = centroid[0], cy = centroid[1];
+    if (maze_kind) { cx = cx - (R_(13) * start_xy[0]) / R_(n_parts); cy = cy - (R_(13) * start_xy[1]) / R_(n_parts); }
+    REAL dx = prev_target[0] - cx, dy = prev_target[1] - cy;
+    return -RSQRT(dy * dy + dx * dx) / dt;
+}
 
 typedef struct FN(orc_env) {
     hrl_config cfg;
@@ -1139,9 +1318,15 @@ void FN(orc_env_init)(const hrl_config *cfg, FN(orc_env) * E) {
     FN(orc_world_init)(cfg, &E->W);
 }
 
+/* the goal a flagrun env is chasing: kept in items[0..1] (max_target_dist and manual modes) or the k-th of the shared list */
+static void FN(flag_current_goal)(const hrl_config *cfg, const REAL *items, const int32_t *aux, REAL *g) {
+    if (cfg->flag_max_target_dist > 0 || cfg->flag_manual_goals) { g[0] = items[0]; g[1] = items[1]; }
+    else FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)aux[3] & 0xffffu, g);
+}
+
 /* observation of the CURRENT state (used by reset and by step) for ant kinds that do not need step-only data */
 static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *items, const int32_t *aux, const REAL *feet,
-                         REAL *obs, REAL *wtd_out, int *nlim_out, REAL *s28_out) {
+                         REAL *obs, REAL *wtd_out, int *nlim_out, REAL *s28_out, REAL *centroid_out) {
     const hrl_config *cfg = &E->cfg;
     if (cfg->env_kind == HRL_POINT_GATHER) {
         REAL rpy[3], tgt[2] = {0, 0};
@@ -1154,7 +1339,7 @@ static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *item
     int nlim;
     if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { tgt[0] = R_(cfg->targets[aux[3]][0]); tgt[1] = R_(cfg->targets[aux[3]][1]); }
     if (cfg->env_kind == HRL_ANT_FLAGRUN) FN(flag_current_goal)(cfg, items, aux, tgt);
-    FN(orc_ant_calc_state)(cfg, &E->K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+    FN(orc_ant_calc_state)(cfg, &E->K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy, centroid_out);
     if (wtd_out) *wtd_out = wtd;
     if (nlim_out) *nlim_out = nlim;
     if (s28_out) for (int i = 0; i < 28; ++i) s28_out[i] = s28[i];
@@ -1188,14 +1373,21 @@ static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *item
 void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, REAL *obs) {
     const hrl_config *cfg = &E->cfg;
     uint32_t ep = (uint32_t)aux[2];
+    const int maze_kind = cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ;
+    /* what the robot was walking towards before this reset (see orc_reset_potential) */
+    REAL prev_target[2] = {R_(cfg->walk_target[0]), R_(cfg->walk_target[1])};
+    if (ep > 0) {
+        if (maze_kind) { prev_target[0] = R_(cfg->targets[aux[3]][0]); prev_target[1] = R_(cfg->targets[aux[3]][1]); }
+        if (cfg->env_kind == HRL_ANT_FLAGRUN) FN(flag_current_goal)(cfg, items, aux, prev_target);
+    }
     for (int i = 0; i < HRL_STATE_STRIDE; ++i) st[i] = 0;
     st[6] = 1; /* identity quaternion (x,y,z,w) */
     if (cfg->env_kind == HRL_POINT_GATHER) { st[2] = R_(0.5); st[HRL_INITZ_OFF] = 1; } /* point_bot.py:12,18 */
     else {
         if (cfg->env_kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:132-155: start (0,0,0.25), first goal popped */
-            aux[3] = 1;
+            aux[3] = cfg->flag_manual_goals ? 0 : 1; /* manual: goals.clear() (:149), nothing popped */
             st[0] = R_(cfg->start_pos[0]); st[1] = R_(cfg->start_pos[1]); st[2] = R_(cfg->start_pos[2]);
-        } else if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_MAZE_MJ) { /* ant_maze_bullet_env.py:108-118, ant_maze_mj_env.py:85-101 */
+        } else if (maze_kind) { /* ant_maze_bullet_env.py:108-118, ant_maze_mj_env.py:85-101 */
             uint32_t r[4];
             orc_philox4x32(cfg->seed, env, ep, (3u << 16), 0, r);
             aux[3] = (int32_t)(r[0] % (uint32_t)cfg->n_targets);
@@ -1214,16 +1406,37 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
         for (int i = 0; i < cfg->n_food + cfg->n_poison; ++i) FN(respawn_item)(cfg, env, ep, 1, i, origin, items + 2 * i);
     }
     aux[0] = 0; aux[2] = (int32_t)(ep + 1); /* NB: the flagrun goal stream is keyed by the NEW episode index */
-    if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_max_target_dist > 0) { /* reset -> next_target -> create_close_target (:153, :111-112) */
+    if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_manual_goals) { /* the walk target survives the reset (:149-152), pending goals do not */
+        for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+        items[0] = prev_target[0]; items[1] = prev_target[1];
+    } else if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_max_target_dist > 0) { /* reset -> next_target -> create_close_target (:153, :111-112) */
         REAL g2[2];
         for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
         FN(flag_close_goal)(cfg, env, ep + 1, 1, st, g2);
         items[0] = g2[0]; items[1] = g2[1];
     }
-    REAL feet[4] = {0, 0, 0, 0}, wtd = 0;
-    FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0);
-    /* upstream calc_potential = -dist/dt; only the flat and maze kinds use it */
-    st[HRL_POTENTIAL_OFF] = (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) ? R_(0) : -wtd / (E->K.h * R_(E->K.nsub));
+    REAL feet[4] = {0, 0, 0, 0}, wtd = 0, cen[2] = {0, 0};
+    FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0, cen);
+    const REAL dt = E->K.h * R_(E->K.nsub);
+    if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) st[HRL_POTENTIAL_OFF] = 0; /* never read */
+    else if (cfg->env_kind == HRL_ANT_FLAT) st[HRL_POTENTIAL_OFF] = -wtd / dt; /* upstream reset: calc_potential at the reset pose */
+    else {
+        REAL sxy[2] = {R_(cfg->start_pos[0]), R_(cfg->start_pos[1])};
+        st[HRL_POTENTIAL_OFF] = FN(orc_reset_potential)(maze_kind, prev_target, cen, sxy, 13 + cfg->centroid_n_static, dt);
+    }
+}
+
+/* `env.goals = [...]; env.next_target()` of a manual_goal_creation flagrun env (ant_flagrun_env.py:91-118), see
+ * hrl_set_goals() in include/hrl_envs.h: goal 0 becomes the current one, the others are stacked so that they are popped
+ * in the given order; _rewarded is cleared (:115), the potential is left alone (:116 re-reads the value step() has just
+ * stored), the returned state is calc_state() towards the new goal (:117). */
+void FN(orc_env_set_goals_one)(const FN(orc_env) * E, REAL *st, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals, REAL *obs) {
+    items[0] = goals_xy[0]; items[1] = goals_xy[1];
+    for (int k = 1; k < n_goals; ++k) { items[2 + 2 * (n_goals - 1 - k)] = goals_xy[2 * k]; items[3 + 2 * (n_goals - 1 - k)] = goals_xy[2 * k + 1]; }
+    for (int i = 2 * n_goals; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+    aux[3] = (int32_t)(((uint32_t)(n_goals - 1) & 0xffffu) | ((uint32_t)aux[3] & 0x7fff0000u));
+    REAL feet[4] = {0, 0, 0, 0};
+    FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0);
 }
 
 /* One env step on the packed record.  Mirrors hrl_step() of include/hrl_envs.h. */
@@ -1233,17 +1446,21 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
     const FN(orc_consts) *K = &E->K;
     REAL q[15], u[14], feet[4] = {0, 0, 0, 0};
     uint32_t t_life = (uint32_t)aux[1];
+    const int gather = cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER;
+    const int n_items = gather ? cfg->n_food + cfg->n_poison : 0;
+    FN(orc_substep_dbg) dbg;
+    memset(&dbg, 0, sizeof(dbg));
     for (int i = 0; i < 15; ++i) q[i] = st[i];
     for (int k = 0; k < 3; ++k) { u[k] = st[HRL_QVEL_OFF + 3 + k]; u[3 + k] = st[HRL_QVEL_OFF + k]; }
     for (int j = 0; j < NJ; ++j) u[6 + j] = st[HRL_QVEL_OFF + 6 + j];
     if (cfg->env_kind == HRL_POINT_GATHER) { /* point_bot.py:28-31: a/|a|*500 N in the world xy plane */
         REAL n = RSQRT(act[0] * act[0] + act[1] * act[1]), f[3] = {act[0] / n * R_(cfg->model.point_force), act[1] / n * R_(cfg->model.point_force), 0};
-        for (int s = 0; s < K->nsub; ++s) FN(orc_point_substep)(K, &E->W, q, u, f);
+        for (int s = 0; s < K->nsub; ++s) FN(orc_point_substep)(K, &E->W, q, u, f, items, n_items, &dbg);
     } else {
         REAL tau[NJ];
         for (int j = 0; j < NJ; ++j) tau[j] = R_(cfg->model.torque_scale) * FN(clampr)(act[j], -1, 1);
         int gt[13];
-        for (int s = 0; s < K->nsub; ++s) FN(orc_ant_substep)(K, &E->W, q, u, tau, gt, 0);
+        for (int s = 0; s < K->nsub; ++s) FN(orc_ant_substep)(K, &E->W, q, u, tau, gather ? items : 0, n_items, gt, &dbg);
         for (int l = 0; l < 4; ++l) feet[l] = (gt[2 + 3 * l] || gt[3 + 3 * l]) ? R_(1) : R_(0);
     }
     for (int i = 0; i < 15; ++i) st[i] = q[i];
@@ -1252,28 +1469,21 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
 
     REAL rew = 0, food_rew = 0, dead_rew = 0;
     int done = 0;
-    if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) {
-        /* pickups (ant_gather_env.py:84-92) -- item order = food slots then poison slots */
-        int n = cfg->n_food + cfg->n_poison;
-        if (cfg->robot_coll_dist > 0)
-            for (int i = 0; i < n; ++i)
-                if (FN(orc_sq_dist)(items + 2 * i, st) < R_(cfg->robot_coll_dist)) {
-                    food_rew += (i < cfg->n_food) ? 1 : -1;
-                    if (cfg->respawn) FN(respawn_item)(cfg, env, t_life, 0, i, st, items + 2 * i);
-                    else { items[2 * i] = 100; items[2 * i + 1] = 0; }
-                }
-        int no = orc_obs_dim(cfg);
-        if (cfg->env_kind == HRL_ANT_GATHER) feet[0] = feet[1] = feet[2] = feet[3] = 0; /* ant_gather_env.py:105-111 */
-        FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0);
-        REAL alive = 1;
-        if (cfg->env_kind == HRL_ANT_GATHER) alive = (obs[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
-        done = alive < 0;
-        for (int i = 0; i < no; ++i) if (!isfinite(obs[i])) done = 1;
-        dead_rew = alive < 0 ? R_(cfg->dying_cost) : 0;
-        rew = food_rew + dead_rew;
+    if (gather) { /* the task half is the golden-pinned orc_gather_task (ant_gather_env.py:81-119, gather_base.py:80-109) */
+        const int ant = cfg->env_kind == HRL_ANT_GATHER;
+        REAL base[28], rpy[3], wtd, tgt[2] = {0, 0};
+        int nlim, contact_items[MAXC];
+        if (ant) { feet[0] = feet[1] = feet[2] = feet[3] = 0; /* ant_gather_env.py:105-111 */
+                   FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, base, &nlim, &wtd, rpy, 0); }
+        else { FN(orc_quat_to_rpy)(st + 3, rpy); FN(orc_pointbot_state)(st, rpy, st + HRL_QVEL_OFF, tgt, 1, base); }
+        /* getContactPoints after stepSimulation = the contacts of the step's last collision pass (:114) */
+        for (int c = 0; c < dbg.n_contacts; ++c) contact_items[c] = dbg.surface[c] >= ORC_SURF_ITEM && dbg.surface[c] < ORC_SURF_ITEM + HRL_MAX_ITEMS ? dbg.surface[c] - ORC_SURF_ITEM : -1;
+        FN(orc_philox_src) src = {cfg, env, t_life, 0};
+        FN(orc_gather_task_src)(cfg, ant, base, ant ? 28 : 8, st, rpy[2], st[HRL_INITZ_OFF], ant ? R_(0.26) : R_(-1), items, FN(orc_draw_philox), &src, 64,
+                                contact_items, dbg.n_contacts, obs, &rew, &done, &food_rew, &dead_rew);
     } else if (cfg->env_kind == HRL_ANT_FLAT) {
         REAL wtd; int nlim;
-        FN(make_obs)(E, st, items, aux, feet, obs, &wtd, &nlim, 0);
+        FN(make_obs)(E, st, items, aux, feet, obs, &wtd, &nlim, 0, 0);
         REAL pot = -wtd / (K->h * R_(K->nsub));
         FN(orc_antmj_reward)(obs, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &rew, &done);
         st[HRL_POTENTIAL_OFF] = pot;
@@ -1281,29 +1491,31 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
                                                      (ant_flagrun_env.py:133-135), then ant_flagrun_env.py:162-204 */
         REAL wtd, s28[28], rpy[3], tgt[2];
         int nlim, steps = (aux[3] >> 16) & 0x7fff, rewarded = (aux[3] >> 31) & 1, cur = aux[3] & 0xffff, retarget;
-        const int close_mode = cfg->flag_max_target_dist > 0;
+        const int close_mode = cfg->flag_max_target_dist > 0 && !cfg->flag_manual_goals, manual = cfg->flag_manual_goals;
         FN(flag_current_goal)(cfg, items, aux, tgt);
-        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy, 0);
         REAL alive = (s28[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
         int idone = alive < 0;
         for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
         REAL pot = -wtd / (K->h * R_(K->nsub)), progress = pot - st[HRL_POTENTIAL_OFF];
         st[HRL_POTENTIAL_OFF] = pot; /* next_target() re-reads the same stale potential (:116), i.e. leaves it unchanged */
         const int budget = close_mode ? (1 << 20) : cfg->flag_max_targets; /* max_target_dist mode never runs out (:111-112) */
-        int goals_left = budget - cur;
+        int goals_left = manual ? cur : budget - cur; /* manual: `cur` counts the pending goals */
         FN(orc_flagrun_task)(cfg, alive + progress, idone, wtd, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
-        cur = budget - goals_left;
+        if (steps > 0x7fff) steps = 0x7fff; /* steps_since_goal_change saturates in its 15-bit field (only reachable with the timeout off) */
+        cur = manual ? goals_left : budget - goals_left;
+        if (manual && retarget) { items[0] = items[2 + 2 * cur]; items[1] = items[3 + 2 * cur]; } /* goals.pop() (:114) */
         if (close_mode && retarget) { /* set_target(*create_close_target()): around the robot's current xy (:80-89, :112) */
             REAL g2[2];
             FN(flag_close_goal)(cfg, env, (uint32_t)aux[2], (uint32_t)cur, st, g2);
             items[0] = g2[0]; items[1] = g2[1];
         }
         aux[3] = (int32_t)(((uint32_t)cur & 0xffffu) | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
-        FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0); /* calc_state w.r.t. the (possibly new) goal */
+        FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0); /* calc_state w.r.t. the (possibly new) goal */
     } else if (cfg->env_kind == HRL_ANT_MAZE_MJ) { /* MjAnt.py:36-97 then ant_maze_mj_env.py:66-78 */
         REAL wtd, s28[28], rpy[3], inner, tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};
         int nlim, idone;
-        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy, 0);
         REAL pot = -wtd / (K->h * R_(K->nsub));
         FN(orc_antmj_reward)(st, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &inner, &idone);
         st[HRL_POTENTIAL_OFF] = pot;
@@ -1311,7 +1523,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
     } else { /* maze: upstream WalkerBaseBulletEnv.step then ant_maze_bullet_env.py:77-97 */
         REAL wtd, s28[28], rpy[3], tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};
         int nlim;
-        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy);
+        FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy, 0);
         REAL alive = (s28[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
         int idone = alive < 0;
         for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
@@ -1353,6 +1565,17 @@ void FN(orc_step_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t
         FN(orc_env_step_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE,
                              items ? items + (size_t)i * HRL_ITEMS_STRIDE : 0, aux + (size_t)i * HRL_AUX_STRIDE,
                              actions + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, info + (size_t)i * HRL_INFO_STRIDE);
+}
+
+void FN(orc_set_goals_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals, const uint8_t *mask, REAL *obs) {
+    FN(orc_env) E;
+    FN(orc_env_init)(cfg, &E);
+    int od = orc_obs_dim(cfg);
+    for (int i = 0; i < cfg->num_envs; ++i) {
+        if (mask && !mask[i]) continue;
+        FN(orc_env_set_goals_one)(&E, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * HRL_ITEMS_STRIDE, aux + (size_t)i * HRL_AUX_STRIDE,
+                                  goals_xy + (size_t)i * n_goals * 2, n_goals, obs + (size_t)i * od);
+    }
 }
 
 /* CPU baseline loop for bench.py: reset, then `steps` env steps of all cfg->num_envs envs with U(-1,1) actions from a
@@ -1432,19 +1655,24 @@ void FN(orc_ant_minv)(const hrl_model *M, const REAL *q, REAL *out196) {
         for (int r = 0; r < NDOF; ++r) out196[r * NDOF + c] = du[r];
     }
 }
-void FN(orc_ant_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *tau, int n, int *info3) {
+void FN(orc_ant_substeps_items)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *tau, int n, const REAL *items_xy, int n_items, int *info3, int *dbg_out /* [1 + MAXC]: candidates, surfaces */, REAL *lambda_out /* [MAXR] */) {
     FN(orc_env) E; FN(orc_substep_dbg) dbg; int gt[13];
     FN(orc_env_init)(cfg, &E);
     memset(&dbg, 0, sizeof(dbg));
-    for (int s = 0; s < n; ++s) FN(orc_ant_substep)(&E.K, &E.W, q, u, tau, gt, &dbg);
+    for (int s = 0; s < n; ++s) FN(orc_ant_substep)(&E.K, &E.W, q, u, tau, items_xy, n_items, gt, &dbg);
     if (info3) { info3[0] = dbg.n_rows; info3[1] = dbg.n_limits; info3[2] = dbg.n_contacts; }
+    if (dbg_out) { dbg_out[0] = dbg.n_candidates; for (int c = 0; c < MAXC; ++c) dbg_out[1 + c] = c < dbg.n_contacts ? dbg.surface[c] : -1; }
+    if (lambda_out) for (int r = 0; r < MAXR; ++r) lambda_out[r] = r < dbg.n_rows ? dbg.lambda[r] : 0;
 }
 
+void FN(orc_ant_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *tau, int n, int *info3) {
+    FN(orc_ant_substeps_items)(cfg, q, u, tau, n, 0, 0, info3, 0, 0);
+}
 /* n point-bot substeps on q[7] (x,y,z,quat xyzw) and u[6] (omega, v) under a constant world-frame force (tests) */
 void FN(orc_point_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *force, int n) {
     FN(orc_env) E;
     FN(orc_env_init)(cfg, &E);
-    for (int s = 0; s < n; ++s) FN(orc_point_substep)(&E.K, &E.W, q, u, force);
+    for (int s = 0; s < n; ++s) FN(orc_point_substep)(&E.K, &E.W, q, u, force, 0, 0, 0);
 }
 
 #undef NJ

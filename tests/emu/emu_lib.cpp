@@ -39,6 +39,12 @@ struct CpuExec {
         else { for (int lane = 63; lane >= 0; --lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane]); } }
         return n;
     }
+    template <class P> unsigned long long each_ballot(P pred) {
+        unsigned long long m = 0;
+        if (!reverse) { for (int lane = 0; lane < 64; ++lane) if (pred(lane)) m |= 1ull << lane; }
+        else { for (int lane = 63; lane >= 0; --lane) if (pred(lane)) m |= 1ull << lane; }
+        return m;
+    }
     template <class P, class C> void each_row(int src, P produce, C apply) {
         F2b v[64];
         if (!reverse) for (int lane = 0; lane < 64; ++lane) v[lane] = produce(lane);
@@ -80,6 +86,13 @@ int emu_step(const hrl_config *cfg, const hrl_buffers *b, int reverse) {
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, nullptr);
     for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; step_dispatch(x, d, c, e); }
+    return HRL_OK;
+}
+int emu_set_goals(const hrl_config *cfg, const hrl_buffers *b, const float *goals_xy, int n_goals, const uint8_t *mask, int reverse) {
+    if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN || !cfg->flag_manual_goals || n_goals < 1 || n_goals > HRL_MAX_GOALS) return HRL_ERR_BAD_ARG;
+    DevCfg c; build_devcfg(*cfg, c);
+    DevBufs d = to_dev(b, mask);
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; set_goals_entry(x, d, c, e, goals_xy, n_goals); }
     return HRL_OK;
 }
 int emu_lds_bytes(void) { return (int)sizeof(WaveLds); }

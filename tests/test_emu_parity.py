@@ -173,8 +173,13 @@ def test_validation_errors():
     L = emu_env.lib()
     bad = orc.default_config(K.HRL_ANT_GATHER, n_food=12, n_poison=12)
     assert b'n_food' in L.emu_validate(C.byref(bad))
-    bad = orc.default_config(K.HRL_ANT_GATHER, robot_coll_dist=0)
-    assert b'robot_coll_dist' in L.emu_validate(C.byref(bad))
+    bad = orc.default_config(K.HRL_ANT_GATHER, robot_coll_dist=0, model_item_collision=0)
+    assert b'robot_coll_dist' in L.emu_validate(C.byref(bad))  # contact pickup needs the cubes as colliders
+    assert L.emu_validate(C.byref(orc.default_config(K.HRL_ANT_GATHER, robot_coll_dist=0))) == b''
+    bad = orc.default_config(K.HRL_ANT_MAZE, n_bins=1, sensor_span=3.0)
+    assert b'n_bins' in L.emu_validate(C.byref(bad))  # the wall sensor would divide by n_bins - 1
+    bad = orc.default_config(K.HRL_ANT_MAZE, sense_walls=0, sense_target=1, sensor_span=0.0)
+    assert b'sensor_span' in L.emu_validate(C.byref(bad))
     bad = orc.default_config(K.HRL_ANT_MAZE, n_targets=0)
     assert b'n_targets' in L.emu_validate(C.byref(bad))
     assert L.emu_validate(C.byref(orc.default_config(K.HRL_ANT_MAZE))) == b''
@@ -196,6 +201,10 @@ def test_product_defaults_equal_oracle_defaults():
     (K.HRL_ANT_MAZE, 5, dict(target_encoding=1, sense_walls=0, tol=3.0, targ_dist_rew=1, max_steps=20, done_at_target=0)),
     (K.HRL_ANT_MAZE_MJ, 4, dict(inner_rew_weight=0.5, n_bins=6)),
     (K.HRL_ANT_GATHER, 3, dict(model_solver_iters=2, model_frame_skip=2, model_limit_margin=0.1)),
+    (K.HRL_ANT_GATHER, 6, dict(model_self_collision=0, model_item_collision=0)),
+    (K.HRL_ANT_GATHER, 6, dict(robot_coll_dist=0.0)),
+    (K.HRL_POINT_GATHER, 6, dict(robot_coll_dist=-1.0, respawn=0)),
+    (K.HRL_ANT_MAZE, 5, dict(inner_rew_weight=1.0)),
     (K.HRL_ANT_FLAGRUN, 7, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
 ])
 def test_non_default_configs_bit_exact(kind, n, kw):
@@ -208,6 +217,167 @@ def test_non_default_configs_bit_exact(kind, n, kw):
         o.step(a); e.step(a)
         for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
             assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, name)
+
+
+def both(cfg, reverse=False):
+    return orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg, reverse=reverse)
+
+
+def same(o, e, tag=''):
+    for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
+        assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (tag, name)
+
+
+@pytest.mark.parametrize('kind', [K.HRL_ANT_GATHER, K.HRL_POINT_GATHER])
+def test_item_cubes_collide_and_contact_pickup(kind):
+    """The food / poison cubes are static boxes (food.xml:12,19): robots parked on top of / next to cubes are pushed by
+    them, and with robot_coll_dist <= 0 every contact point with a cube pays +-1 and moves it (ant_gather_env.py:113-116).
+    Both lane orders of the wave phases equal the oracle bit for bit."""
+    n = 32
+    for kw in (dict(), dict(robot_coll_dist=0.0)):
+        cfg = orc.default_config(kind, num_envs=n, seed=13, auto_reset=1, **kw)
+        (o, e), er = both(cfg), emu_env.EmuEnv(cfg, reverse=True)
+        o.reset(); e.reset(); er.reset()
+        rng = np.random.RandomState(2)
+        touched = paid = 0
+        for t in range(30):
+            k = rng.randint(0, 16, n)
+            off = rng.uniform(-1.0, 1.0, (n, 2)).astype(np.float32) * (1.4 if kind == K.HRL_ANT_GATHER else 0.45)
+            if kw:  # contact mode: nothing is picked up by distance, so stand right next to / on the cube
+                xy = o.items.reshape(n, 16, 2)[np.arange(n), k] + off
+                for env in (o, e, er):
+                    env.state[:, 0:2] = xy
+            a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+            it0 = o.items.copy()
+            o.step(a); e.step(a); er.step(a)
+            same(o, e, t); same(e, er, (t, 'lane order'))
+            paid += int((o.info[:, 0] != 0).sum()); touched += int(np.any(o.items != it0, axis=1).sum())
+        if kw:
+            assert paid > 20 and touched > 20, (paid, touched)
+    # the cubes matter to the physics: the same rollout without them diverges
+    c1 = orc.default_config(kind, num_envs=n, seed=13, robot_coll_dist=0.0)
+    c0 = orc.default_config(kind, num_envs=n, seed=13, robot_coll_dist=4.0, respawn=0, model_item_collision=0)
+    o1, o0 = orc.OracleEnv(c1, np.float32), orc.OracleEnv(c0, np.float32)
+    o1.reset(); o0.reset()
+    # ant: the torso over the cube; point bot: one of its bottom corners over the cube (its contact points are the 8 corners)
+    xy = o1.items.reshape(n, 16, 2)[:, 3] + np.float32(0.05 if kind == K.HRL_ANT_GATHER else 0.33)
+    o1.state[:, 0:2] = xy; o0.state[:, 0:2] = xy; o0.items[...] = o1.items
+    if kind == K.HRL_ANT_GATHER:
+        o1.state[:, 2] = 0.4; o0.state[:, 2] = 0.4  # torso low enough to sit on the 0.225 m high cube
+    a = np.zeros((n, o1.ad), np.float32) + np.float32(0.3)
+    o1.step(a); o0.step(a)
+    assert np.abs(o1.state[:, :15] - o0.state[:, :15]).max() > 1e-3
+
+
+def test_self_collision_rows_bit_exact_and_keep_legs_apart():
+    """Hips forced far beyond their +-40 degree range so that capsules of different legs meet (within the range they
+    cannot: step_core.h broad phase): the two-body rows of the wave phases equal the oracle's bit for bit in both lane
+    orders, and the contacts push the legs apart again (with self-collision off they stay interpenetrated longer)."""
+    import ctypes as C
+    n = 48
+    cfg = orc.default_config(K.HRL_ANT_FLAT, num_envs=n, seed=5, auto_reset=0)
+    (o, e), er = both(cfg), emu_env.EmuEnv(cfg, reverse=True)
+    o.reset(); e.reset(); er.reset()
+    rng = np.random.RandomState(1)
+    seen = 0
+    for t in range(25):
+        if t % 5 == 0:
+            hips = rng.uniform(-1.5, 1.5, (n, 4)).astype(np.float32)
+            ank = rng.uniform(-1.8, 1.8, (n, 4)).astype(np.float32)
+            for env in (o, e, er):
+                env.state[:, 2] = 1.5; env.state[:, 7:15:2] = hips; env.state[:, 8:15:2] = ank; env.state[:, 15:29] = 0
+        # how many self contacts does the oracle see in these poses?
+        for i in range(0, n, 8):
+            q = o.state[i, :15].astype(np.float64); u = np.zeros(14); info = np.zeros(3, np.int32); dbg = np.zeros(13, np.int32)
+            orc.lib().orc_ant_substeps_items_f64(C.byref(cfg), orc.ptr(q), orc.ptr(u), orc.ptr(np.zeros(8)), 1, None, 0, orc.ptr(info), orc.ptr(dbg), None)
+            seen += int((dbg[1:] >= 64).sum())
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a); er.step(a)
+        same(o, e, t); same(e, er, (t, 'lane order'))
+    assert seen >= 10, seen  # sampled every 8th env: the rollouts really contain self contacts
+
+
+def test_self_collision_broad_phase_is_exact():
+    """The wave phases skip the 48 capsule pairs while every |hip angle| <= 0.75 rad and |ankle angle| <= 2 rad; the oracle
+    always tests them.  On random poses inside those bounds (any torso orientation) the oracle never finds a pair within
+    reach; just outside the ankle bound it does (a foot folded back over the torso)."""
+    import ctypes as C
+    cfg = orc.default_config(K.HRL_ANT_FLAT)
+    rng = np.random.RandomState(8)
+    for i in range(4000):
+        q = np.zeros(15); q[2] = 5.0
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(-3.1, 3.1)
+        q[3:6], q[6] = ax * np.sin(ang / 2), np.cos(ang / 2)
+        q[7::2] = rng.choice([-0.75, 0.75, 0.0], 4) if i % 3 == 0 else rng.uniform(-0.75, 0.75, 4)
+        q[8::2] = rng.choice([-2.0, 2.0], 4) if i % 5 == 0 else rng.uniform(-2.0, 2.0, 4)
+        info = np.zeros(3, np.int32); dbg = np.zeros(13, np.int32)
+        orc.lib().orc_ant_substeps_items_f64(C.byref(cfg), orc.ptr(q), orc.ptr(np.zeros(14)), orc.ptr(np.zeros(8)), 1, None, 0, orc.ptr(info), orc.ptr(dbg), None)
+        assert dbg[0] == 0 and info[2] == 0, (i, q[7:], dbg)
+    found = 0
+    for i in range(300):  # outside the ankle bound a foot can fold back over the torso onto another leg
+        q = np.zeros(15); q[2] = 5.0; q[6] = 1
+        q[7::2] = rng.uniform(-0.75, 0.75, 4); q[8::2] = rng.uniform(2.2, 3.1, 4) * rng.choice([-1, 1], 4)
+        orc.lib().orc_ant_substeps_items_f64(C.byref(cfg), orc.ptr(q), orc.ptr(np.zeros(14)), orc.ptr(np.zeros(8)), 1, None, 0, orc.ptr(info), orc.ptr(dbg), None)
+        found += int(dbg[0] > 0)
+    assert found > 0
+
+
+def test_flagrun_manual_goals():
+    """manual_goal_creation (ant_flagrun_env.py:24,149-152): reset draws no goal, goals come through hrl_set_goals
+    (emu_set_goals here), are visited in the given order and the episode ends when they run out."""
+    import ctypes as C
+    n, G = 8, 3
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=6, auto_reset=0, flag_manual_goals=1, flag_max_targets=0, flag_timeout=0)
+    o, e = both(cfg)
+    o.reset(); e.reset()
+    same(o, e, 'reset')
+    assert np.all(o.items[:, 0] == 1000) and np.all(o.items[:, 1:] == 0) and np.all(o.aux[:, 3] == 0)  # upstream default walk target
+    goals = np.random.RandomState(0).uniform(-4, 4, (n, G, 2)).astype(np.float32)
+    orc.lib().orc_set_goals_batch_f32(C.byref(cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(goals), G, None, orc.ptr(o.obs))
+    b = e._bufs()
+    assert emu_env.lib().emu_set_goals(C.byref(cfg), C.byref(b), orc.ptr(goals), G, None, 0) == 0
+    same(o, e, 'set_goals')
+    assert np.array_equal(o.items[:, 0:2], goals[:, 0]) and np.all((o.aux[:, 3] & 0xffff) == G - 1)
+    rng = np.random.RandomState(1)
+    visited = np.zeros(n, int); done_at = np.full(n, -1)
+    for t in range(12):
+        cur = o.items[:, 0:2].copy()
+        # walk_target_dist is measured from the parts centroid, which holds 13 robot parts and 2 static bodies (SURVEY A.5)
+        xy = ((15 * cur - np.array([-6.0, 0.0], np.float32)) / 13).astype(np.float32)
+        for env in (o, e):
+            env.state[:, 0:2] = xy; env.state[:, 2] = 0.5
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        same(o, e, t)
+        for i in range(n):
+            if done_at[i] < 0:
+                if o.rew[i] > 1000:
+                    visited[i] += 1
+                if visited[i] <= G - 1 and o.rew[i] > 1000 and not o.done[i]:
+                    assert np.array_equal(o.items[i, 0:2], goals[i, visited[i]])  # the next goal in the given order
+                if o.done[i]:
+                    done_at[i] = t
+    assert np.all(visited >= G) and np.all(done_at >= 0)  # all goals reached, then the episode ends for lack of goals
+
+
+def test_reset_potential_is_taken_before_the_target_switch():
+    """ant_flagrun_env.py:116 / ant_maze_bullet_env.py:111: the potential a reset leaves behind belongs to the PREVIOUS
+    target (first episode: upstream's default walk target (1e3, 0)), so the first step's `progress` carries the jump."""
+    dt = np.float32(0.0165 / 4) * 4
+    for kind, kw in ((K.HRL_ANT_FLAGRUN, dict()), (K.HRL_ANT_MAZE, dict(inner_rew_weight=1.0)), (K.HRL_ANT_MAZE_MJ, dict(inner_rew_weight=1.0))):
+        cfg = orc.default_config(kind, num_envs=6, seed=2, auto_reset=0, **kw)
+        o, e = both(cfg)
+        o.reset(); e.reset()
+        same(o, e, 'reset 1')
+        pot1 = o.state[:, 31].copy()
+        assert np.all(np.abs(pot1 * dt + 1000) < 8)   # distance to (1e3, 0) from the start area
+        a = np.zeros((6, 8), np.float32)
+        o.step(a); e.step(a)
+        same(o, e, 'step 1')
+        assert np.all(o.rew > 5e4)                    # the reference's first-step jump (ADVICE r1: ~ +6e4)
+        o.reset(); e.reset()
+        same(o, e, 'reset 2')
+        assert np.all(np.abs(o.state[:, 31] * dt) < 20)  # second episode: against the previous episode's goal / target
 
 
 def test_specified_transcendentals_accuracy_and_agreement():
