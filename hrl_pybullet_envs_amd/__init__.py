@@ -21,10 +21,20 @@ def make(env_id, **kwargs):
     return _REGISTRY[env_id](**kwargs)
 
 
-try:  # pragma: no cover - gym is not installed in the build image
-    import gym
-    for _name, _cls in _REGISTRY.items():
-        gym.envs.register(id=_name.replace('-v0', 'AMD-v0'), entry_point=f'{_cls.__module__}:{_cls.__name__}',
-                          max_episode_steps=2000)
-except Exception:
-    pass
+def register_with(gym_module):
+    """The reference's registration (hrl_pybullet_envs/__init__.py:11-16): the same ids, `<ClassName>-v0`, each with
+    max_episode_steps=2000, so that `gym.make('AntGatherBulletEnv-v0')` of a user script resolves to this package when it
+    is imported in place of hrl_pybullet_envs.  AntMjEnv is importable but, as in the reference (:9), not registered."""
+    ids = []
+    for cls in (AntGatherBulletEnv, AntMazeMjEnv, AntMazeBulletEnv, AntFlagrunBulletEnv, PointGatherBulletEnv):
+        gym_module.envs.register(id=f'{cls.__name__}-v0', entry_point=f'{cls.__module__}:{cls.__name__}', max_episode_steps=2000)
+        ids.append(f'{cls.__name__}-v0')
+    return ids
+
+
+try:
+    import gym as _gym
+except ImportError:  # gym is optional (absent in the build image): make() above serves the same ids
+    _gym = None
+if _gym is not None:  # pragma: no cover
+    register_with(_gym)

@@ -1,19 +1,13 @@
 """AntMazeBulletEnv -- mirror of hrl_pybullet_envs/envs/ant_maze/ant_maze_bullet_env.py:17-178 on the HIP step."""
-from enum import Enum
-
 import numpy as np
 
 from ... import _capi as K
 from ... import _lib
+from ...utils import PositionEncoding
 from ..base import BatchedGymEnv
 
 _eval_target = [-2, 4]
 _targets = ([2, -3], [2, 0], [2, 3], _eval_target)  # ant_maze_bullet_env.py:13-14
-
-
-class PositionEncoding(Enum):  # hrl_pybullet_envs/utils.py:66-68
-    normed_vec = 0
-    angle = 1
 
 
 class AntMazeBulletEnv(BatchedGymEnv):

@@ -47,7 +47,7 @@ def _make_box(low, high, shape):
 class BatchedGymEnv:
     """Common machinery; subclasses fill `self._cfg` (hrl_config) from their reference constructor kwargs."""
 
-    metadata = {'render.modes': []}
+    metadata = {'render.modes': ['rgb_array']}
     reward_range = (-float('inf'), float('inf'))
     max_episode_steps = 2000  # hrl_pybullet_envs/__init__.py:15
 
@@ -92,12 +92,14 @@ class BatchedGymEnv:
         if self.num_envs == 1:
             act = torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(1, -1), device=env.device)
             obs, rew, done, info = env.step(act)
-            row = env.info[0].cpu().numpy()
-            d = bool(done[0].item())
-            out = {'food_rew': float(row[0]), 'dead_rew': float(row[1])} if self._gather_info else {}
-            if d and env.aux[0, 0].item() >= self.max_episode_steps > 0:
+            # one device-side gather + ONE host copy per step: obs | reward | done | info row | episode step
+            row = torch.cat([obs[0], rew[:1], done[:1].to(torch.float32), env.info[0], env.aux[0, :1].to(torch.float32)]).cpu().numpy()
+            od = obs.shape[1]
+            d = bool(row[od + 1] != 0)
+            out = {'food_rew': float(row[od + 2]), 'dead_rew': float(row[od + 3])} if self._gather_info else {}
+            if d and int(row[od + 6]) >= self.max_episode_steps > 0:
                 out['TimeLimit.truncated'] = True
-            return obs[0].double().cpu().numpy(), float(rew[0].item()), d, out
+            return row[:od].astype(np.float64), float(row[od]), d, out
         return env.step(a)
 
     def close(self):
@@ -105,8 +107,17 @@ class BatchedGymEnv:
             self._env.close()
             self._env = None
 
-    def render(self, mode='human'):
-        raise NotImplementedError('rendering is out of scope (SURVEY.md section 2, row 15)')
+    def render(self, mode='human', index=0, size=256):
+        """`rgb_array`: a top-down picture of env `index` (arena, walls, maze box, food green / poison red, the robot),
+        drawn on the host from the state record -- a debugging aid.  The reference renders through
+        pybullet's GUI / camera (upstream MJCFBaseBulletEnv.render); `human` mode has no window here and returns None."""
+        if mode != 'rgb_array':
+            return None
+        from .render import draw_env
+        env = self._backend()
+        st = env.state[index].cpu().numpy()
+        items = env.items[index].cpu().numpy() if self._gather_info else None
+        return draw_env(self._cfg, st, items, size)
 
     _gather_info = False
 

@@ -2,16 +2,11 @@
 (+ gather_base.py:11-191, point_bot.py:10-74) on the HIP step."""
 import numpy as np
 
-from ... import _capi as K
-from ... import _lib
-from ..base import BatchedGymEnv
+from .gather_base import GatherBulletEnv
+from .point_bot import PointBot
 
 
-class PointGatherBulletEnv(BatchedGymEnv):
-    FOOD = 'food'
-    POISON = 'poison'
-    _gather_info = True
-
+class PointGatherBulletEnv(GatherBulletEnv):
     def __init__(self,
                  n_food=8,
                  n_poison=8,
@@ -27,13 +22,7 @@ class PointGatherBulletEnv(BatchedGymEnv):
                  respawn=True,
                  debug=False,
                  num_envs=1, device='cuda:0', seed=None):
-        cfg = _lib.default_config(K.HRL_POINT_GATHER, n_food=int(n_food), n_poison=int(n_poison),
-                                  world_size=tuple(float(w) for w in world_size), n_bins=int(n_bins),
-                                  sensor_range=float(sensor_range), sensor_span=float(sensor_span),
-                                  robot_coll_dist=float(robot_coll_dist), robot_object_spacing=float(robot_object_spacing),
-                                  dying_cost=float(dying_cost), use_sensor=int(bool(use_sensor)), respawn=int(bool(respawn)))
-        self.n_bins, self.sensor_span, self.sensor_range = n_bins, sensor_span, sensor_range
-        self.use_sensor, self.dying_cost, self.robot_coll_dist = use_sensor, dying_cost, robot_coll_dist
-        self.n_food, self.n_poison, self.world_size = n_food, n_poison, world_size
-        self.spacing, self.respawn, self.debug = robot_object_spacing, respawn, debug
-        self._finish_init(cfg, num_envs, device, seed)
+        self.robot = PointBot()
+        super().__init__(self.robot, n_food, n_poison, world_size, n_bins, sensor_range, sensor_span, robot_coll_dist,
+                         robot_object_spacing, dying_cost, render, use_sensor, respawn, debug,
+                         num_envs=num_envs, device=device, seed=seed)

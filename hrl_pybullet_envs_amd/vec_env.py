@@ -75,6 +75,18 @@ class BatchedEnv:
                 'episode_length': self.info[:, 3]}
         return self.obs, self.reward, self.done, info
 
+    def set_goals(self, goals, mask=None):
+        """AntFlagrun with flag_manual_goals: goals float32 [N, n_goals, 2] on this device (include/hrl_envs.h: hrl_set_goals)."""
+        goals = goals.to(device=self.device, dtype=torch.float32).contiguous()
+        if goals.dim() != 3 or goals.shape[0] != self.num_envs or goals.shape[2] != 2:
+            raise ValueError(f'goals must be [num_envs={self.num_envs}, n_goals, 2], got {tuple(goals.shape)}')
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hrl_set_goals(self._h, C.byref(self._bufs), goals.data_ptr(), int(goals.shape[1]),
+                                                None if m is None else m.data_ptr(), self._stream()))
+        self._last_goals = goals  # keep alive until the stream has consumed it
+        return self.obs
+
     # state access (identical-state parity tests)
     @property
     def qpos(self):

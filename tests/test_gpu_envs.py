@@ -136,3 +136,46 @@ def test_bench_starts_two_ranks_from_a_bare_shell():
                        '--gather-every', '10', '--no-cpu-baseline'])
     assert out['n_gpus'] == 2 and out['config']['global_envs'] == 1024 and out['scaling'] == 'weak'
     assert out['config']['returns_gathered_ok'] is True and out['value'] > 0
+
+
+def test_gymnasium_adapter_on_a_real_batched_env():
+    """The 5-tuple adapter on the real thing: a batched PointGather env whose time limit (5 steps) truncates every env."""
+    import hrl_pybullet_envs_amd as H
+    from hrl_pybullet_envs_amd.adapters import GymnasiumAdapter
+    env = H.PointGatherBulletEnv(num_envs=64, seed=2)
+    env.max_episode_steps = 5
+    env._cfg.max_episode_steps = 5
+    g = GymnasiumAdapter(env)
+    obs, info = g.reset(seed=4)
+    assert obs.shape == (64, 18) and info == {} and env._cfg.seed == 4
+    for t in range(5):
+        obs, rew, term, trunc, info = g.step(torch.rand(64, 2, device='cuda') * 2 - 1)
+        assert obs.shape == (64, 18) and rew.shape == (64,) and term.dtype == torch.bool and trunc.dtype == torch.bool
+        assert not bool(term.any())  # the point bot cannot die (point_bot.py:73-74)
+        assert bool(trunc.all()) == (t == 4)
+    g.close()
+    one = GymnasiumAdapter(H.AntGatherBulletEnv(seed=1))
+    obs, _ = one.reset()
+    obs, rew, term, trunc, info = one.step(np.zeros(8))
+    assert obs.shape == (46,) and isinstance(rew, float) and term is False and trunc is False and 'food_rew' in info
+    one.close()
+
+
+def test_flagrun_manual_goal_creation_class_api_and_render():
+    import hrl_pybullet_envs_amd as H
+    env = H.AntFlagrunBulletEnv(manual_goal_creation=True, seed=3)
+    env.reset()
+    assert env.goal == (1000.0, 0.0)                      # upstream's default walk target until goals are pushed
+    ob = env.set_goals([[1.0, 2.0], [-2.0, 0.5]])
+    assert ob.shape == (28,) and env.goal == (1.0, 2.0)
+    ob, rew, done, info = env.step(np.zeros(8))
+    assert ob.shape == (28,) and not done
+    img = env.render('rgb_array')
+    assert img.shape == (256, 256, 3) and img.dtype == np.uint8 and (img != 255).any()
+    assert env.render('human') is None
+    env.close()
+    b = H.AntFlagrunBulletEnv(manual_goal_creation=True, num_envs=32, seed=3)
+    b.reset()
+    ob = b.set_goals(torch.rand(32, 3, 2) * 4 - 2)
+    assert ob.shape == (32, 28) and ob.is_cuda and b.goal.shape == (32, 2)
+    b.close()

@@ -273,6 +273,11 @@ CONFIG_MATRIX = [
     (K.HRL_ANT_FLAGRUN, 21, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
     (K.HRL_ANT_FLAT, 1, dict()),
     (K.HRL_ANT_GATHER, 3, dict(model_solver_iters=2, model_frame_skip=2, model_limit_margin=0.1)),
+    (K.HRL_ANT_GATHER, 40, dict(model_self_collision=0, model_item_collision=0)),
+    (K.HRL_ANT_GATHER, 70, dict(robot_coll_dist=0.0)),
+    (K.HRL_POINT_GATHER, 45, dict(robot_coll_dist=-1.0, respawn=0)),
+    (K.HRL_ANT_MAZE, 33, dict(inner_rew_weight=1.0)),
+    (K.HRL_ANT_MAZE_MJ, 17, dict(inner_rew_weight=1.0)),
 ]
 
 
@@ -292,3 +297,82 @@ def test_non_default_configs_match_oracle(kind, n, kw):
         flips += int(obs_bad_rows(go.cpu().numpy(), o.obs).sum())
     assert flips == 0
     assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux)
+
+
+@pytest.mark.parametrize('kind', [K.HRL_ANT_GATHER, K.HRL_POINT_GATHER])
+def test_contact_pickup_on_item_cubes(kind):
+    """robot_coll_dist <= 0 (ant_gather_env.py:113-116): robots teleported onto / next to cubes touch them, are paid +-1 per
+    contact point and the cube moves; device == oracle bit for bit (identical inputs every step)."""
+    n = 256
+    g, o = make(kind, n, seed=13, robot_coll_dist=0.0)
+    g.reset(); o.reset()
+    rng = np.random.RandomState(2)
+    paid = 0
+    for t in range(25):
+        k = rng.randint(0, 16, n)
+        off = rng.uniform(-1.0, 1.0, (n, 2)).astype(np.float32) * (1.4 if kind == K.HRL_ANT_GATHER else 0.45)
+        o.state[:, 0:2] = o.items.reshape(n, 16, 2)[np.arange(n), k] + off
+        push(g, o)
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(g.items.cpu().numpy(), o.items), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(g.info.cpu().numpy(), o.info) and np.array_equal(gd.cpu().numpy(), o.done), t
+        fin = np.isfinite(o.obs).all(axis=1)
+        assert obs_bad_rows(go.cpu().numpy()[fin], o.obs[fin]).sum() == 0
+        paid += int((o.info[:, 0] != 0).sum())
+    assert paid > 150, paid
+
+
+def test_self_collision_rows_on_device():
+    """Hips forced beyond their range so that capsules of different legs meet: the two-body rows (second impulse response,
+    10-term row products) on the device equal the oracle's bit for bit."""
+    import ctypes as C
+    n = 256
+    g, o = make(K.HRL_ANT_FLAT, n, seed=5)
+    g.reset(); o.reset()
+    rng = np.random.RandomState(1)
+    seen = 0
+    for t in range(20):
+        if t % 5 == 0:
+            o.state[:, 2] = 1.5; o.state[:, 15:29] = 0
+            o.state[:, 7:15:2] = rng.uniform(-1.5, 1.5, (n, 4)).astype(np.float32)
+            o.state[:, 8:15:2] = rng.uniform(-1.8, 1.8, (n, 4)).astype(np.float32)
+            for i in range(0, n, 16):
+                q = o.state[i, :15].astype(np.float64); info = np.zeros(3, np.int32); dbg = np.zeros(13, np.int32)
+                orc.lib().orc_ant_substeps_items_f64(C.byref(o.cfg), orc.ptr(q), orc.ptr(np.zeros(14)), orc.ptr(np.zeros(8)), 1, None, 0, orc.ptr(info), orc.ptr(dbg), None)
+                seen += int((dbg[1:] >= 64).sum())
+        push(g, o)
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
+    assert seen >= 10, seen
+
+
+def test_flagrun_manual_goals_through_the_c_abi():
+    """hrl_set_goals (manual_goal_creation, ant_flagrun_env.py:91-118): goals visited in order, episode over when they run out."""
+    import ctypes as C
+    n, G = 64, 4
+    g, o = make(K.HRL_ANT_FLAGRUN, n, seed=6, flag_manual_goals=1, flag_max_targets=0, flag_timeout=0)
+    g.cfg.auto_reset = 0
+    g.reset(); o.reset()
+    assert np.array_equal(g.items.cpu().numpy(), o.items)
+    goals = np.random.RandomState(0).uniform(-4, 4, (n, G, 2)).astype(np.float32)
+    mask = np.ones(n, np.uint8); mask[::7] = 0
+    gobs = g.set_goals(torch.from_numpy(goals).cuda(), torch.from_numpy(mask).cuda())
+    orc.lib().orc_set_goals_batch_f32(C.byref(o.cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(goals), G, orc.ptr(mask), orc.ptr(o.obs))
+    assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux)
+    assert obs_bad_rows(gobs.cpu().numpy(), o.obs).sum() == 0
+    rng = np.random.RandomState(1)
+    for t in range(10):
+        o.state[:, 0:2] = ((15 * o.items[:, 0:2] - np.array([-6.0, 0.0], np.float32)) / 13).astype(np.float32)
+        o.state[:, 2] = 0.5
+        push(g, o)
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
+    from hrl_pybullet_envs_amd import _lib
+    bad, _ = make(K.HRL_ANT_FLAGRUN, 4)
+    with pytest.raises(_lib.HrlError, match='manual'):
+        bad.set_goals(torch.zeros(4, 2, 2).cuda())

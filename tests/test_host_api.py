@@ -180,3 +180,55 @@ def test_default_config_rejects_unknown_fields():
         _lib.default_config(K.HRL_ANT_GATHER, n_foods=3)
     with pytest.raises(TypeError):
         _lib.default_config(K.HRL_ANT_GATHER, model_gravty=3.0)
+
+
+def test_mirrored_module_paths_and_reference_ids():
+    """same names and module paths under ...envs as the reference, same registered ids (__init__.py:11-16)."""
+    import hrl_pybullet_envs_amd as H
+    from hrl_pybullet_envs_amd.envs.ant_maze.ant_maze_bullet_env import PositionEncoding as PE2
+    from hrl_pybullet_envs_amd.envs.gather.gather_base import GatherBulletEnv
+    from hrl_pybullet_envs_amd.envs.gather.point_bot import PointBot
+    from hrl_pybullet_envs_amd.utils import PositionEncoding
+    assert PositionEncoding is PE2 and PositionEncoding.angle.value == 1 and PositionEncoding(0) is PositionEncoding.normed_vec  # utils.py:66-68
+    bot = PointBot()
+    assert bot.start_pos == [0, 0, 0.5] and bot.initial_z == 1 and bot.action_space.shape == (2,) and bot.observation_space.shape == (8,)
+    g = GatherBulletEnv(bot, n_bins=7)                                # gather_base.py:14-28: the robot comes first, n_bins defaults to 5
+    assert g.observation_space.shape == (8 + 14,) and GatherBulletEnv(bot).observation_space.shape == (18,)
+    assert issubclass(H.PointGatherBulletEnv, GatherBulletEnv) and isinstance(H.PointGatherBulletEnv().robot, PointBot)  # point_gather_env.py:7-24
+    with pytest.raises(TypeError):
+        GatherBulletEnv(object())
+
+    class FakeGym:
+        class envs:
+            calls = []
+
+            @staticmethod
+            def register(**kw):
+                FakeGym.envs.calls.append(kw)
+    ids = H.register_with(FakeGym)
+    assert ids == ['AntGatherBulletEnv-v0', 'AntMazeMjEnv-v0', 'AntMazeBulletEnv-v0', 'AntFlagrunBulletEnv-v0', 'PointGatherBulletEnv-v0']
+    assert all(c['max_episode_steps'] == 2000 for c in FakeGym.envs.calls)
+    mod, cls = FakeGym.envs.calls[0]['entry_point'].split(':')
+    import importlib
+    assert getattr(importlib.import_module(mod), cls) is H.AntGatherBulletEnv
+    # contact-based pickup and manual goals are constructor options now, as in the reference
+    assert H.AntGatherBulletEnv(robot_coll_dist=0)._cfg.robot_coll_dist == 0.0
+    f = H.AntFlagrunBulletEnv(manual_goal_creation=True)
+    assert f._cfg.flag_manual_goals == 1
+    with pytest.raises(RuntimeError):
+        H.AntFlagrunBulletEnv().set_goals([[1, 1]])
+
+
+def test_rgb_array_render_draws_the_scene():
+    import hrl_pybullet_envs_amd as H
+    from hrl_pybullet_envs_amd.envs.render import ant_points, draw_env
+    st = np.zeros(32, np.float32); st[2] = 0.75; st[6] = 1; st[7:15] = [0, 1, 0, -1, 0, -1, 0, 1]
+    items = np.random.RandomState(0).uniform(-7, 7, 32).astype(np.float32)
+    img = draw_env(H.AntGatherBulletEnv()._cfg, st, items, 200)
+    assert img.shape == (200, 200, 3) and img.dtype == np.uint8
+    assert (img == (0, 170, 0)).all(axis=2).any() and (img == (210, 0, 0)).all(axis=2).any() and (img == (0, 50, 200)).all(axis=2).any()
+    p0, legs = ant_points(st[:15])
+    assert np.allclose(legs[0][0], [0.2, 0.2, 0.75]) and np.allclose(legs[0][1], [0.4, 0.4, 0.75])  # ant.xml:17-20
+    assert abs(np.linalg.norm(legs[0][2] - legs[0][1]) - 0.4 * np.sqrt(2)) < 1e-6  # the float32 quaternion is not exactly unit
+    assert draw_env(H.AntMazeBulletEnv()._cfg, st, None, 64).shape == (64, 64, 3)
+    assert draw_env(H.PointGatherBulletEnv()._cfg, st, items, 64).shape == (64, 64, 3)
