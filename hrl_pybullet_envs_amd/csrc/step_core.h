@@ -1388,7 +1388,7 @@ HRL_DEV void respawn_item(const DevCfg &c, long long env, uint32_t index, uint32
 /* Phase O2 (item map): pickup + respawn (ant_gather_env.py:84-92, gather_scene.py:95-114) and the item's sensor
  * contribution (ant_gather_env.py:145-162).  robot_coll_dist <= 0 (:113-116): +-1 per contact point between the robot and
  * the item's cube among the `n_contacts` contacts of the step's last collision pass (L.csurf), the observation is taken
- * BEFORE such an item is moved (:95-96 precede :113), and it is moved once. */
+ * BEFORE such an item is moved (:95-96 precede :113). */
 HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, bool pickups, int n_contacts) {
     const int n = c.n_food + c.n_poison;
     if (lane >= 16) return;
@@ -1419,7 +1419,9 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
             for (int i = 0; i < n_contacts; ++i) hits += L.csurf[i] == SURF_ITEM + lane ? 1 : 0;
             if (hits > 0) {
                 rew = (lane < c.n_food ? 1.f : -1.f) * (float)hits;
-                if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane, rx, ry, &ix, &iy);
+                /* the reference moves the item once per contact point (gather_scene.py:95-114); the moves are independent
+                 * draws, keyed item | move << 4, so the last one is where it ends up */
+                if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane | ((hits - 1) << 4), rx, ry, &ix, &iy);
                 else { ix = 100.f; iy = 0.f; }
                 L.items[2 * lane] = ix; L.items[2 * lane + 1] = iy;
             }

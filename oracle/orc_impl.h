@@ -396,21 +396,22 @@ int FN(orc_gather_task_src)(const hrl_config *cfg, int ant, const REAL *base_sta
     if (alive_z > 0) alive = (obs[0] + initial_z > alive_z) ? R_(1) : R_(-1); /* :99 + upstream Ant.alive_bonus */
     int d = alive < 0;                                                         /* :100 */
     for (int i = 0; i < no; ++i) if (!isfinite(obs[i])) d = 1;                 /* :101-103 */
-    if (!(cfg->robot_coll_dist > 0)) { /* :113-116: one reward_collision() per contact point, in contact order.  An item touched
-                                         * by k contact points pays k times and is moved k times; the position it ends up at is
-                                         * one more independent draw of the same distribution, so it is drawn once here. */
-        int moved[HRL_MAX_ITEMS] = {0};
+    if (!(cfg->robot_coll_dist > 0)) { /* :113-116: one reward_collision() per contact point, in contact order: an item touched
+                                         * by k contact points pays k times and is moved k times (gather_scene.py:95-114 does
+                                         * not look at where the item is).  Move m of item i draws from the source under the
+                                         * key i | m << 4; every move is independent of the previous one, so where the item ends
+                                         * up is its LAST move (what the device computes directly). */
+        int hits[HRL_MAX_ITEMS] = {0};
         for (int c = 0; c < n_contacts; ++c) {
             int i = contact_items[c];
             if (i < 0 || i >= n) continue; /* not an item: reward_collision returns 0 */
             food_reward += (i < nf) ? 1 : -1;
-            if (moved[i]) continue;
-            moved[i] = 1;
             if (cfg->respawn) {
-                int k = FN(random_on_plane_src)(ws, torso_xyz, R_(cfg->robot_object_spacing), draw, ctx, i, max_attempts, items_xy + 2 * i);
+                int k = FN(random_on_plane_src)(ws, torso_xyz, R_(cfg->robot_object_spacing), draw, ctx, i | (hits[i] << 4), max_attempts, items_xy + 2 * i);
                 if (k < 0) return -1;
                 used += k;
             } else { items_xy[2 * i] = 100; items_xy[2 * i + 1] = 0; }
+            ++hits[i];
         }
     }
     REAL dead_rew = alive < 0 ? R_(cfg->dying_cost) : 0;                       /* :118 */

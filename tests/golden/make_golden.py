@@ -54,10 +54,28 @@ def install_stubs():
             pass
 
     class AntBulletEnv(_Empty):
-        """Stand-in base: step() returns whatever the test parked on the instance."""
+        """Stand-in base: step() returns whatever the test parked on the instance.
+
+        With `_bookkeeping` set on the instance (the reset-sequence fixtures only) reset()/step() restate, from memory of
+        upstream WalkerBaseBulletEnv (unverified), the ORDER in which it touches `potential`:
+        reset: robot back to its home pose -> calc_state -> potential = calc_potential();
+        step: calc_state -> potential_old = potential; potential = calc_potential(); reward = alive(+1) + progress.
+        The fixtures generated this way pin the order of operations of the IN-TREE reset()/next_target()/step() around
+        those calls (which target a potential belongs to), not upstream arithmetic."""
+
+        def reset(self):
+            self.robot._pos = list(self.robot._home)
+            s = self.robot.calc_state()
+            self.potential = self.robot.calc_potential()
+            return s
 
         def step(self, a):
-            return self._super_step_result
+            if not getattr(self, '_bookkeeping', False):
+                return self._super_step_result
+            s = self.robot.calc_state()
+            potential_old = self.potential
+            self.potential = self.robot.calc_potential()
+            return s, 1.0 + float(self.potential - potential_old), False, {}
 
     class WalkerBaseMuJoCoEnv(_Empty):
         def HUD(self, *a):
@@ -581,7 +599,148 @@ def main():
                    'target_after': [float(self.walk_target_x), float(self.walk_target_y)]})
     G['flagrun_close_step'] = fc
 
+    # ---------------------------------------------------------------- contact-based pickup (robot_coll_dist <= 0):
+    # ant_gather_env.py:113-116 / gather_base.py:103-106 with scripted getContactPoints() results
+    def contact_step_case(cls, k):
+        lrs = np.random.RandomState(17000 + k)
+        n_bins = 10 if cls is AntGatherBulletEnv else 5
+        respawn = k % 5 != 0
+        sc = GatherScene(None, 9.8, 0.0165 / 4, 4, (15, 15), 8, 8, 2.0, respawn)
+        sc.rs = LoggingRS(17500 + k)
+        sc.loaded = True
+        cl = FakeClient()
+        sc._p = cl
+        sc.episode_restart(cl)
+        n_restart = len(sc.rs.log)
+        items0 = [list(sc.all_items[i]) for i in sc.all_items]
+        ids = list(sc.all_items.keys())
+        xy = lrs.uniform(-6, 6, 2)
+        z = lrs.uniform(0.3, 0.9)
+        rpy = [lrs.uniform(-.3, .3), lrs.uniform(-.3, .3), lrs.uniform(-np.pi, np.pi)]
+        body = Body([xy[0], xy[1], z], rpy)
+        nstate = 28 if cls is AntGatherBulletEnv else 8
+        st = lrs.uniform(-1, 1, nstate)
+        initial_z = 0.75 if cls is AntGatherBulletEnv else 1.0
+        st[0] = z - initial_z
+        st = st.astype(np.float32)
+        # contact points of the robot: ground (id 3), a wall (id 4) and items, some of them several times
+        n_cp = int(lrs.randint(0, 9))
+        touched = [int(lrs.choice([3, 4] + ids[:6] + ids[8:12])) for _ in range(n_cp)]
+        cl.getContactPoints = lambda body_id: [(0, body_id, oid, -1, -1) for oid in touched]
+        if cls is AntGatherBulletEnv:
+            robot = NS(apply_action=lambda a: None, calc_state=lambda: st.copy(), initial_z=initial_z, objects=[1],
+                       body_rpy=rpy, alive_bonus=lambda zz, p: +1 if zz > 0.26 else -1)
+            self = cls.__new__(cls)
+            self.__dict__.update(dict(robot=robot, scene=NS(global_step=lambda: None), stadium_scene=sc,
+                                      parts={'torso': body}, robot_body=body, robot_coll_dist=0, use_sensor=True,
+                                      n_bins=n_bins, sensor_span=np.pi, sensor_range=20., dying_cost=-10,
+                                      debug=False, _p=cl))
+        else:
+            robot = NS(apply_action=lambda a: None, calc_state=lambda: st.copy(), initial_z=initial_z, objects=[1],
+                       robot_body=body, alive_bonus=lambda zz, p: 1)
+            self = cls.__new__(cls)
+            self.__dict__.update(dict(robot=robot, scene=NS(global_step=lambda: None), stadium_scene=sc,
+                                      robot_coll_dist=-1, use_sensor=True, n_bins=n_bins, sensor_span=np.pi,
+                                      sensor_range=20., dying_cost=-10, debug=False, _p=cl))
+        obs, rew, done, info = cls.step(self, np.zeros(8))
+        return {'cls': cls.__name__, 'n_bins': n_bins, 'respawn': respawn, 'state_in': st.astype(float).tolist(), 'initial_z': initial_z,
+                'torso_xyz': [float(xy[0]), float(xy[1]), float(z)], 'rpy': list(map(float, rpy)),
+                'items_before': [p[:2] for p in items0], 'respawn_draws': sc.rs.log[n_restart:],
+                'contact_items': [ids.index(o) if o in ids else -1 for o in touched],
+                'items_after': [list(sc.all_items[i])[:2] for i in sc.all_items],
+                'obs': tolist(obs), 'rew': float(rew), 'done': bool(done), 'food_rew': float(info['food_rew']),
+                'dead_rew': float(info['dead_rew'])}
+
+    G['gather_contact_step'] = [contact_step_case(AntGatherBulletEnv, k) for k in range(40)] + \
+        [contact_step_case(GatherBulletEnv, 100 + k) for k in range(20)]
+
+    # ---------------------------------------------------------------- which target the potential of a reset belongs to
+    # AntFlagrunBulletEnv.reset / next_target (ant_flagrun_env.py:110-155) and AntMazeBulletEnv.reset
+    # (ant_maze_bullet_env.py:104-121) run IN-TREE around the stand-in bookkeeping of AntBulletEnv above.
+    DT = 0.0165
+
+    class SeqRobot:
+        """Duck-typed walker: walk_target_dist is measured from the body position (stand-in for upstream's parts centroid)."""
+
+        def __init__(self, home):
+            self._home, self._pos = list(home), list(home)
+            self.walk_target_x, self.walk_target_y = 1e3, 0.0   # upstream WalkerBase default
+            self.walk_target_dist = 0.0
+            self.objects = [1]
+            self.robot_body = NS(get_position=lambda: np.array(self._pos, dtype=float))
+            self.start_pos_x, self.start_pos_y, self.start_pos_z = -2.0, -5.0, 0.25
+
+        body_real_xyz = property(lambda self: np.array(self._pos, dtype=float))
+
+        def calc_state(self):
+            self.walk_target_dist = float(np.linalg.norm([self.walk_target_y - self._pos[1], self.walk_target_x - self._pos[0]]))
+            return np.array(self._pos, dtype=np.float32)
+
+        def calc_potential(self):
+            return -self.walk_target_dist / DT
+
+        def robot_specific_reset(self, p):
+            pass
+
+    class SeqClient(FakeClient):
+        def __init__(self, robot):
+            super().__init__()
+            self.robot = robot
+
+        def resetBasePositionAndOrientation(self, obj, pos, orn):
+            self.robot._pos = list(pos)
+
+    seq = {'dt': DT, 'flagrun': [], 'maze': []}
+    for k in range(6):
+        lrs = np.random.RandomState(18000 + k)
+        robot = SeqRobot([0.0, 0.0, 0.75])
+        env = AntFlagrunBulletEnv.__new__(AntFlagrunBulletEnv)
+        env.__dict__.update(dict(robot=robot, _p=SeqClient(robot), scene=NS(_p=None), _bookkeeping=True, tol=0.5, timeout=200,
+                                 switch_flag_on_collision=True, max_targets=3, max_target_dist=0, manual_goal_creation=False,
+                                 size=10, mpi_common_rand=np.random.RandomState(18100 + k), goals=[], steps_since_goal_change=0,
+                                 _rewarded=False, debug=False, use_sensor=False, isRender=False, flag=None,
+                                 walk_target_x=1e3, walk_target_y=0.0, _sq_dist_goal=0, _goal_start_pos=np.array([0, 0])))
+        events = []
+        for ep in range(3):
+            AntFlagrunBulletEnv.reset(env)
+            events.append({'op': 'reset', 'pos': list(map(float, robot._pos)), 'target': [float(env.walk_target_x), float(env.walk_target_y)],
+                           'potential': float(env.potential)})
+            for t in range(3):
+                robot._pos = [float(v) for v in (np.array(robot._pos) + np.r_[lrs.uniform(-0.3, 0.3, 2), 0.0])]
+                if t == 1 and ep == 1:  # jump onto the goal: +5000, retarget
+                    robot._pos = [float(env.walk_target_x) + 0.1, float(env.walk_target_y), 0.5]
+                _, r, d, info = AntFlagrunBulletEnv.step(env, np.zeros(8))
+                events.append({'op': 'step', 'pos': list(map(float, robot._pos)), 'target': [float(env.walk_target_x), float(env.walk_target_y)],
+                               'potential': float(env.potential), 'rew': float(r), 'done': bool(d), 'retargeted': 'target' in info})
+        seq['flagrun'].append(events)
+    for k in range(6):
+        lrs = np.random.RandomState(18500 + k)
+        robot = SeqRobot([0.0, 0.0, 0.75])
+        env = AntMazeBulletEnv.__new__(AntMazeBulletEnv)
+        targets = ([2, -3], [2, 0], [2, 3], [-2, 4])
+        maze._p = None  # reset() hands scene._p to robot_specific_reset (a no-op here)
+        env.__dict__.update(dict(robot=robot, _p=SeqClient(robot), scene=maze, _bookkeeping=True, n_bins=10, sensor_range=5.0,
+                                 sensor_span=2 * np.pi, targets=targets, sense_walls=True, sense_target=False, done_at_target=True,
+                                 max_steps=-1, t=0, tol=1.5, inner_rew_weight=1.0, targ_dist_rew=False,
+                                 target_encoding=PositionEncoding(0), debug=0, rs=np.random.RandomState(18600 + k),
+                                 robot_body=NS(pose=lambda: NS(xyz=lambda: np.array(robot._pos, dtype=float), rpy=lambda: [0, 0, 0.3]))))
+        events = []
+        for ep in range(3):
+            AntMazeBulletEnv.reset(env)
+            events.append({'op': 'reset', 'pos': list(map(float, robot._pos)), 'target': list(map(float, env.target)),
+                           'potential': float(env.potential)})
+            for t in range(2):
+                robot._pos = [float(v) for v in (np.array(robot._pos) + np.r_[lrs.uniform(-0.3, 0.3, 2), 0.0])]
+                _, r, d, _ = AntMazeBulletEnv.step(env, np.zeros(8))
+                events.append({'op': 'step', 'pos': list(map(float, robot._pos)), 'target': list(map(float, env.target)),
+                               'potential': float(env.potential), 'rew': float(r), 'done': bool(d)})
+        seq['maze'].append(events)
+    G['reset_potential_seq'] = seq
+
+    only = set(sys.argv[1:])  # optional: names of the fixtures to (re)write; default all
     for name, val in G.items():
+        if only and name not in only:
+            continue
         with open(os.path.join(OUT_DIR, name + '.json'), 'w') as f:
             json.dump(val, f, allow_nan=True)
         print(name, os.path.getsize(os.path.join(OUT_DIR, name + '.json')), 'bytes')

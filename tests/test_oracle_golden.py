@@ -279,3 +279,59 @@ def test_flagrun_close_targets():
             np.testing.assert_allclose(close_target(c, 10.0, 3.0), c['target_after'], atol=1e-12)
     assert n_retarget >= 8
 
+
+
+def test_gather_contact_pickup_step():
+    """robot_coll_dist <= 0 (ant_gather_env.py:113-116, gather_base.py:103-106): one reward_collision() per contact point of
+    the robot, AFTER the observation was assembled; items touched several times are paid and moved several times."""
+    multi = 0
+    for c in load('gather_contact_step'):
+        ant = c['cls'] == 'AntGatherBulletEnv'
+        cfg = orc.default_config(K.HRL_ANT_GATHER if ant else K.HRL_POINT_GATHER, robot_coll_dist=0.0 if ant else -1.0, respawn=int(c['respawn']))
+        st = arr(c['state_in']); items = arr(c['items_before']).copy()
+        draws = arr(c['respawn_draws']).reshape(-1, 2) if c['respawn_draws'] else np.zeros((1, 2))
+        ci = np.asarray(c['contact_items'], np.int32) if c['contact_items'] else np.zeros(1, np.int32)
+        nobs = (26 if ant else 8) + 2 * c['n_bins']
+        obs = np.zeros(nobs); rew = C.c_double(); done = C.c_int(); fr = C.c_double(); dr = C.c_double()
+        used = orc.lib().orc_gather_task_contacts_f64(C.byref(cfg), int(ant), orc.ptr(st), len(st), orc.ptr(arr(c['torso_xyz'])),
+                                                      C.c_double(c['rpy'][2]), C.c_double(c['initial_z']),
+                                                      C.c_double(0.26 if ant else -1.0), orc.ptr(items), orc.ptr(draws),
+                                                      len(c['respawn_draws']), orc.ptr(ci), len(c['contact_items']),
+                                                      orc.ptr(obs), C.byref(rew), C.byref(done), C.byref(fr), C.byref(dr))
+        assert used == len(c['respawn_draws'])
+        np.testing.assert_allclose(items, c['items_after'], atol=1e-12)
+        np.testing.assert_allclose(obs, c['obs'], atol=1e-12, equal_nan=True)  # sensor readings of the OLD item positions
+        assert rew.value == c['rew'] and bool(done.value) == c['done'] and fr.value == c['food_rew'] and dr.value == c['dead_rew']
+        hit = [i for i in c['contact_items'] if i >= 0]
+        multi += len(hit) != len(set(hit))
+        assert abs(c['food_rew']) <= len(hit)
+    assert multi > 5  # the fixture really contains items touched by several contact points
+
+
+def test_reset_potential_belongs_to_the_previous_target():
+    """Sequence fixture (reference reset()/next_target()/step() run in-tree around a restated upstream bookkeeping, see
+    make_golden.py): the potential a reset leaves is the distance to the PREVIOUS target -- from the new pose (flagrun,
+    ant_flagrun_env.py:116) or from the robot's home pose (maze, ant_maze_bullet_env.py:111) -- and a retarget inside
+    step() leaves the potential of the old target."""
+    g = load('reset_potential_seq')
+    dt = g['dt']
+    pot = orc.lib().orc_reset_potential_f64
+    pot.restype = C.c_double
+    for name, maze_kind in (('flagrun', 0), ('maze', 1)):
+        for events in g[name]:
+            prev_target, prev = [1e3, 0.0], None  # upstream's default walk target before the first episode
+            for e in events:
+                pos = arr(e['pos'][:2])
+                if e['op'] == 'reset':
+                    v = pot(maze_kind, orc.ptr(arr(prev_target)), orc.ptr(pos), orc.ptr(arr([-2.0, -5.0])), 13, C.c_double(dt))
+                    assert v == pytest.approx(e['potential'], abs=1e-9), (name, e)
+                else:
+                    # step: the new potential is measured against the target in effect BEFORE any retarget of this step
+                    assert e['potential'] == pytest.approx(-np.linalg.norm(pos - arr(prev_target)) / dt, abs=1e-9)
+                    base = 1.0 + (e['potential'] - prev['potential'])
+                    if name == 'flagrun':
+                        reached = np.linalg.norm(pos - arr(prev_target)) < 0.5
+                        assert e['rew'] == pytest.approx(base + (5000 if reached else 0), abs=1e-6) and e['retargeted'] == bool(reached)
+                    else:
+                        assert e['rew'] == pytest.approx(base * 1.0, abs=1e-6)  # inner_rew_weight = 1
+                prev_target, prev = e['target'], e
