@@ -284,10 +284,13 @@ HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
         t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
     }
 }
-/* the three row directions of a contact, computed once by the lane that found it (phase C) for its three rows (R1) */
-HRL_DEV void store_contact_frame(WaveLds &L, int i, const float *n) {
+/* the three row directions of a contact, computed once by the lane that found it (phase C) for its three rows (R1).
+ * up: the normal is exactly (0, 0, 1) (ground pass): tangent_basis then has a = 1 and k = 1 exactly, so its results are
+ * the constants below (signed zeros as the formula produces them) without the square root and the division. */
+HRL_DEV void store_contact_frame(WaveLds &L, int i, const float *n, bool up = false) {
     float t1[3], t2[3];
-    tangent_basis(n, t1, t2);
+    if (up) { t1[0] = 0.f; t1[1] = -1.f; t1[2] = 0.f; t2[0] = 1.f; t2[1] = -0.f; t2[2] = -0.f; }
+    else tangent_basis(n, t1, t2);
 #pragma unroll
     for (int k = 0; k < 3; ++k) L.cdir[0][i][k] = n[k];
 #pragma unroll
@@ -602,8 +605,8 @@ HRL_DEV float sphere_vs_box(const float *p, float rad, const float *lo, const fl
 #pragma unroll
     for (int k = 0; k < 3; ++k) { float cp = clampf(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 = fma_(d[k], d[k], d2); }
     if (d2 > 0.f) {
-        float len = sqrtf(d2);
-        n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len;
+        const float len = sqrtf(d2), il = 1.f / len;
+        n[0] = d[0] * il; n[1] = d[1] * il; n[2] = d[2] * il;
         return len - rad;
     }
     if (!(d2 == 0.f)) { n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; return 1e30f; } /* non-finite centre: no contact */
@@ -688,7 +691,7 @@ HRL_DEV Hit capsule_pair(const DevCfg &c, const WaveLds &L, int id) {
     if (h.ok) {
         const float len = sqrtf(d2n);
         h.dist = len - (c.r_caps + c.r_caps);
-        if (len > 0.f) { h.n[0] = dv[0] / len; h.n[1] = dv[1] / len; h.n[2] = dv[2] / len; }
+        if (len > 0.f) { const float il = 1.f / len; h.n[0] = dv[0] * il; h.n[1] = dv[1] * il; h.n[2] = dv[2] * il; }
 #pragma unroll
         for (int t = 0; t < 3; ++t) h.r[t] = 0.5f * (c1[t] + c2[t]);
     }
@@ -848,17 +851,37 @@ HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int 
 /* Phase I (dof map): integrate positions; the joint rates were clamped by the caller.  Lane k < 16 produces element k
  * of the new q: the quaternion (exponential map, every lane computes it) or one fma for a position / joint angle. */
 HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float *qn, int lane) {
-    const float h = c.h;
+    const float h = c.h, hh = 0.5f * h;
     const float u0 = L.u[0], u1 = L.u[1], u2 = L.u[2];
-    float wn = sqrtf(fma_(u2, u2, fma_(u1, u1, u0 * u0))), th = wn * h, dq[4];
-    if (th > 1e-6f) { float sh_, ch_; sincos_spec(0.5f * th, &sh_, &ch_); float s = sh_ / wn; dq[0] = u0 * s; dq[1] = u1 * s; dq[2] = u2 * s; dq[3] = ch_; }
-    else { float s = 0.5f * h; dq[0] = u0 * s; dq[1] = u1 * s; dq[2] = u2 * s; dq[3] = 1.f; }
-    float x = q[3], y = q[4], z = q[5], w = q[6];
-    float nx = fma_(-dq[2], y, fma_(dq[1], z, fma_(dq[0], w, dq[3] * x)));
-    float ny = fma_(dq[2], x, fma_(dq[1], w, fma_(-dq[0], z, dq[3] * y)));
-    float nz = fma_(dq[2], w, fma_(-dq[1], x, fma_(dq[0], y, dq[3] * z)));
-    float nw = fma_(-dq[2], z, fma_(-dq[1], y, fma_(-dq[0], x, dq[3] * w)));
-    float inv = 1.f / sqrtf(fma_(nx, nx, ny * ny) + fma_(nz, nz, nw * nw));
+    /* quaternion increment exp(h omega / 2) = (omega (h/2) sinc(x), cos(x)), x = |omega| h / 2, through z = x^2: while x <= 0.5
+     * (|omega| <= 242 rad/s at the default h) the Taylor polynomials of sinc and cos in z up to z^4 are exact to 3e-10 and need
+     * neither the square root nor the division; beyond that the closed form is used (wave-uniform branch). */
+    const float ww = fma_(u2, u2, fma_(u1, u1, u0 * u0)), z = ww * (hh * hh);
+    const bool small = z <= 0.25f;
+    float dq[4];
+    if (small) {
+        float ps = fma_(z, 2.75573192239858906e-6f, -1.98412698412698413e-4f);
+        ps = fma_(ps, z, 8.33333333333333333e-3f); ps = fma_(ps, z, -1.66666666666666667e-1f); ps = fma_(ps, z, 1.0f);
+        float pc = fma_(z, 2.48015873015873016e-5f, -1.38888888888888889e-3f);
+        pc = fma_(pc, z, 4.16666666666666667e-2f); pc = fma_(pc, z, -0.5f); pc = fma_(pc, z, 1.0f);
+        const float sc = hh * ps;
+        dq[0] = u0 * sc; dq[1] = u1 * sc; dq[2] = u2 * sc; dq[3] = pc;
+    } else {
+        const float wn = sqrtf(ww);
+        float sh_, ch_;
+        sincos_spec(hh * wn, &sh_, &ch_);
+        const float sc = sh_ / wn;
+        dq[0] = u0 * sc; dq[1] = u1 * sc; dq[2] = u2 * sc; dq[3] = ch_;
+    }
+    float x = q[3], y = q[4], zq = q[5], w = q[6];
+    float nx = fma_(-dq[2], y, fma_(dq[1], zq, fma_(dq[0], w, dq[3] * x)));
+    float ny = fma_(dq[2], x, fma_(dq[1], w, fma_(-dq[0], zq, dq[3] * y)));
+    float nz = fma_(dq[2], w, fma_(-dq[1], x, fma_(dq[0], y, dq[3] * zq)));
+    float nw = fma_(-dq[2], zq, fma_(-dq[1], y, fma_(-dq[0], x, dq[3] * w)));
+    /* renormalisation: the product of two unit quaternions is off unit length by rounding only, so one Newton step of
+     * 1/sqrt at 1, (3 - n2) / 2, is exact to (n2 - 1)^2 ~ 1e-14; the closed-form branch keeps the exact 1/sqrt */
+    const float n2 = fma_(nx, nx, ny * ny) + fma_(nz, nz, nw * nw);
+    const float inv = small ? fma_(-0.5f, n2, 1.5f) : 1.f / sqrtf(n2);
     const int k = lane & 15;
     /* position k < 3 advances with the linear velocity u[3 + k], joint angle q[7 + j] with the joint rate u[6 + j] */
     const int ui = k < 3 ? k + 3 : (k >= 7 && k < 15 ? k - 1 : 0);
@@ -970,13 +993,13 @@ HRL_DEV int ant_substep(X &x, const DevCfg &c, int qi, bool items_on) {
         for (int k = 0; k < 3; ++k) { const float cp = clampf(q[k], c.box_lo[k], c.box_hi[k]); d2 += (q[k] - cp) * (q[k] - cp); }
         near_box = d2 < reach * reach;
     }
-    auto keep = [&](int base) {
-        return [&L, base](int, int rank, const Hit &h) {
+    auto keep = [&](int base, bool up = false) {
+        return [&L, base, up](int, int rank, const Hit &h) {
             const int i = base + rank;
             if (i < MAXC) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) L.cr[i][k] = h.r[k];
-                store_contact_frame(L, i, h.n);
+                store_contact_frame(L, i, h.n, up);
                 L.cdist_[i] = h.dist; L.clink[i] = h.link; L.clink2[i] = h.link2; L.csurf[i] = h.surf; L.cmu[i] = h.mu;
             }
         };
@@ -991,7 +1014,7 @@ HRL_DEV int ant_substep(X &x, const DevCfg &c, int qi, bool items_on) {
                 const int fi = lane / 13, sph = lane - 13 * fi;
                 return sphere_vs_surface(c, L, q, fi < nsurf ? sph : -1, f0 + fi, -1);
             },
-            keep(nC),
+            keep(nC, pass == 0),
             [&](int lane, const Hit &h) { if (pass == 0 && lane < 16) L.gtouch[lane] = h.ok ? 1 : 0; });
         nC += cnt;
         if (nC > MAXC) nC = MAXC;
@@ -1203,7 +1226,7 @@ HRL_DEV void quat_to_rpy(const float *qq, float *rpy) {
 /* ant_gather_env.py:148-155: python `%` then fold to (-pi, pi] */
 HRL_DEV float wrap_angle(float a) {
     const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
-    a = fmodf(a, two_pi);
+    if (!(fabsf(a) < two_pi)) a = fmodf(a, two_pi); /* fmod is exact: for |a| < 2 pi it returns a itself */
     if (a < 0.f) a += two_pi;
     if (a >= two_pi) a -= two_pi;
     if (a > pi) a = a - two_pi;

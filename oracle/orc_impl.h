@@ -819,6 +819,41 @@ static void FN(orc_response)(const FN(orc_dyn) * D, const REAL *phi, int level, 
     }
 }
 
+/* Orientation update q <- normalize(exp(h omega / 2) (x) q), omega = u[0..2] in world axes.
+ * exp(h omega / 2) = (omega (h/2) sinc(x), cos(x)) with x = |omega| h / 2, evaluated through z = x^2: while x <= 0.5 the
+ * Taylor polynomials of sinc and cos in z up to z^4 (exact to 3e-10 there) replace the square root, the division and the
+ * sine / cosine; beyond that the closed form.  The product of two unit quaternions is off unit length by rounding only, so
+ * the renormalisation on the polynomial branch is one Newton step of 1/sqrt at 1, (3 - n2) / 2, exact to (n2 - 1)^2;
+ * the closed-form branch divides by the square root.  (The textbook reference uses the closed forms throughout.) */
+static void FN(quat_integrate)(REAL h, REAL *q, const REAL *u) {
+    const REAL hh = R_(0.5) * h;
+    const REAL ww = FMA_(u[2], u[2], FMA_(u[1], u[1], u[0] * u[0])), z = ww * (hh * hh);
+    const int small = z <= R_(0.25);
+    REAL dq[4];
+    if (small) {
+        REAL ps = FMA_(z, R_(2.75573192239858906e-6), R_(-1.98412698412698413e-4));
+        ps = FMA_(ps, z, R_(8.33333333333333333e-3)); ps = FMA_(ps, z, R_(-1.66666666666666667e-1)); ps = FMA_(ps, z, R_(1.0));
+        REAL pc = FMA_(z, R_(2.48015873015873016e-5), R_(-1.38888888888888889e-3));
+        pc = FMA_(pc, z, R_(4.16666666666666667e-2)); pc = FMA_(pc, z, R_(-0.5)); pc = FMA_(pc, z, R_(1.0));
+        const REAL sc = hh * ps;
+        dq[0] = u[0] * sc; dq[1] = u[1] * sc; dq[2] = u[2] * sc; dq[3] = pc;
+    } else {
+        const REAL wn = RSQRT(ww);
+        REAL sh_, ch_;
+        FN(dyn_sincos)(hh * wn, &sh_, &ch_);
+        const REAL sc = sh_ / wn;
+        dq[0] = u[0] * sc; dq[1] = u[1] * sc; dq[2] = u[2] * sc; dq[3] = ch_;
+    }
+    const REAL x = q[3], y = q[4], zq = q[5], w = q[6]; /* q <- dq (x) q */
+    const REAL nx = FMA_(-dq[2], y, FMA_(dq[1], zq, FMA_(dq[0], w, dq[3] * x)));
+    const REAL ny = FMA_(dq[2], x, FMA_(dq[1], w, FMA_(-dq[0], zq, dq[3] * y)));
+    const REAL nz = FMA_(dq[2], w, FMA_(-dq[1], x, FMA_(dq[0], y, dq[3] * zq)));
+    const REAL nw = FMA_(-dq[2], zq, FMA_(-dq[1], y, FMA_(-dq[0], x, dq[3] * w)));
+    const REAL n2 = FMA_(nx, nx, ny * ny) + FMA_(nz, nz, nw * nw);
+    const REAL inv = small ? FMA_(R_(-0.5), n2, R_(1.5)) : R_(1) / RSQRT(n2);
+    q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
+}
+
 /* btPlaneSpace1-style tangent basis for a unit normal */
 static void FN(tangent_basis)(const REAL *n, REAL *t1, REAL *t2) {
     if (RFABS(n[2]) > R_(0.70710678118654752440)) {
@@ -896,7 +931,7 @@ static void FN(sphere_info)(const FN(orc_consts) * K, const FN(orc_dyn) * D, int
 static REAL FN(sphere_vs_box)(const REAL *p, REAL rad, const REAL *lo, const REAL *hi, REAL *n) {
     REAL d[3], d2 = 0;
     for (int k = 0; k < 3; ++k) { REAL cp = FN(clampr)(p[k], lo[k], hi[k]); d[k] = p[k] - cp; d2 = FMA_(d[k], d[k], d2); }
-    if (d2 > 0) { REAL len = RSQRT(d2); for (int k = 0; k < 3; ++k) n[k] = d[k] / len; return len - rad; }
+    if (d2 > 0) { REAL len = RSQRT(d2), il = R_(1) / len; for (int k = 0; k < 3; ++k) n[k] = d[k] * il; return len - rad; } /* one reciprocal, three products */
     if (!(d2 == 0)) { FN(v3set)(n, 0, 0, 1); return R_(1e30); } /* non-finite centre: no contact */
     int best = 0; REAL bd = R_(1e30), sgn = 1; /* centre inside the box: exit through the nearest face */
     for (int k = 0; k < 3; ++k) {
@@ -992,7 +1027,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                         const REAL len = RSQRT(d2n);
                         cc->level = a; cc->leg = i; cc->level2 = b; cc->leg2 = j; cc->sphere = -1; cc->surface = ORC_SURF_SELF + id; cc->mu = K->mu_self;
                         cc->dist = len - (K->r_caps + K->r_caps);
-                        if (len > 0) for (int k = 0; k < 3; ++k) cc->n[k] = dv[k] / len; else FN(v3set)(cc->n, 0, 0, 1);
+                        if (len > 0) { const REAL il = R_(1) / len; for (int k = 0; k < 3; ++k) cc->n[k] = dv[k] * il; } else FN(v3set)(cc->n, 0, 0, 1);
                         for (int k = 0; k < 3; ++k) cc->r[k] = R_(0.5) * (c1[k] + c2[k]); /* equal radii: midway between the two surface points */
                     }
     }
@@ -1071,18 +1106,7 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
     for (int j = 0; j < NJ; ++j) un[6 + j] = FN(clampr)(un[6 + j], -K->vmax, K->vmax);
     for (int k = 0; k < NDOF; ++k) u[k] = un[k];
     for (int k = 0; k < 3; ++k) q[k] = FMA_(h, u[3 + k], q[k]);
-    {
-        REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
-        if (th > R_(1e-6)) { REAL sh_, ch_; FN(dyn_sincos)(R_(0.5) * th, &sh_, &ch_); REAL s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
-        else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
-        REAL x = q[3], y = q[4], z = q[5], w = q[6]; /* q <- dq (x) q */
-        REAL nx = FMA_(-dq[2], y, FMA_(dq[1], z, FMA_(dq[0], w, dq[3] * x)));
-        REAL ny = FMA_(dq[2], x, FMA_(dq[1], w, FMA_(-dq[0], z, dq[3] * y)));
-        REAL nz = FMA_(dq[2], w, FMA_(-dq[1], x, FMA_(dq[0], y, dq[3] * z)));
-        REAL nw = FMA_(-dq[2], z, FMA_(-dq[1], y, FMA_(-dq[0], x, dq[3] * w)));
-        REAL inv = R_(1) / RSQRT(FMA_(nx, nx, ny * ny) + FMA_(nz, nz, nw * nw));
-        q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
-    }
+    FN(quat_integrate)(h, q, u);
     for (int j = 0; j < NJ; ++j) q[7 + j] = FMA_(h, u[6 + j], q[7 + j]);
     if (dbg) { dbg->n_rows = nr; dbg->n_limits = nl; dbg->n_contacts = nc; dbg->n_candidates = ncand; for (int r = 0; r < nr; ++r) dbg->lambda[r] = lam[r]; for (int c = 0; c < nc; ++c) dbg->surface[c] = C[c].surface; }
 }
@@ -1149,17 +1173,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
     for (int k = 0; k < 6; ++k) un[k] = un16[k];
     for (int k = 0; k < 6; ++k) u[k] = un[k];
     for (int k = 0; k < 3; ++k) q[k] = FMA_(h, u[3 + k], q[k]);
-    {
-        REAL wn = RSQRT(FN(v3dot)(u, u)), th = wn * h, dq[4];
-        if (th > R_(1e-6)) { REAL sh_, ch_; FN(dyn_sincos)(R_(0.5) * th, &sh_, &ch_); REAL s = sh_ / wn; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = ch_; }
-        else { REAL s = R_(0.5) * h; dq[0] = u[0] * s; dq[1] = u[1] * s; dq[2] = u[2] * s; dq[3] = 1; }
-        REAL nx = FMA_(-dq[2], y, FMA_(dq[1], z, FMA_(dq[0], w, dq[3] * x)));
-        REAL ny = FMA_(dq[2], x, FMA_(dq[1], w, FMA_(-dq[0], z, dq[3] * y)));
-        REAL nz = FMA_(dq[2], w, FMA_(-dq[1], x, FMA_(dq[0], y, dq[3] * z)));
-        REAL nw = FMA_(-dq[2], z, FMA_(-dq[1], y, FMA_(-dq[0], x, dq[3] * w)));
-        REAL inv = R_(1) / RSQRT(FMA_(nx, nx, ny * ny) + FMA_(nz, nz, nw * nw));
-        q[3] = nx * inv; q[4] = ny * inv; q[5] = nz * inv; q[6] = nw * inv;
-    }
+    FN(quat_integrate)(h, q, u);
 }
 
 /* =================================================================================================================
