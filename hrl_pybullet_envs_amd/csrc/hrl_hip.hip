@@ -12,6 +12,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <string>
 
 #include "host_cfg.h"
@@ -23,12 +25,28 @@ namespace {
 thread_local std::string g_err;
 unsigned long long *g_stamps = nullptr; /* set only by the diagnostic entry point hrl_debug_set_stamps */
 
+/* G = envs (= waves) per workgroup.  G = 1: one 64-thread workgroup per env, every phase on the env's own wave.  G = 4: four
+ * env-waves share a 256-thread workgroup and the lane-sparse phases of all four run once on wave 0 (step_core.h,
+ * ant_group_block); phases of one wave are ordered by a wave-level LDS fence, the two blocks of a substep by s_barrier. */
+template <int G>
 struct GpuExec {
-    WaveLds &L;
+    WaveLds *Ls; /* the group's records, [G] */
     LaneRegs r;
-    int lane;
-    __device__ __forceinline__ WaveLds &lds() { return L; }
+    int lane, wave;
+    __device__ __forceinline__ WaveLds &lds() { return Ls[G == 1 ? 0 : wave]; }
+    __device__ __forceinline__ WaveLds &lds(int k) { return Ls[G == 1 ? 0 : k]; }
     __device__ __forceinline__ LaneRegs &reg(int) { return r; }
+    /* orders this wave's LDS writes before its later LDS reads (the lanes of a wave exchange data through LDS) */
+    __device__ __forceinline__ void wave_sync() {
+        if (G == 1) __syncthreads(); /* a 64-thread workgroup: compiles to the wait, no s_barrier */
+        else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    }
+    __device__ __forceinline__ void group_sync() { if (G > 1) __syncthreads(); }
+    /* a phase of the group block: executed by the leader wave, lane >> 4 = env of the group */
+    template <class F>
+    __device__ __forceinline__ void leader(F f) {
+        if (G == 1 || wave == 0) { f(lane); wave_sync(); }
+    }
     __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
     /* Makes the lane id (and the friction links) opaque to the optimizer at this point.  Without it every
      * lane-derived value of the unrolled solver (44 `lane == r` masks, LDS addresses, ...) is loop-invariant, gets
@@ -66,7 +84,7 @@ struct GpuExec {
     template <class F>
     __device__ __forceinline__ void each(F f) {
         f(lane);
-        __syncthreads();
+        wave_sync();
     }
     template <class P, class W, class Q>
     __device__ __forceinline__ int each_compact(P pred, W write, Q post) {
@@ -75,7 +93,7 @@ struct GpuExec {
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
         if (h.ok) write(lane, rank, h);
         post(lane, h);
-        __syncthreads();
+        wave_sync();
         return __popcll(m);
     }
     /* lane mask of a predicate (v_cmp into an SGPR pair) */
@@ -103,35 +121,43 @@ struct GpuExec {
  * passed by value: by-value kernel arguments were all preloaded into SGPRs and spilled.
  * One kernel per env kind: each contains only its own env's code, which keeps the instruction footprint small
  * (all waves of a CU share one instruction cache). */
-template <int KIND>
-__global__ __launch_bounds__(64, 4) void k_step(DevBufs b, const DevCfg *__restrict__ cp) {
-    __shared__ WaveLds L;
+template <int KIND, int G>
+__global__ __launch_bounds__(64 * G, 4) void k_step(DevBufs b, const DevCfg *__restrict__ cp) {
+    __shared__ WaveLds L[G];
     LaneRegs regs; /* deliberately uninitialised: every field is defined by the phase that produces it */
-    GpuExec x{L, regs, (int)threadIdx.x};
-    step_entry<KIND>(x, b, *cp, (int)blockIdx.x);
+    GpuExec<G> x{L, regs, (int)threadIdx.x & 63, (int)threadIdx.x >> 6};
+    step_entry<KIND>(x, b, *cp, (int)blockIdx.x * G + ((int)threadIdx.x >> 6));
 }
 template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__restrict__ cp) {
-    __shared__ WaveLds L;
+    __shared__ WaveLds L[1];
     LaneRegs regs;
-    GpuExec x{L, regs, (int)threadIdx.x};
+    GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
     reset_entry<KIND>(x, b, *cp, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(64, 4) void k_set_goals(DevBufs b, const DevCfg *__restrict__ cp, const float *goals_xy, int n_goals) {
-    __shared__ WaveLds L;
+    __shared__ WaveLds L[1];
     LaneRegs regs;
-    GpuExec x{L, regs, (int)threadIdx.x};
+    GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
     set_goals_entry(x, b, *cp, (int)blockIdx.x, goals_xy, n_goals);
 }
 using kernel_fn = void (*)(DevBufs, const DevCfg *);
-kernel_fn step_kernel(int kind) {
+/* group = envs per workgroup of the step kernel: 4 for the ant kinds (1 selectable for A/B measurements), 1 for the point bot */
+kernel_fn step_kernel(int kind, int group) {
+    if (group == 4) switch (kind) {
+        case HRL_ANT_FLAT: return k_step<HRL_ANT_FLAT, 4>;
+        case HRL_ANT_GATHER: return k_step<HRL_ANT_GATHER, 4>;
+        case HRL_ANT_MAZE: return k_step<HRL_ANT_MAZE, 4>;
+        case HRL_ANT_MAZE_MJ: return k_step<HRL_ANT_MAZE_MJ, 4>;
+        case HRL_ANT_FLAGRUN: return k_step<HRL_ANT_FLAGRUN, 4>;
+    }
     switch (kind) {
-        case HRL_ANT_FLAT: return k_step<HRL_ANT_FLAT>;
-        case HRL_ANT_GATHER: return k_step<HRL_ANT_GATHER>;
-        case HRL_ANT_MAZE: return k_step<HRL_ANT_MAZE>;
-        case HRL_ANT_MAZE_MJ: return k_step<HRL_ANT_MAZE_MJ>;
-        case HRL_ANT_FLAGRUN: return k_step<HRL_ANT_FLAGRUN>;
-        default: return k_step<HRL_POINT_GATHER>;
+        case HRL_ANT_FLAT: return k_step<HRL_ANT_FLAT, 1>;
+        case HRL_ANT_GATHER: return k_step<HRL_ANT_GATHER, 1>;
+        case HRL_ANT_MAZE: return k_step<HRL_ANT_MAZE, 1>;
+        case HRL_ANT_MAZE_MJ: return k_step<HRL_ANT_MAZE_MJ, 1>;
+        case HRL_ANT_FLAGRUN: return k_step<HRL_ANT_FLAGRUN, 1>;
+        default: return k_step<HRL_POINT_GATHER, 1>;
     }
 }
 kernel_fn reset_kernel(int kind) {
@@ -180,6 +206,7 @@ struct hrl_handle {
     DevCfg dc;
     DevCfg *d_dc; /* device copy of the constants (the only device memory the library owns) */
     int device;
+    int group;    /* envs per workgroup of the step kernel */
 };
 
 extern "C" {
@@ -203,6 +230,8 @@ int hrl_create(const hrl_config *cfg, hrl_handle **out) {
     h->cfg = *cfg;
     build_devcfg(*cfg, h->dc);
     h->d_dc = nullptr;
+    h->group = cfg->env_kind == HRL_POINT_GATHER ? 1 : 4;
+    if (const char *g = getenv("HRL_STEP_GROUP")) { if (g[0] == '1') h->group = 1; } /* measurement aid: the one-wave-per-env launch */
     hipError_t e2 = hipGetDevice(&h->device);
     if (e2 == hipSuccess) e2 = hipMalloc((void **)&h->d_dc, sizeof(DevCfg));
     if (e2 == hipSuccess) e2 = hipMemcpy(h->d_dc, &h->dc, sizeof(DevCfg), hipMemcpyHostToDevice);
@@ -236,7 +265,8 @@ int hrl_step(hrl_handle *h, const hrl_buffers *b, void *stream) {
     if (!h || !b || !b->state || !b->aux || !b->obs || !b->actions || !b->reward || !b->done || !b->info)
         return fail(HRL_ERR_BAD_ARG, "hrl_step: null handle or buffer");
     if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist or manual goals)");
-    hipLaunchKernelGGL(step_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
+    const int G = h->group;
+    hipLaunchKernelGGL(step_kernel(h->dc.kind, G), dim3((h->dc.n_envs + G - 1) / G), dim3(64 * G), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_step launch");
 }

@@ -187,7 +187,8 @@ HRL_DEV void sincos_spec(float x, float *sn, float *cs) {
     float pc = fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f);
     pc = fma_(pc, z, 4.166664568298827e-2f);
     const float cr = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
-    const int q = ((int)k) & 3;
+    /* quadrant; out of int range (exploded states, NaN) the conversion would be implementation-defined: quadrant 0 then */
+    const int q = ((int)(fabsf(k) < 1e9f ? k : 0.f)) & 3;
     const float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
     *sn = (q & 2) ? -s1 : s1;
     *cs = ((q + 1) & 2) ? -c1 : c1;
@@ -960,23 +961,42 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
     });
 }
 
-/* One physics substep.  On entry L.q[qi] / L.u / L.tau hold the state; on exit L.q[qi ^ 1] / L.u are advanced by h. */
+/* ------------------------------------------------------------------------------------------------ the ant substep
+ * A substep is two blocks.  The GROUP block holds the lane-sparse phases -- position integration of the previous substep,
+ * then K1, K2, S, B, V: nine bodies / 14 dofs of distinct work per env -- and is executed ONCE for all the envs of a
+ * workgroup by its leader wave, 16 lanes per env (lane >> 4 = env of the group, lane & 15 = body / dof): one instruction
+ * stream serves four envs instead of four streams serving one each.  The ENV block (contacts, limits, rows, A, sweeps,
+ * velocity reconstruction: up to 44 rows of distinct work) is executed by every env's own wave.  A workgroup barrier
+ * separates the blocks; inside a block the phases of a wave are separated by wave-level LDS synchronisation only.
+ * With a group of one (executor G = 1) the leader is the env's own wave and the four 16-lane slices compute the same
+ * values on the same record, which is the one-wave-per-env form.
+ * qi = index of the position buffer the dynamics work on; integration reads q[qi ^ 1] and writes q[qi]. */
 template <class X>
-HRL_DEV int ant_substep(X &x, const DevCfg &c, int qi, bool items_on) {
-    WaveLds &L = x.lds();
-    const float *q = L.q[qi];
-    float *qn = L.q[qi ^ 1];
+HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi, bool integrate_prev, bool dynamics) {
     x.refresh(); /* keep lane-derived values local to the substep (see GpuExec::refresh) */
     x.stamp(0);
-    x.each([&](int lane) { phase_kin_ankle(c, L, x.reg(lane), q, lane); });
+    if (integrate_prev) x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_integrate(c, L, L.q[qi ^ 1], L.q[qi], lane & 15); });
+    if (!dynamics) return;
+    /* the phases index bodies as lane >> 2 (four lanes per body in the one-env form): (lane & 15) << 2 gives body = lane & 15 */
+    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_kin_ankle(c, L, x.reg(lane), L.q[qi], (lane & 15) << 2); });
     x.stamp(1);
-    x.each([&](int lane) { phase_hip(L, x.reg(lane), lane); });
+    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_hip(L, x.reg(lane), (lane & 15) << 2); });
     x.stamp(2);
-    x.each([&](int lane) { phase_leg_sum(L, lane); });
-    x.each([&](int lane) { phase_base(L, x.reg(lane), lane); });
+    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_leg_sum(L, lane & 15); phase_leg_sum(L, (lane & 15) + 16); });
+    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_base(L, x.reg(lane), (lane & 15) << 2); });
     x.stamp(3);
-    x.each([&](int lane) { const float v = phase_forward_vel(c, L, lane); x.reg(lane).ud = v; if (lane < 16) L.ustar[lane] = v; });
+    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); const float v = phase_forward_vel(c, L, lane & 15); L.ustar[lane & 15] = v; });
     x.stamp(4);
+}
+
+/* ENV block of a substep: on entry L.q[qi] / L.u / L.ustar and the articulated-body quantities of the group block are in the
+ * env's record; on exit L.u holds the constrained, clamped velocity.  Returns the number of contacts kept. */
+template <class X>
+HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
+    WaveLds &L = x.lds();
+    const float *q = L.q[qi];
+    x.refresh();
+    x.each([&](int lane) { x.reg(lane).ud = L.ustar[lane & 15]; }); /* the velocity if no row turns up */
     /* contacts in surface-major, sphere-minor order (ballot ranks follow lane order), at most MAXC kept:
      * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = world boxes, then the item
      * cubes near the robot (up to four cubes per pass, 13 lanes each), then the capsule pairs of different legs */
@@ -1084,7 +1104,6 @@ HRL_DEV int ant_substep(X &x, const DevCfg &c, int qi, bool items_on) {
         if (d >= 6 && d < 14) v = clampf(v, -c.vmax, c.vmax);
         if (lane < 16) L.u[lane] = v;
     });
-    x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });
     return nC;
 }
 
@@ -1701,37 +1720,58 @@ HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, con
     store_env(x, b, c, e);
 }
 
-/* hrl_step for one env (one wave) */
+/* hrl_step for one env (one wave; the waves of a workgroup form a group, see ant_group_block).  e >= n_envs: a wave of the
+ * last group without an env of its own, which only takes part in the group's barriers. */
 template <int KIND, class X>
 HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     WaveLds &L = x.lds();
     const long long env = c.env_id_offset + e;
-    load_env(x, b, c, e, true);
-    x.each([&](int lane) {
-        if (lane < 16) {
-            L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f;
-            /* qvel (v, omega, joint rates) -> u (omega, v, joint rates) */
-            const int src = lane < 3 ? 15 + 3 + lane : (lane < 6 ? 15 + lane - 3 : 15 + lane);
-            L.u[lane] = lane < 14 ? L.st[src] : 0.f;
-        }
-        if (lane >= 16 && lane < 24) {
-            const int j = lane - 16;
-            if (KIND == 3) { /* point_bot.py:28-31: a / |a| * 500 N in the world xy plane */
-                const float n = sqrtf(L.act[0] * L.act[0] + L.act[1] * L.act[1]);
-                L.tau[j] = j < 2 ? L.act[j] / n * c.point_force : 0.f;
-            } else L.tau[j] = c.torque_scale * clampf(L.act[j], -1.f, 1.f);
-        }
-    });
+    const bool on = e < c.n_envs;
+    if (on) {
+        load_env(x, b, c, e, true);
+        x.each([&](int lane) {
+            if (lane < 16) {
+                L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f;
+                /* qvel (v, omega, joint rates) -> u (omega, v, joint rates) */
+                const int src = lane < 3 ? 15 + 3 + lane : (lane < 6 ? 15 + lane - 3 : 15 + lane);
+                L.u[lane] = lane < 14 ? L.st[src] : 0.f;
+            }
+            if (lane >= 16 && lane < 24) {
+                const int j = lane - 16;
+                if (KIND == 3) { /* point_bot.py:28-31: a / |a| * 500 N in the world xy plane */
+                    const float n = sqrtf(L.act[0] * L.act[0] + L.act[1] * L.act[1]);
+                    L.tau[j] = j < 2 ? L.act[j] / n * c.point_force : 0.f;
+                } else L.tau[j] = c.torque_scale * clampf(L.act[j], -1.f, 1.f);
+            }
+        });
+    }
     x.stamp(12);
     int qi = 0, n_contacts = 0; /* n_contacts: the contacts of the step's last collision pass (contact-based pickup) */
     const bool items_on = (KIND == 1 || KIND == 3) && c.item_collision != 0;
     HRL_PIN_INT(qi);
+    if constexpr (KIND == 3) {
 #pragma unroll 1
-    for (int s = 0; s < c.nsub; ++s) { /* one copy of the substep body: it is the kernel's instruction-cache footprint */
-        if constexpr (KIND == 3) n_contacts = point_substep(x, c, qi, items_on); else n_contacts = ant_substep(x, c, qi, items_on);
-        qi ^= 1;
-        HRL_PIN_INT(qi); /* keep the ping-pong index a run-time value so the body is not cloned per parity */
+        for (int s = 0; s < c.nsub; ++s) { /* one copy of the substep body: it is the kernel's instruction-cache footprint */
+            n_contacts = point_substep(x, c, qi, items_on);
+            qi ^= 1;
+            HRL_PIN_INT(qi); /* keep the ping-pong index a run-time value so the body is not cloned per parity */
+        }
+    } else {
+        x.group_sync(); /* every record of the group is loaded before the leader reads it */
+#pragma unroll 1
+        for (int s = 0; s <= c.nsub; ++s) { /* trip s: integrate substep s - 1, dynamics of substep s | its constraints */
+            if (s > 0) qi ^= 1;
+            HRL_PIN_VGPR(qi); /* run-time value: one copy of the bodies for both parities (a vector register: the compiler does not
+                                 know that the waves of a group agree on it) */
+            ant_group_block(x, c, qi, s > 0, s < c.nsub);
+            x.group_sync();
+            if (s < c.nsub) {
+                if (on) n_contacts = ant_env_block(x, c, qi, items_on);
+                x.group_sync();
+            }
+        }
     }
+    if (!on) return;
     x.each([&](int lane) { /* back to the packed record */
         if (lane < 15) L.st[lane] = L.q[qi][lane];
         if (lane >= 16 && lane < 30) {

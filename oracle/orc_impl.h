@@ -73,7 +73,8 @@ static inline void FN(dyn_sincos)(REAL x, REAL *sn, REAL *cs) {
     float pc = FMA_(2.443315711809948e-5f, z, -1.388731625493765e-3f);
     pc = FMA_(pc, z, 4.166664568298827e-2f);
     float cr = FMA_(pc * z, z, FMA_(-0.5f, z, 1.0f));
-    int q = ((int)k) & 3;
+    /* quadrant; out of int range (exploded states, NaN) the conversion would be implementation-defined: quadrant 0 then */
+    int q = ((int)(fabsf(k) < 1e9f ? k : 0.f)) & 3;
     float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
     *sn = (q & 2) ? -s1 : s1;
     *cs = ((q + 1) & 2) ? -c1 : c1;

@@ -8,16 +8,36 @@
  * exposes same-phase cross-lane LDS dependencies that a real wave (and the forward emulation) would hide.
  */
 #define HRL_EMU 1
+#include <pthread.h>
+
+#include <thread>
+#include <vector>
+
 #include "../../hrl_pybullet_envs_amd/csrc/host_cfg.h"
 
 using namespace hrl;
 
+/* A workgroup of G env-waves: their LDS records and the workgroup barrier.  G = 1: the one-wave-per-env form.  G = 4: four
+ * host threads run the four waves of a group concurrently, exactly as the kernel's workgroup does (step_core.h,
+ * ant_group_block): the leader wave executes the group block on all four records while the others wait at the barrier. */
+struct CpuGroup {
+    int G;
+    WaveLds L[4];
+    pthread_barrier_t bar;
+    explicit CpuGroup(int g) : G(g) { memset(L, 0x7f, sizeof(L)); if (G > 1) pthread_barrier_init(&bar, nullptr, (unsigned)G); } /* poison LDS with large finite floats */
+    ~CpuGroup() { if (G > 1) pthread_barrier_destroy(&bar); }
+};
+
 struct CpuExec {
-    WaveLds L;
+    CpuGroup &grp;
+    int wave;
     LaneRegs regs[64];
     bool reverse = false;
-    CpuExec() { memset(&L, 0x7f, sizeof(L)); memset(regs, 0, sizeof(regs)); } /* poison LDS with large finite floats */
-    WaveLds &lds() { return L; }
+    CpuExec(CpuGroup &g, int w) : grp(g), wave(w) { memset(regs, 0, sizeof(regs)); }
+    WaveLds &lds() { return grp.L[grp.G == 1 ? 0 : wave]; }
+    WaveLds &lds(int k) { return grp.L[grp.G == 1 ? 0 : k]; }
+    void group_sync() { if (grp.G > 1) pthread_barrier_wait(&grp.bar); }
+    template <class F> void leader(F f) { if (grp.G == 1 || wave == 0) each(f); }
     LaneRegs &reg(int lane) { return regs[lane]; }
     int uniform(int v) { return v; }
     void refresh() {}
@@ -78,21 +98,36 @@ int emu_reset(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, 
     if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, mask);
-    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; reset_dispatch(x, d, c, e); }
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; reset_dispatch(x, d, c, e); }
     return HRL_OK;
 }
-int emu_step(const hrl_config *cfg, const hrl_buffers *b, int reverse) {
-    if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
+/* group = envs per workgroup: 4 = the product's launch for the ant kinds (four host threads per group), 1 = one wave per env */
+int emu_step_group(const hrl_config *cfg, const hrl_buffers *b, int reverse, int group) {
+    if (!validate(cfg).empty() || (group != 1 && group != 4)) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, nullptr);
-    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; step_dispatch(x, d, c, e); }
+    if (group == 1 || cfg->env_kind == HRL_POINT_GATHER) {
+        for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; step_dispatch(x, d, c, e); }
+        return HRL_OK;
+    }
+    const int n_groups = (cfg->num_envs + 3) / 4;
+    std::vector<CpuGroup *> groups;
+    for (int k = 0; k < n_groups; ++k) groups.push_back(new CpuGroup(4));
+    std::vector<std::thread> team;
+    for (int w = 0; w < 4; ++w)
+        team.emplace_back([&, w]() {
+            for (int k = 0; k < n_groups; ++k) { CpuExec x(*groups[k], w); x.reverse = reverse != 0; step_dispatch(x, d, c, 4 * k + w); }
+        });
+    for (auto &t : team) t.join();
+    for (auto *g : groups) delete g;
     return HRL_OK;
 }
+int emu_step(const hrl_config *cfg, const hrl_buffers *b, int reverse) { return emu_step_group(cfg, b, reverse, 4); }
 int emu_set_goals(const hrl_config *cfg, const hrl_buffers *b, const float *goals_xy, int n_goals, const uint8_t *mask, int reverse) {
     if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN || !cfg->flag_manual_goals || n_goals < 1 || n_goals > HRL_MAX_GOALS) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, mask);
-    for (int e = 0; e < cfg->num_envs; ++e) { CpuExec x; x.reverse = reverse != 0; set_goals_entry(x, d, c, e, goals_xy, n_goals); }
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; set_goals_entry(x, d, c, e, goals_xy, n_goals); }
     return HRL_OK;
 }
 int emu_lds_bytes(void) { return (int)sizeof(WaveLds); }
@@ -101,7 +136,8 @@ int emu_lds_bytes(void) { return (int)sizeof(WaveLds); }
 /* debug dump of the articulated-body quantities after phases K and B (same layout as orc_dyn_dump_f32 minus qdd) */
 extern "C" void emu_dyn_dump(const hrl_config *cfg, const float *q, const float *u, const float *tau, float *out) {
     DevCfg c; build_devcfg(*cfg, c);
-    CpuExec x;
+    CpuGroup grp(1);
+    CpuExec x(grp, 0);
     WaveLds &L = x.lds();
     for (int i = 0; i < 16; ++i) { L.q[0][i] = i < 15 ? q[i] : 0.f; L.u[i] = i < 14 ? u[i] : 0.f; }
     for (int j = 0; j < 8; ++j) L.tau[j] = tau[j];
