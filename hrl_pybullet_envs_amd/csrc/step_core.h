@@ -1165,8 +1165,9 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
             }
         };
     };
-    for (int f = 0; f < 1 + c.n_planes; ++f) {
-        int cnt = x.each_compact([&](int lane) { return corner(lane, lane < 8, f, -1); }, keep(nC), [&](int, const CornerHit &) {});
+    { /* ground and the (at most four) lateral planes in one pass: lane >> 3 = surface, lane & 7 = corner -- the surface-major,
+         corner-minor candidate order of the specification is the lane order */
+        int cnt = x.each_compact([&](int lane) { return corner(lane, (lane >> 3) < 1 + c.n_planes, lane >> 3, -1); }, keep(nC), [&](int, const CornerHit &) {});
         nC += cnt;
         if (nC > MAXC) nC = MAXC;
     }

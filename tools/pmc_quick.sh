@@ -11,5 +11,5 @@ for r in csv.DictReader(open(f)):
     if 'k_step' in r['Kernel_Name']:
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(acc.items()):
-    print(f'{k:24s} {sum(v) / len(v) / 4096:10.1f} per wave')
+    print(f"{k:24s} {sum(v) / len(v) / 4096:10.1f} per env")
 PY
