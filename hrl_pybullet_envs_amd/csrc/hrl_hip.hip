@@ -62,20 +62,22 @@ struct GpuExec {
     /* same for a wave-uniform value: comparisons against it are redone (one s_cmp each) after this point */
     __device__ __forceinline__ void refresh_uniform(int &v) { asm volatile("" : "+s"(v)); }
 #ifdef HRL_STAMPS
-    /* diagnostic build (never shipped): cycles between phase boundaries, summed per phase id; stamp id = the phase
-     * that just ENDED.  s_memtime + lgkmcnt(0) as one statement (cdna_hip_programming.md, In-kernel stamps). */
-    unsigned long long t_last = 0, acc[16] = {};
+    /* diagnostic build (never shipped): cycles between phase boundaries, summed per phase id; stamp id = the phase that just
+     * ENDED.  s_memtime + lgkmcnt(0) as one statement (cdna_hip_programming.md, In-kernel stamps).  The sums live in LDS
+     * (one lane adds), not in registers: sixteen 64-bit accumulators per lane would push the kernel into scratch. */
+    unsigned long long t_last = 0;
+    unsigned long long *acc; /* [24] in LDS, this wave's */
     __device__ __forceinline__ void stamp(int id) {
         unsigned long long t;
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (t_last) acc[id] += t - t_last;
+        if (t_last && lane == 0) acc[id] += t - t_last;
         t_last = t;
     }
     __device__ __forceinline__ void flush_stamps(const DevBufs &b) {
         if (b.stamps && lane == 0)
-            for (int i = 0; i < 16; ++i) atomicAdd(&b.stamps[i], acc[i]);
+            for (int i = 0; i < 24; ++i) atomicAdd(&b.stamps[i], acc[i]);
     }
 #else
     __device__ __forceinline__ void stamp(int) {}
@@ -126,6 +128,11 @@ __global__ __launch_bounds__(64 * G, 4) void k_step(DevBufs b, const DevCfg *__r
     __shared__ WaveLds L[G];
     LaneRegs regs; /* deliberately uninitialised: every field is defined by the phase that produces it */
     GpuExec<G> x{L, regs, (int)threadIdx.x & 63, (int)threadIdx.x >> 6};
+#ifdef HRL_STAMPS
+    __shared__ unsigned long long stamp_acc[G][24];
+    if ((threadIdx.x & 63) < 24) stamp_acc[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+    x.acc = stamp_acc[threadIdx.x >> 6];
+#endif
     step_entry<KIND>(x, b, *cp, (int)blockIdx.x * G + ((int)threadIdx.x >> 6));
 }
 template <int KIND>

@@ -121,6 +121,7 @@ struct alignas(16) WaveLds {
     float lamf[MAXR];    /* final impulses, for the velocity reconstruction */
     float ustar[16];     /* unconstrained velocity (dof order) */
     float st[32];        /* packed state record as stored in HBM */
+    float jlim[2][NJ];   /* joint ranges, copied from the constants when the env is loaded (phase L reads them per lane) */
     float items[32];
     float act[8];
     int aux[4];
@@ -403,8 +404,13 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
     crm(cbh, v0, vjh);
     crm(cba, vx, vja);
     /* the lane's rigid body: mass model, axis, COM (relative to O) and spatial velocity */
-    const float bm = type == 0 ? c.m2 : (type == 1 ? c.m1 : c.m0);
-    const float bal = type == 0 ? c.a2 : (type == 1 ? c.a1 : c.a0), bbe = type == 0 ? c.b2 : (type == 1 ? c.b1 : c.b0);
+    /* the nine constants as scalar loads + lane selects (left to itself the compiler indexes the constant block by `type`,
+     * i.e. three vector-memory loads on the leader's dependent path) */
+    float m0 = c.m0, a0_ = c.a0, b0_ = c.b0, m1 = c.m1, a1_ = c.a1, b1_ = c.b1, m2 = c.m2, a2_ = c.a2, b2_ = c.b2;
+    HRL_PIN_VGPR(m0); HRL_PIN_VGPR(a0_); HRL_PIN_VGPR(b0_); HRL_PIN_VGPR(m1); HRL_PIN_VGPR(a1_); HRL_PIN_VGPR(b1_);
+    HRL_PIN_VGPR(m2); HRL_PIN_VGPR(a2_); HRL_PIN_VGPR(b2_);
+    const float bm = type == 0 ? m2 : (type == 1 ? m1 : m0);
+    const float bal = type == 0 ? a2_ : (type == 1 ? a1_ : a0_), bbe = type == 0 ? b2_ : (type == 1 ? b1_ : b0_);
     float be[3], bc[3], bv[6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -976,6 +982,7 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi, bool integrate_prev,
     x.refresh(); /* keep lane-derived values local to the substep (see GpuExec::refresh) */
     x.stamp(0);
     if (integrate_prev) x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_integrate(c, L, L.q[qi ^ 1], L.q[qi], lane & 15); });
+    x.stamp(20);
     if (!dynamics) return;
     /* the phases index bodies as lane >> 2 (four lanes per body in the one-env form): (lane & 15) << 2 gives body = lane & 15 */
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_kin_ankle(c, L, x.reg(lane), L.q[qi], (lane & 15) << 2); });
@@ -1085,7 +1092,7 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
         [&](int lane) {
             LimitHit r; r.ok = false; r.sgn = 0.f; r.dist = 0.f;
             if (lane < NJ) {
-                float dlo = q[7 + lane] - c.jlo[lane], dhi = c.jhi[lane] - q[7 + lane];
+                float dlo = q[7 + lane] - L.jlim[0][lane], dhi = L.jlim[1][lane] - q[7 + lane];
                 if (dlo < c.lmargin) { r.ok = true; r.sgn = 1.f; r.dist = dlo; }
                 else if (dhi < c.lmargin) { r.ok = true; r.sgn = -1.f; r.dist = dhi; }
             }
@@ -1677,6 +1684,7 @@ HRL_DEV void load_env(X &x, const DevBufs &b, const DevCfg &c, int e, bool with_
         else L.items[lane - 32] = b.items ? b.items[(size_t)e * 32 + (lane - 32)] : 0.f;
         if (lane < 4) L.aux[lane] = b.aux[(size_t)e * 4 + lane];
         if (lane < 8) L.act[lane] = (with_actions && lane < c.act_dim) ? b.actions[(size_t)e * c.act_dim + lane] : 0.f;
+        if (lane >= 8 && lane < 16) { L.jlim[0][lane - 8] = c.jlo[lane - 8]; L.jlim[1][lane - 8] = c.jhi[lane - 8]; }
     });
 }
 template <class X>
@@ -1764,11 +1772,19 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             if (s > 0) qi ^= 1;
             HRL_PIN_VGPR(qi); /* run-time value: one copy of the bodies for both parities (a vector register: the compiler does not
                                  know that the waves of a group agree on it) */
+#ifndef HRL_ABLATE_GROUP
             ant_group_block(x, c, qi, s > 0, s < c.nsub);
+#endif
+            x.stamp(16);
             x.group_sync();
+            x.stamp(17); /* waiting for the leader (the leader: for the stragglers of the previous env block) */
             if (s < c.nsub) {
+#ifndef HRL_ABLATE_ENV /* timing-ablation builds only (tools/variants.py): never defined in the product */
                 if (on) n_contacts = ant_env_block(x, c, qi, items_on);
+#endif
+                x.stamp(18);
                 x.group_sync();
+                x.stamp(19); /* waiting for the slowest env block of the group */
             }
         }
     }

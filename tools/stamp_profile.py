@@ -14,8 +14,9 @@ sys.path.insert(0, ROOT)
 from hrl_pybullet_envs_amd import _capi as K  # noqa: E402
 from hrl_pybullet_envs_amd import _lib  # noqa: E402
 
-NAMES = ['(substep entry)', 'K1 kin+ankle', 'K2 hip', 'B base', 'V forward/vel', 'C contacts', 'L limits', 'R1 rows J,B',
-         'R2 A,w', 'PGS sweeps', 'final u', 'I integrate', 'load/init', '(substeps->obs)', 'obs pipeline', 'reward+store']
+NAMES = ['(block entry)', 'K1 kin+ankle', 'K2 hip', 'S+B base', 'V forward/vel', 'C contacts', 'L limits', 'R1 rows J,B',
+         'R2 A,w', 'PGS sweeps', 'point: final u', 'point: integrate', 'load/init', '(substeps->obs)', 'obs pipeline', 'reward+store',
+         '(group block end)', 'WAIT for leader', 'recon+clamp', 'WAIT for env blocks', 'I integrate', '', '', '']
 
 
 def main():
@@ -34,7 +35,7 @@ def main():
     acts = torch.rand(32, n, env.act_dim, device='cuda') * 2 - 1
     for t in range(60):
         env.step(acts[t % 32])
-    stamps = torch.zeros(16, dtype=torch.int64, device='cuda')
+    stamps = torch.zeros(24, dtype=torch.int64, device='cuda')
     L.hrl_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
     steps = 100
     for t in range(steps):
@@ -42,9 +43,11 @@ def main():
     torch.cuda.synchronize()
     v = stamps.cpu().numpy().astype(float) / (n * steps)
     tot = v.sum()
-    print(f'kind {kind}, {n} envs: {tot:.0f} cycles per env-step (stamped build)')
+    print(f'kind {kind}, {n} envs: {tot:.0f} cycles per env-wave per step (stamped build; the group-block phases are the leader wave\'s, '
+          f'1 wave in 4, the others spend that time in "WAIT for leader")')
     for i, name in enumerate(NAMES):
-        print(f'  {i:2d} {name:18s} {v[i]:9.0f} cyc  {100 * v[i] / tot:5.1f} %')
+        if name:
+            print(f'  {i:2d} {name:22s} {v[i]:9.0f} cyc  {100 * v[i] / tot:5.1f} %')
 
 
 if __name__ == '__main__':
