@@ -51,7 +51,7 @@ struct GpuExec {
     /* Makes the lane id (and the friction links) opaque to the optimizer at this point.  Without it every
      * lane-derived value of the unrolled solver (44 `lane == r` masks, LDS addresses, ...) is loop-invariant, gets
      * hoisted to the top of the kernel and is spilled to scratch for the whole substep loop. */
-    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(lane), "+v"(r.fn)); }
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(lane), "+v"(r.fn), "+v"(wave)); }
     /* 1.0 on lane r (wave-uniform), 0.0 elsewhere: one v_cndmask on a scalar lane mask */
     __device__ __forceinline__ float lane_one(int, int r) {
         float d;

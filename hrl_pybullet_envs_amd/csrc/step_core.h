@@ -291,7 +291,11 @@ HRL_DEV void tangent_basis(const float *n, float *t1, float *t2) {
  * the constants below (signed zeros as the formula produces them) without the square root and the division. */
 HRL_DEV void store_contact_frame(WaveLds &L, int i, const float *n, bool up = false) {
     float t1[3], t2[3];
-    if (up) { t1[0] = 0.f; t1[1] = -1.f; t1[2] = 0.f; t2[0] = 1.f; t2[1] = -0.f; t2[2] = -0.f; }
+    if (up) { /* tangent_basis with a = 1, k = 1: (0, -1, 0) and (1, -0, -0), formed from n (as constants the compiler keeps them in
+                 registers around the substep loop, and spills them) */
+        t1[0] = 0.f; t1[1] = -n[2]; t1[2] = n[1];
+        t2[0] = n[2]; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
+    }
     else tangent_basis(n, t1, t2);
 #pragma unroll
     for (int k = 0; k < 3; ++k) L.cdir[0][i][k] = n[k];
@@ -772,7 +776,9 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
 HRL_DEV void phase_self_rows(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane, int nL, int nC) {
     const int nR = nL + 3 * nC;
     if (lane >= MAXR) return;
-    L.J2[lane][0] = 0.f; L.J2[lane][1] = 0.f;
+    float z0 = 0.f;
+    HRL_PIN_VGPR(z0); /* materialised here, not hoisted out of the substep loop as a live register */
+    L.J2[lane][0] = z0; L.J2[lane][1] = z0;
     if (lane < nL || lane >= nR) return;
     const int row = lane - nL;
     const int ci = row < nC ? row : (row - nC) >> 1, which = row < nC ? 0 : 1 + ((row - nC) & 1);
@@ -1789,6 +1795,8 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         }
     }
     if (!on) return;
+    int eo = e; /* the env index again, opaque: the output addresses are formed here, not kept in registers since the loads */
+    HRL_PIN_VGPR(eo);
     x.each([&](int lane) { /* back to the packed record */
         if (lane < 15) L.st[lane] = L.q[qi][lane];
         if (lane >= 16 && lane < 30) {
@@ -1875,7 +1883,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         L.red[1] = L.st[29] + rew; L.red[2] = (float)t_ep;
     });
     x.each([&](int lane) { /* each LDS word below is read and written by one lane only */
-        if (lane == 0) { L.aux[0] = L.aux[0] + 1; b.reward[e] = L.scal[0]; b.done[e] = (uint8_t)L.flags[1]; }
+        if (lane == 0) { L.aux[0] = L.aux[0] + 1; b.reward[eo] = L.scal[0]; b.done[eo] = (uint8_t)L.flags[1]; }
         if (lane == 1) L.aux[1] = L.aux[1] + 1;
         if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
@@ -1892,7 +1900,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         }
         if (lane >= 4 && lane < 8) {
             const int k = lane - 4;
-            b.info[(size_t)e * 4 + k] = k == 0 ? L.scal[1] : (k == 1 ? L.scal[2] : (k == 2 ? L.red[1] : L.red[2]));
+            b.info[(size_t)eo * 4 + k] = k == 0 ? L.scal[1] : (k == 1 ? L.scal[2] : (k == 2 ? L.red[1] : L.red[2]));
         }
     });
     const int done_u = x.uniform(L.flags[1]);
@@ -1900,7 +1908,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         if (x.uniform(L.flags[3])) compute_obs<KIND>(x, c, env, true);
     }
     if (done_u && c.auto_reset) reset_env<KIND>(x, c, env);
-    store_env(x, b, c, e);
+    store_env(x, b, c, eo);
     x.stamp(15);
     x.flush_stamps(b);
 }

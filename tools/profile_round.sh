@@ -1,9 +1,9 @@
 #!/bin/bash
 # GPU box: the rocprofv3 passes whose summaries are committed under profiles/ (tools/summarize_profile.py condenses them).
-#   usage: tools/profile_round.sh gpurun_out/prof_<tag>
 # Kernel trace + stats and every counter group run as separate passes of the same bench command.
+#   usage: tools/profile_round.sh gpurun_out/prof_<tag> [kind [envs]]
 O=${1:?out dir}; mkdir -p $O
-B="python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline"
+B="python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --kind ${2:-gather} --envs ${3:-4096}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/bench_trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/f.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/w.log 2>&1 || exit 1
