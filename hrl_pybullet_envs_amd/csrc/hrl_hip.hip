@@ -18,6 +18,10 @@
 
 #include "host_cfg.h"
 
+#ifndef HRL_PRIO_MODE
+#define HRL_PRIO_MODE 1 /* 0 = equal wave priorities (A/B builds of tools/variants.py) */
+#endif
+
 using namespace hrl;
 
 namespace {
@@ -58,6 +62,27 @@ struct GpuExec {
         const unsigned long long m = 1ull << r;
         asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(d) : "s"(m));
         return d;
+    }
+    /* Issue arbitration between the waves of a SIMD goes by priority, then age: with four workgroups per CU at equal priority the
+     * first-dispatched one runs at its solo speed and the last one gets the leftover slots, so the launch lasts as long as its
+     * slowest workgroup while the mean one is done 13 % earlier (tools/wg_times.py).  slot() = the wave's slot on its SIMD
+     * (HW_ID.WAVE_ID; with four workgroups of four waves per CU it equals the workgroup's slot on the CU); priority(p) sets the
+     * wave's priority to p mod 4: rotating it with the substep hands every wave of a SIMD every rank once per step. */
+    __device__ __forceinline__ int slot() const {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
+        return (int)hw;
+    }
+    __device__ __forceinline__ void priority(int p) const {
+#if HRL_PRIO_MODE
+        switch (p & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
+        (void)p;
     }
     /* same for a wave-uniform value: comparisons against it are redone (one s_cmp each) after this point */
     __device__ __forceinline__ void refresh_uniform(int &v) { asm volatile("" : "+s"(v)); }
@@ -133,7 +158,23 @@ __global__ __launch_bounds__(64 * G, 4) void k_step(DevBufs b, const DevCfg *__r
     if ((threadIdx.x & 63) < 24) stamp_acc[threadIdx.x >> 6][threadIdx.x & 63] = 0;
     x.acc = stamp_acc[threadIdx.x >> 6];
 #endif
+#ifdef HRL_WGTIME
+    /* diagnostic build (never shipped, tools/wg_times.py): start / end clock and hardware id of every env-wave */
+    unsigned long long wg_t0, wg_t1;
+    if ((threadIdx.x & 63) == 0) L[threadIdx.x >> 6].dbg_rows = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
+#endif
     step_entry<KIND>(x, b, *cp, (int)blockIdx.x * G + ((int)threadIdx.x >> 6));
+#ifdef HRL_WGTIME
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1)::"memory");
+    if (b.stamps && (threadIdx.x & 63) == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = b.stamps + 4 * ((int)blockIdx.x * G + ((int)threadIdx.x >> 6));
+        o[0] = wg_t0; o[1] = wg_t1; o[2] = hw; o[3] = (xcc & 15) | ((unsigned long long)(unsigned)L[threadIdx.x >> 6].dbg_rows << 8);
+    }
+#endif
 }
 template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__restrict__ cp) {
@@ -305,7 +346,7 @@ int hrl_set_goals(hrl_handle *h, const hrl_buffers *b, const float *goals_xy, in
 const char *hrl_last_error(void) { return g_err.c_str(); }
 const char *hrl_backend(void) { return "hip-gfx950"; }
 
-#ifdef HRL_STAMPS
+#if defined(HRL_STAMPS) || defined(HRL_WGTIME)
 /* diagnostic builds only: device buffer of 16 u64 that k_step adds its per-phase cycle sums into */
 void hrl_debug_set_stamps(unsigned long long *dev16) { g_stamps = dev16; }
 #endif

@@ -45,6 +45,7 @@
 #define HRL_PIN_INT(x) asm volatile("" : "+s"(x))
 #endif
 
+
 namespace hrl {
 
 constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (assets/ant.xml:18-54) */
@@ -144,6 +145,9 @@ struct alignas(16) WaveLds {
     int ljoint[NJ];
     float lsign[NJ], ldist[NJ];
     int gtouch[16];
+#ifdef HRL_WGTIME
+    int dbg_rows; /* diagnostic build (tools/wg_times.py): solver rows | cube passes << 16 | self-contact substeps << 24, summed over the step */
+#endif
 };
 
 /* Per-lane registers that live across phases: the solver's working set.  On the GPU these are VGPRs (the row-space
@@ -1014,6 +1018,9 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
      * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = world boxes, then the item
      * cubes near the robot (up to four cubes per pass, 13 lanes each), then the capsule pairs of different legs */
     int nC = 0, nS = 0;
+#ifdef HRL_WGTIME
+    int n_cube_passes = 0;
+#endif
     /* Broad phase (wave-uniform): every contact sphere lies within 1.25 m of the torso centre (hip 0.283 + aux 0.283 +
      * foot 0.566 + radius 0.08 + contact_dist), so a lateral surface farther than that from the torso cannot produce a
      * contact and its pass is skipped.  Exactly the same contact list as testing every pair. */
@@ -1059,6 +1066,9 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
             return lane < c.n_food + c.n_poison && fabsf(q[0] - L.items[2 * (lane & 15)]) < R && fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R;
         });
         while (near) {
+#ifdef HRL_WGTIME
+            ++n_cube_passes;
+#endif
             int it[4], n_it = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1107,6 +1117,9 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
         [&](int lane, int rank, const LimitHit &r) { L.ljoint[rank] = lane; L.lsign[rank] = r.sgn; L.ldist[rank] = r.dist; },
         [&](int, const LimitHit &) {});
     x.stamp(6);
+#ifdef HRL_WGTIME
+    x.each([&](int lane) { if (lane == 0) L.dbg_rows += (nL + 3 * nC) | (n_cube_passes << 16) | ((nS > 0 ? 1 : 0) << 24); });
+#endif
     x.each([&](int lane) { phase_build_row(c, L, x.reg(lane), lane, nL, nC); });
     if (nS > 0) x.each([&](int lane) { phase_self_rows(c, L, x.reg(lane), lane, nL, nC); });
     x.stamp(7);
@@ -1764,9 +1777,11 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     int qi = 0, n_contacts = 0; /* n_contacts: the contacts of the step's last collision pass (contact-based pickup) */
     const bool items_on = (KIND == 1 || KIND == 3) && c.item_collision != 0;
     HRL_PIN_INT(qi);
+    const int slot = x.slot();
     if constexpr (KIND == 3) {
 #pragma unroll 1
         for (int s = 0; s < c.nsub; ++s) { /* one copy of the substep body: it is the kernel's instruction-cache footprint */
+            x.priority(slot + s); /* scheduling only, no effect on results: see GpuExec::priority */
             n_contacts = point_substep(x, c, qi, items_on);
             qi ^= 1;
             HRL_PIN_INT(qi); /* keep the ping-pong index a run-time value so the body is not cloned per parity */
@@ -1776,6 +1791,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
 #pragma unroll 1
         for (int s = 0; s <= c.nsub; ++s) { /* trip s: integrate substep s - 1, dynamics of substep s | its constraints */
             if (s > 0) qi ^= 1;
+            x.priority(slot + s); /* scheduling only, no effect on results: see GpuExec::priority */
             HRL_PIN_VGPR(qi); /* run-time value: one copy of the bodies for both parities (a vector register: the compiler does not
                                  know that the waves of a group agree on it) */
 #ifndef HRL_ABLATE_GROUP

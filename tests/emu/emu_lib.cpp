@@ -41,6 +41,8 @@ struct CpuExec {
     LaneRegs &reg(int lane) { return regs[lane]; }
     int uniform(int v) { return v; }
     void refresh() {}
+    int slot() const { return 0; } /* scheduling hints of the device executor: no effect on results */
+    void priority(int) const {}
     void refresh_uniform(int &) {}
     float lane_one(int lane, int r) { return lane == r ? 1.f : 0.f; }
     void stamp(int) {}
