@@ -1025,9 +1025,12 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
      * foot 0.566 + radius 0.08 + contact_dist), so a lateral surface farther than that from the torso cannot produce a
      * contact and its pass is skipped.  Exactly the same contact list as testing every pair. */
     const float reach = 0.2f * 1.41421356f + c.L1 + c.L2 + c.r_caps + c.cdist + 0.02f;
+    /* no short-circuit operators in these wave-uniform tests: `a && b` on LDS operands compiles to one load -> wait -> branch per
+     * term, a chain of dependent round trips (8 of them in the joint-range test below cost 0.35 us per substep) */
     bool near_plane = false, near_box = false;
-    for (int f = 0; f < c.n_planes; ++f)
-        near_plane = near_plane || ((c.plane_n[f][0] * q[0] + c.plane_n[f][1] * q[1] + c.plane_n[f][2] * q[2]) - c.plane_d[f] < reach);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+        near_plane = near_plane | ((f < c.n_planes) & ((c.plane_n[f][0] * q[0] + c.plane_n[f][1] * q[1] + c.plane_n[f][2] * q[2]) - c.plane_d[f] < reach));
     if (c.n_boxes > 0) {
         float d2 = 0.f;
         for (int k = 0; k < 3; ++k) { const float cp = clampf(q[k], c.box_lo[k], c.box_hi[k]); d2 += (q[k] - cp) * (q[k] - cp); }
@@ -1063,7 +1066,7 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
                        half extent more than the planes' bound, per axis), then the near cubes are tested four at a time */
         const float R = reach + ITEM_HALF;
         unsigned long long near = x.each_ballot([&](int lane) {
-            return lane < c.n_food + c.n_poison && fabsf(q[0] - L.items[2 * (lane & 15)]) < R && fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R;
+            return (lane < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * (lane & 15)]) < R) & (fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R);
         });
         while (near) {
 #ifdef HRL_WGTIME
@@ -1093,9 +1096,10 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
         coordinate axes (hence from the other legs' jointless capsules) and >= 0.4 m from one another, so no two capsule
         axes of different legs come within 2 r + contact_dist < 0.2 m: the pair test is skipped -- the same contact list
         as testing all 48 pairs (the joints' own limits are +-0.698 and +-1.745 rad). */
-        bool spread = (c.r_caps + c.r_caps) + c.cdist < 0.2f;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) spread = spread && fabsf(q[7 + 2 * l]) <= 0.75f && fabsf(q[8 + 2 * l]) <= 2.0f;
+        const bool thin = (c.r_caps + c.r_caps) + c.cdist < 0.2f;
+        const bool spread = x.each_ballot([&](int lane) { /* lane = joint: outside the safe range? */
+            return (lane < NJ) & !(thin & (fabsf(q[7 + (lane & 7)]) <= ((lane & 1) ? 2.0f : 0.75f)));
+        }) == 0;
         if (!x.uniform(spread)) {
             int cnt = x.each_compact([&](int lane) { return capsule_pair(c, L, lane < 48 ? lane : -1); }, keep(nC), [&](int, const Hit &) {});
             nS = nC + cnt > MAXC ? MAXC - nC : cnt; /* self contacts among the kept ones: their rows take the two-body path */
@@ -1200,7 +1204,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
     if (items_on) { /* cubes whose box comes within reach of a corner (half diagonal 0.35 sqrt 3 = 0.607), four per pass */
         const float R = 0.35f * 1.7320508f + ITEM_HALF + c.cdist + 0.02f;
         unsigned long long near = x.each_ballot([&](int lane) {
-            return lane < c.n_food + c.n_poison && fabsf(q[0] - L.items[2 * (lane & 15)]) < R && fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R;
+            return (lane < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * (lane & 15)]) < R) & (fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R);
         });
         while (near) {
             int it[4];
