@@ -37,12 +37,14 @@
 #define HRL_DEV inline
 #define HRL_PIN_VGPR(x) ((void)0)
 #define HRL_PIN_INT(x) ((void)0)
+#define HRL_PIN_SCALAR(x) ((void)0)
 #else
 #define HRL_DEV __device__ __forceinline__
 /* Materialise a wave-uniform value in a register at this point (and make it opaque to the optimizer): keeps
  * scalar loads of constants out of the solver loop, and keeps run-time what must not be specialised at compile time. */
 #define HRL_PIN_VGPR(x) asm volatile("" : "+v"(x))
 #define HRL_PIN_INT(x) asm volatile("" : "+s"(x))
+#define HRL_PIN_SCALAR(x) asm volatile("" : "+s"(x)) /* a float constant, loaded by a scalar load here */
 #endif
 
 
@@ -145,6 +147,7 @@ struct alignas(16) WaveLds {
     int ljoint[NJ];
     float lsign[NJ], ldist[NJ];
     int gtouch[16];
+    float planes[4][4];  /* lateral half-spaces (n, d), copied from the constants when the env is loaded: the collision passes index them per lane */
 #ifdef HRL_WGTIME
     int dbg_rows; /* diagnostic build (tools/wg_times.py): solver rows | cube passes << 16 | self-contact substeps << 24, summed over the step */
 #endif
@@ -645,12 +648,14 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
     h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.r[0] = h.r[1] = h.r[2] = 0.f;
     if (sph < 0 || sph >= 13) return h;
     int level = 0, leg = 0;
-    float rad = c.r_torso, ctr[3] = {0.f, 0.f, 0.f};
+    float r_torso = c.r_torso, r_caps = c.r_caps, ctr[3] = {0.f, 0.f, 0.f};
+    HRL_PIN_SCALAR(r_torso); /* two scalar loads and a select: left alone, the compiler selects the ADDRESS per lane and */
+    HRL_PIN_SCALAR(r_caps);  /* fetches the radius with a vector memory load in the middle of the collision pass           */
+    const float rad = sph > 0 ? r_caps : r_torso;
     if (sph > 0) {
         leg = (sph - 1) / 3; level = (sph - 1) % 3;
         const float *src = level == 0 ? L.ph[leg] : (level == 1 ? L.pa[leg] : L.tip[leg]);
         ctr[0] = src[0]; ctr[1] = src[1]; ctr[2] = src[2];
-        rad = c.r_caps;
     }
     h.link = level | (leg << 2);
     float p[3] = {q[0] + ctr[0], q[1] + ctr[1], q[2] + ctr[2]};
@@ -660,8 +665,8 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
         h.dist = sphere_vs_box(p, rad, lo, hi, h.n); h.surf = SURF_ITEM + item;
     } else if (f == 0) h.dist = (p[2] - c.ground_z) - rad;
     else if (f <= c.n_planes) {
-        h.n[0] = c.plane_n[f - 1][0]; h.n[1] = c.plane_n[f - 1][1]; h.n[2] = c.plane_n[f - 1][2];
-        h.dist = (dot3(h.n, p) - c.plane_d[f - 1]) - rad; h.surf = f;
+        h.n[0] = L.planes[f - 1][0]; h.n[1] = L.planes[f - 1][1]; h.n[2] = L.planes[f - 1][2];
+        h.dist = (dot3(h.n, p) - L.planes[f - 1][3]) - rad; h.surf = f;
     } else { h.dist = sphere_vs_box(p, rad, c.box_lo, c.box_hi, h.n); h.surf = SURF_BOX + (f - 1 - c.n_planes); }
 #pragma unroll
     for (int k = 0; k < 3; ++k) h.r[k] = fma_(-rad, h.n[k], ctr[k]);
@@ -1178,8 +1183,8 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
                 h.dist = sphere_vs_box(p, 0.f, lo, hi, h.n); h.surf = SURF_ITEM + item;
             } else if (f == 0) h.dist = p[2] - c.ground_z;
             else {
-                h.n[0] = c.plane_n[f - 1][0]; h.n[1] = c.plane_n[f - 1][1]; h.n[2] = c.plane_n[f - 1][2];
-                h.dist = dot3(h.n, p) - c.plane_d[f - 1];
+                h.n[0] = L.planes[f - 1][0]; h.n[1] = L.planes[f - 1][1]; h.n[2] = L.planes[f - 1][2];
+                h.dist = dot3(h.n, p) - L.planes[f - 1][3];
             }
             h.ok = h.dist < c.cdist;
         }
@@ -1708,6 +1713,7 @@ HRL_DEV void load_env(X &x, const DevBufs &b, const DevCfg &c, int e, bool with_
         if (lane < 4) L.aux[lane] = b.aux[(size_t)e * 4 + lane];
         if (lane < 8) L.act[lane] = (with_actions && lane < c.act_dim) ? b.actions[(size_t)e * c.act_dim + lane] : 0.f;
         if (lane >= 8 && lane < 16) { L.jlim[0][lane - 8] = c.jlo[lane - 8]; L.jlim[1][lane - 8] = c.jhi[lane - 8]; }
+        if (lane >= 16 && lane < 32) { const int f = (lane - 16) >> 2, k = lane & 3; L.planes[f][k] = k < 3 ? c.plane_n[f][k] : c.plane_d[f]; }
     });
 }
 template <class X>
