@@ -102,7 +102,7 @@ struct GpuExec {
     }
     __device__ __forceinline__ void flush_stamps(const DevBufs &b) {
         if (b.stamps && lane == 0)
-            for (int i = 0; i < 24; ++i) atomicAdd(&b.stamps[i], acc[i]);
+            for (int i = 0; i < 24; ++i) atomicAdd(&b.stamps[(G == 1 ? 0 : 24 * wave) + i], acc[i]); /* one table per wave of the group */
     }
 #else
     __device__ __forceinline__ void stamp(int) {}
@@ -347,7 +347,7 @@ const char *hrl_last_error(void) { return g_err.c_str(); }
 const char *hrl_backend(void) { return "hip-gfx950"; }
 
 #if defined(HRL_STAMPS) || defined(HRL_WGTIME)
-/* diagnostic builds only: device buffer of 16 u64 that k_step adds its per-phase cycle sums into */
+/* diagnostic builds only: device buffer of 4 x 24 u64 that k_step adds its per-phase cycle sums into */
 void hrl_debug_set_stamps(unsigned long long *dev16) { g_stamps = dev16; }
 #endif
 

@@ -35,19 +35,28 @@ def main():
     acts = torch.rand(32, n, env.act_dim, device='cuda') * 2 - 1
     for t in range(60):
         env.step(acts[t % 32])
-    stamps = torch.zeros(24, dtype=torch.int64, device='cuda')
+    stamps = torch.zeros(96, dtype=torch.int64, device='cuda')
     L.hrl_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
     steps = 100
     for t in range(steps):
         env.step(acts[t % 32])
     torch.cuda.synchronize()
-    v = stamps.cpu().numpy().astype(float) / (n * steps)
+    w = stamps.cpu().numpy().astype(float).reshape(4, 24)
+    grouped = w[1:].sum() > 0
+    v = w.sum(axis=0) / (n * steps)
     tot = v.sum()
-    print(f'kind {kind}, {n} envs: {tot:.0f} cycles per env-wave per step (stamped build; the group-block phases are the leader wave\'s, '
-          f'1 wave in 4, the others spend that time in "WAIT for leader")')
-    for i, name in enumerate(NAMES):
-        if name:
-            print(f'  {i:2d} {name:22s} {v[i]:9.0f} cyc  {100 * v[i] / tot:5.1f} %')
+    print(f'kind {kind}, {n} envs: {tot:.0f} cycles per env-wave per step (stamped build)')
+    if grouped:
+        lead, rest = w[0] / (n / 4 * steps), w[1:].sum(axis=0) / (3 * n / 4 * steps)
+        print('     phase                      leader wave      other waves   (cycles per step)')
+        for i, name in enumerate(NAMES):
+            if name:
+                print(f'  {i:2d} {name:22s} {lead[i]:12.0f}  {rest[i]:15.0f}')
+        print(f'     total                  {lead.sum():12.0f}  {rest.sum():15.0f}')
+    else:
+        for i, name in enumerate(NAMES):
+            if name:
+                print(f'  {i:2d} {name:22s} {v[i]:9.0f} cyc  {100 * v[i] / tot:5.1f} %')
 
 
 if __name__ == '__main__':
