@@ -24,7 +24,7 @@ def bind(path):
 
 
 def main():
-    n = 4096
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     libs = {'product': bind(_lib.LIB_PATH)}
     for p in sorted(glob.glob(os.path.join(ROOT, 'build', 'variants', 'lib_*.so'))):
         libs[os.path.basename(p)[4:-3]] = bind(p)
