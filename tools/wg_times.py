@@ -33,30 +33,37 @@ def main():
         env.step(acts[t % 32])
     buf = torch.zeros(4 * n, dtype=torch.int64, device='cuda')
     L.hrl_debug_set_stamps(C.c_void_p(buf.data_ptr()))
-    rows = []
+    rows, us = [], []
     for t in range(20):
-        env.step(acts[t % 32])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); env.step(acts[t % 32]); e1.record()
         torch.cuda.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3)
         rows.append(buf.cpu().numpy().reshape(n, 4).copy())
+    print(f'launch + step wrapper, HIP events: median {np.median(us):.1f} us (this diagnostic build)')
     v = np.concatenate(rows)
     launch = np.repeat(np.arange(20), n)
     t0, t1, hw, xcc = v[:, 0], v[:, 1], v[:, 2], v[:, 3] & 15
     life = (t1 - t0).astype(float)
-    # s_memtime is per XCD: spans are taken inside one (launch, XCD) and averaged
-    spans, ends = [], []
-    for la in range(20):
-        for xc in np.unique(xcc):
-            m = (launch == la) & (xcc == xc)
-            k0 = t0[m].min()
-            spans.append(t1[m].max() - k0)
-            ends.append(np.percentile(t1[m] - k0, [10, 50, 90, 100]) / spans[-1])
-    span = float(np.mean(spans))
+    # s_memtime counters are not synchronised across CUs: spans are taken inside one (launch, CU)
+    cu_all = ((hw >> 8) & 15) | (((hw >> 13) & 7) << 4) | (xcc << 8)
+    key = launch * 4096 + cu_all
+    order = np.argsort(key, kind='stable')
+    ks, st0, st1, sl = key[order], t0[order], t1[order], life[order]
+    bounds = np.flatnonzero(np.diff(ks)) + 1
+    starts = np.concatenate([[0], bounds]); stops = np.concatenate([bounds, [len(ks)]])
+    span_cu = np.array([st1[a:b].max() - st0[a:b].min() for a, b in zip(starts, stops)], dtype=float)
+    ramp_cu = np.array([st0[a:b].max() - st0[a:b].min() for a, b in zip(starts, stops)], dtype=float)
+    mean_cu = np.array([sl[a:b].mean() for a, b in zip(starts, stops)])
     print(f'kind {kind}, {n} envs, 20 launches, s_memtime ticks')
-    print(f'  kernel span inside one XCD (first wave start -> last wave end) {span:9.0f}')
-    print(f'  mean wave life {life.mean():9.0f} = {100 * life.mean() / span:.1f} % of the span; min {life.min():.0f}, p10 {np.percentile(life, 10):.0f}, '
+    print(f'  mean wave life {life.mean():9.0f}; min {life.min():.0f}, p10 {np.percentile(life, 10):.0f}, '
           f'median {np.median(life):.0f}, p90 {np.percentile(life, 90):.0f}, max {life.max():.0f}')
-    e = np.mean(ends, axis=0)
-    print(f'  wave END time / span: p10 {e[0]:.3f}, median {e[1]:.3f}, p90 {e[2]:.3f}')
+    print(f'  per (launch, CU): first wave start -> last wave end: mean {span_cu.mean():.0f}, p50 {np.median(span_cu):.0f}, p90 {np.percentile(span_cu, 90):.0f}, '
+          f'p99 {np.percentile(span_cu, 99):.0f}, max {span_cu.max():.0f}; mean wave life in the CU / that span: {np.mean(mean_cu / span_cu):.3f}; '
+          f'last wave start - first wave start: mean {ramp_cu.mean():.0f}')
+    per_launch_max = np.array([span_cu[(ks[starts] // 4096) == la].max() for la in range(20)])
+    print(f'  slowest CU of a launch (= the launch, but for the dispatch ramp across CUs): mean {per_launch_max.mean():.0f} = {per_launch_max.mean() / span_cu.mean():.3f} x the mean CU, '
+          f'{per_launch_max.mean() / life.mean():.3f} x the mean wave life')
     # HW_ID (gfx9): WAVE_ID [3:0], SIMD_ID [5:4], CU_ID [11:8], SE_ID [15:13], TG_ID [19:16]
     for name, key in (('WAVE_ID (slot on its SIMD)', hw & 15), ('SIMD_ID', (hw >> 4) & 3), ('TG_ID (workgroup slot on its CU)', (hw >> 16) & 15),
                       ('wave index in its workgroup', np.tile(np.arange(n) & 3, 20))):
