@@ -25,17 +25,19 @@ def bind(path):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    kind = int(sys.argv[2]) if len(sys.argv) > 2 else K.HRL_ANT_GATHER
+    obs_dim, act_dim = {0: (29, 8), 1: (46, 8), 2: (38, 8), 3: (18, 2), 4: (47, 8), 5: (38, 8)}[kind]
     libs = {'product': bind(_lib.LIB_PATH)}
     for p in sorted(glob.glob(os.path.join(ROOT, 'build', 'variants', 'lib_*.so'))):
         libs[os.path.basename(p)[4:-3]] = bind(p)
-    cfg = _lib.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=0, auto_reset=1)
+    cfg = _lib.default_config(kind, num_envs=n, seed=0, auto_reset=1)
     envs = {}
-    acts = torch.rand(64, n, 8, device='cuda') * 2 - 1
+    acts = torch.rand(64, n, act_dim, device='cuda') * 2 - 1
     for name, L in libs.items():
         h = C.c_void_p()
         assert L.hrl_create(C.byref(cfg), C.byref(h)) == 0
         t = dict(state=torch.zeros(n, 32, device='cuda'), items=torch.zeros(n, 32, device='cuda'), aux=torch.zeros(n, 4, dtype=torch.int32, device='cuda'),
-                 obs=torch.zeros(n, 46, device='cuda'), rew=torch.zeros(n, device='cuda'), done=torch.zeros(n, dtype=torch.uint8, device='cuda'),
+                 obs=torch.zeros(n, obs_dim + 2, device='cuda'), rew=torch.zeros(n, device='cuda'), done=torch.zeros(n, dtype=torch.uint8, device='cuda'),
                  info=torch.zeros(n, 4, device='cuda'))
         b = K.hrl_buffers(t['state'].data_ptr(), t['items'].data_ptr(), t['aux'].data_ptr(), None, t['obs'].data_ptr(), t['rew'].data_ptr(),
                           t['done'].data_ptr(), t['info'].data_ptr())
