@@ -84,6 +84,22 @@ def main():
         print(f'  least squares: life = {coef[0]:.0f} + {coef[1]:.1f} * rows + {coef[2]:.0f} * cube passes + {coef[3]:.0f} * self substeps; residual sd {res.std():.0f} of sd {gl.std():.0f}')
     widx, simd = np.tile(np.arange(n) & 3, 20), (hw >> 4) & 3
     print('  waves by (index in workgroup, SIMD_ID): ' + ' | '.join(' '.join(str(int(((widx == i) & (simd == j)).sum())) for j in range(4)) for i in range(4)))
+    if rows.max() > 0:
+        R = rows.reshape(20, n)
+        cc = lambda k: float(np.mean([np.corrcoef(R[t], R[t + k])[0, 1] for t in range(20 - k)]))
+        print(f'  persistence of an env\'s row count: correlation with the next step {cc(1):.3f}, 4 steps later {cc(4):.3f}, 8 later {cc(8):.3f}, 16 later {cc(16):.3f}')
+        Lf = life.reshape(20, n)
+        print(f'  persistence of a wave\'s life: next step {float(np.mean([np.corrcoef(Lf[t], Lf[t + 1])[0, 1] for t in range(19)])):.3f}')
+    # which workgroups share a CU?  (last launch) -- the dispatcher's block -> CU map
+    last = slice((20 - 1) * n, 20 * n, 4)
+    cul = cu_all[last]
+    first = {}
+    for w, c_ in enumerate(cul):
+        first.setdefault(int(c_), []).append(w)
+    some = list(first.items())[:6]
+    print('  workgroups of the first CUs seen (block indices): ' + '; '.join(f'{k:#x}: {v}' for k, v in some))
+    strides = sorted({tuple(np.diff(v)) for v in first.values()})
+    print(f'  distinct index-difference patterns of the workgroups sharing a CU: {strides[:8]}{" ..." if len(strides) > 8 else ""} ({len(strides)} patterns)')
     cu = ((hw >> 8) & 15) | (((hw >> 13) & 7) << 4) | (xcc << 8)
     per = np.array([life[cu == c_].mean() for c_ in np.unique(cu)])
     print(f'  {len(per)} CUs; mean life per CU: min {per.min():.0f}, median {np.median(per):.0f}, max {per.max():.0f}')
