@@ -221,6 +221,31 @@ def test_batch_composition_invariance():
     assert torch.equal(big.state[1000:1128], small.state) and torch.equal(big.items[1000:1128], small.items)
 
 
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 7, 4093])
+def test_env_counts_that_do_not_fill_the_last_group(n):
+    """Four env-waves share a workgroup: the waves of the last group without an env of their own only take part in its barriers.
+    Every count from one env up must match the oracle, and nothing outside the n rows of the caller's buffers may be written."""
+    g, o = make(K.HRL_ANT_GATHER, n, seed=11)
+    # the caller's buffers become views into larger allocations: a write past row n - 1 lands in the guard rows behind them
+    big = {}
+    for k in ('state', 'items', 'aux', 'obs', 'reward', 'done', 'info'):
+        t = getattr(g, k)
+        big[k] = torch.full((n + 8,) + tuple(t.shape[1:]), 7, dtype=t.dtype, device=t.device)
+        big[k][:n] = t
+        setattr(g, k, big[k][:n])
+    g._bufs = K.hrl_buffers(g.state.data_ptr(), g.items.data_ptr(), g.aux.data_ptr(), None, g.obs.data_ptr(), g.reward.data_ptr(),
+                            g.done.data_ptr(), g.info.data_ptr())
+    g.reset(); o.reset()
+    rng = np.random.RandomState(3)
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
+        assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
+    assert all(bool((v[n:] == 7).all()) for v in big.values())
+
+
 def test_mixed_ant_point_shard():
     """BASELINE config 5 shape on one GPU: first half AntGather, second half PointGather, two launches per step."""
     n = 512
