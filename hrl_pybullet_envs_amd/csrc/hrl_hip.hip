@@ -1,14 +1,18 @@
 /*
  * hrl_hip.hip -- gfx950 (MI355X) implementation of include/hrl_envs.h.
  *
- * One 64-thread workgroup = one wavefront = one environment.  The wave runs the phases of step_core.h with
- *   - per-wave state staged in LDS (WaveLds < 10 KB and <= 128 VGPRs -> 16 waves per CU, 4 per SIMD),
+ * One wavefront = one environment; four env-waves form a 256-thread workgroup (one for the PointBot).  A wave runs the phases of
+ * step_core.h with
+ *   - per-wave state staged in LDS (WaveLds 7.1 KB, <= 128 VGPRs -> 16 waves per CU, 4 per SIMD),
+ *   - the lane-sparse articulated-body phases of the four envs of a group executed once, 16 lanes per env, by the group's
+ *     leader wave (two s_barrier per substep); everything else by the env's own wave behind wave-level LDS fences,
  *   - coalesced 128-byte loads/stores of the packed state / item records (lane i <-> float i of the record),
  *   - the contact/limit solver entirely in lane registers: row r lives in lane r, its impulse change is broadcast with
  *     one v_readlane_b32 (no LDS, no barrier, no reduction on the dependent chain),
- *   - ballot + mbcnt for compacting active contacts / limits into solver rows.
- * There is no cross-workgroup communication, so no XCD-aware block remap is needed: blockIdx.x = env index and the
- * dispatcher's round-robin over the 8 XCDs spreads the envs evenly.
+ *   - ballot + popcount for compacting active contacts / limits into solver rows,
+ *   - the wave's issue priority rotated with the substep (GpuExec::priority): the four workgroups of a CU take turns.
+ * There is no cross-workgroup communication, so no XCD-aware block remap is needed: blockIdx.x = group index and the
+ * dispatcher's round-robin over the 8 XCDs spreads the groups evenly.
  */
 #include <hip/hip_runtime.h>
 
