@@ -374,6 +374,7 @@ HRL_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f
  * lanes keep their rigid-body quantities in registers for phases K2 / B.
  * The two articulated-body joints of a leg are split over two phases so that only one 6x6 inertia is live in
  * registers at a time (<= 128 VGPRs without scratch). */
+template <bool POS_ONLY = false> /* POS_ONLY: just the leg points ph / pa / tip of pose q (the parts centroid of the observation) */
 HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const float *q, int lane) {
     const float is2 = 0.70710678118654752440f;
     const int grp = lane >> 2, type = grp >> 2, l = grp & 3;
@@ -400,6 +401,13 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
         tip[k] = fma_(c.L2, e2[k], pa[k]);
         caux[k] = fma_(c.L1 * 0.5f, e1[k], ph[k]);
         cfoot[k] = fma_(c.L2 * 0.5f, e2[k], pa[k]);
+    }
+    if (POS_ONLY) {
+        if (type == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { L.ph[l][k] = ph[k]; L.pa[l][k] = pa[k]; L.tip[l][k] = tip[k]; }
+        }
+        return;
     }
     const int jh = 2 * l, ja = jh + 1;
     float Sh[6], Sa[6];
@@ -1606,7 +1614,7 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode, i
     if (centroid) { /* link positions of the final pose for the parts centroid; its LDS hand-off area overlays the
                        task scratch, so it runs before anything below is written */
         x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
-        x.each([&](int lane) { phase_kin_ankle(c, L, x.reg(lane), L.q[0], lane); });
+        x.each([&](int lane) { phase_kin_ankle<true>(c, L, x.reg(lane), L.q[0], lane); });
     }
     x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
     if (KIND == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });

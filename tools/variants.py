@@ -26,11 +26,11 @@ def bind(path):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     kind = int(sys.argv[2]) if len(sys.argv) > 2 else K.HRL_ANT_GATHER
-    obs_dim, act_dim = {0: (29, 8), 1: (46, 8), 2: (38, 8), 3: (18, 2), 4: (47, 8), 5: (38, 8)}[kind]
     libs = {'product': bind(_lib.LIB_PATH)}
     for p in sorted(glob.glob(os.path.join(ROOT, 'build', 'variants', 'lib_*.so'))):
         libs[os.path.basename(p)[4:-3]] = bind(p)
     cfg = _lib.default_config(kind, num_envs=n, seed=0, auto_reset=1)
+    obs_dim, act_dim = _lib.lib().hrl_obs_dim(C.byref(cfg)), _lib.lib().hrl_act_dim(C.byref(cfg))
     envs = {}
     acts = torch.rand(64, n, act_dim, device='cuda') * 2 - 1
     for name, L in libs.items():
