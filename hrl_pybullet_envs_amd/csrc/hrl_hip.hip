@@ -95,17 +95,17 @@ struct GpuExec {
      * ENDED.  s_memtime + lgkmcnt(0) as one statement (cdna_hip_programming.md, In-kernel stamps).  The sums live in LDS
      * (one lane adds), not in registers: sixteen 64-bit accumulators per lane would push the kernel into scratch. */
     unsigned long long t_last = 0;
-    unsigned long long *acc; /* [24] in LDS, this wave's */
+    unsigned long long *acc = nullptr; /* [24] in LDS, this wave's; null in the kernels that do not collect (k_reset, k_set_goals) */
     __device__ __forceinline__ void stamp(int id) {
         unsigned long long t;
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (t_last && lane == 0) acc[id] += t - t_last;
+        if (acc && t_last && lane == 0) acc[id] += t - t_last;
         t_last = t;
     }
     __device__ __forceinline__ void flush_stamps(const DevBufs &b) {
-        if (b.stamps && lane == 0)
+        if (acc && b.stamps && lane == 0)
             for (int i = 0; i < 24; ++i) atomicAdd(&b.stamps[(G == 1 ? 0 : 24 * wave) + i], acc[i]); /* one table per wave of the group */
     }
 #else

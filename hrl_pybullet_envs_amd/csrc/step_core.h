@@ -1622,7 +1622,9 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode, i
         const bool feet = step_mode && (KIND == 2 || KIND == 5); /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
         x.each([&](int lane) { phase_calc_state<KIND>(c, L, lane, feet, centroid); });
     }
+    x.stamp(21);
     if (KIND == 1 || KIND == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode, n_contacts); });
+    x.stamp(22);
     x.each([&](int lane) { phase_pack_obs<KIND>(c, L, lane); });
 }
 
