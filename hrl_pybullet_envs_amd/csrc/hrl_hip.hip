@@ -56,6 +56,8 @@ struct GpuExec {
         if (G == 1 || wave == 0) { f(lane); wave_sync(); }
     }
     __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ int wave_index() const { return __builtin_amdgcn_readfirstlane(wave); }
+    static constexpr __device__ __forceinline__ int group_size() { return G; }
     /* Makes the lane id (and the friction links) opaque to the optimizer at this point.  Without it every
      * lane-derived value of the unrolled solver (44 `lane == r` masks, LDS addresses, ...) is loop-invariant, gets
      * hoisted to the top of the kernel and is spilled to scratch for the whole substep loop. */

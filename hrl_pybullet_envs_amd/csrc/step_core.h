@@ -147,6 +147,7 @@ struct alignas(16) WaveLds {
     int ljoint[NJ];
     float lsign[NJ], ldist[NJ];
     int gtouch[16];
+    int nC, nL, nS, on; /* contacts / limit rows / self contacts found by ant_contacts for this env's substep; on = the record holds an env */
     float planes[4][4];  /* lateral half-spaces (n, d), copied from the constants when the env is loaded: the collision passes index them per lane */
 #ifdef HRL_WGTIME
     int dbg_rows; /* diagnostic build (tools/wg_times.py): solver rows | cube passes << 16 | self-contact substeps << 24, summed over the step */
@@ -449,12 +450,8 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
     }
     if (type != 0) return; /* aux body: continues in K2; torso: in B */
     /* one destination at a time: stores to consecutive addresses that follow each other merge into wide LDS writes */
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.ph[l][k] = ph[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.pa[l][k] = pa[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.tip[l][k] = tip[k];
+    /* (the leg points ph / pa / tip are not published here: their only readers, the collision passes and the parts centroid, take
+     * them from a POS_ONLY pass of their own -- ant_contacts runs on another wave at the same time as this phase) */
 #pragma unroll
     for (int k = 0; k < 3; ++k) L.XYZ[k] = X[k];
 #pragma unroll
@@ -1001,12 +998,9 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
  * values on the same record, which is the one-wave-per-env form.
  * qi = index of the position buffer the dynamics work on; integration reads q[qi ^ 1] and writes q[qi]. */
 template <class X>
-HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi, bool integrate_prev, bool dynamics) {
+HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
     x.refresh(); /* keep lane-derived values local to the substep (see GpuExec::refresh) */
     x.stamp(0);
-    if (integrate_prev) x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_integrate(c, L, L.q[qi ^ 1], L.q[qi], lane & 15); });
-    x.stamp(20);
-    if (!dynamics) return;
     /* the phases index bodies as lane >> 2 (four lanes per body in the one-env form): (lane & 15) << 2 gives body = lane & 15 */
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_kin_ankle(c, L, x.reg(lane), L.q[qi], (lane & 15) << 2); });
     x.stamp(1);
@@ -1019,14 +1013,14 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi, bool integrate_prev,
     x.stamp(4);
 }
 
-/* ENV block of a substep: on entry L.q[qi] / L.u / L.ustar and the articulated-body quantities of the group block are in the
- * env's record; on exit L.u holds the constrained, clamped velocity.  Returns the number of contacts kept. */
+/* Contacts and limit rows of ONE env's pose q[qi] into its record L -- executed by whichever wave has the time: it needs the pose
+ * only (the leg points come from a POS_ONLY kinematics pass of its own), so it runs WHILE the leader wave works through the group
+ * block, on the waves that would otherwise wait at the barrier.  Results: the contact / limit lists and L.nC / nL / nS. */
 template <class X>
-HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
-    WaveLds &L = x.lds();
+HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_on) {
     const float *q = L.q[qi];
     x.refresh();
-    x.each([&](int lane) { x.reg(lane).ud = L.ustar[lane & 15]; }); /* the velocity if no row turns up */
+    x.each([&](int lane) { phase_kin_ankle<true>(c, L, x.reg(lane), q, lane); });
     /* contacts in surface-major, sphere-minor order (ballot ranks follow lane order), at most MAXC kept:
      * pass 0 = ground (13 lanes), pass 1 = all lateral half-spaces (13 lanes each), pass 2 = world boxes, then the item
      * cubes near the robot (up to four cubes per pass, 13 lanes each), then the capsule pairs of different legs */
@@ -1134,9 +1128,25 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
         [&](int lane, int rank, const LimitHit &r) { L.ljoint[rank] = lane; L.lsign[rank] = r.sgn; L.ldist[rank] = r.dist; },
         [&](int, const LimitHit &) {});
     x.stamp(6);
+    x.each([&](int lane) {
+        if (lane == 0) {
+            L.nC = nC; L.nL = nL; L.nS = nS;
 #ifdef HRL_WGTIME
-    x.each([&](int lane) { if (lane == 0) L.dbg_rows += (nL + 3 * nC) | (n_cube_passes << 16) | ((nS > 0 ? 1 : 0) << 24); });
+            L.dbg_rows += (nL + 3 * nC) | (n_cube_passes << 16) | ((nS > 0 ? 1 : 0) << 24);
 #endif
+        }
+    });
+}
+
+/* ENV block of a substep, on the env's own wave: on entry L.q[qi] / L.u / L.ustar, the articulated-body quantities of the group
+ * block and the lists of ant_contacts are in the env's record; rows, sweeps, velocity reconstruction and clamp, then the
+ * positions are integrated into L.q[qi ^ 1]. */
+template <class X>
+HRL_DEV void ant_env_block(X &x, const DevCfg &c, int qi) {
+    WaveLds &L = x.lds();
+    x.refresh();
+    const int nC = x.uniform(L.nC), nL = x.uniform(L.nL), nS = x.uniform(L.nS);
+    x.each([&](int lane) { x.reg(lane).ud = L.ustar[lane & 15]; }); /* the velocity if no row turns up */
     x.each([&](int lane) { phase_build_row(c, L, x.reg(lane), lane, nL, nC); });
     if (nS > 0) x.each([&](int lane) { phase_self_rows(c, L, x.reg(lane), lane, nL, nC); });
     x.stamp(7);
@@ -1147,7 +1157,20 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi, bool items_on) {
         if (d >= 6 && d < 14) v = clampf(v, -c.vmax, c.vmax);
         if (lane < 16) L.u[lane] = v;
     });
-    return nC;
+    x.stamp(18);
+    x.each([&](int lane) { phase_integrate(c, L, L.q[qi], L.q[qi ^ 1], lane & 15); });
+    x.stamp(20);
+}
+
+/* Who finds the contacts of which env while the leader (wave 0) runs the group block: wave w those of env w, wave 1 those of the
+ * leader's env 0 as well.  A group of one does everything itself, in order. */
+template <class X>
+HRL_DEV void ant_contact_duty(X &x, const DevCfg &c, int qi, bool items_on) {
+    const int w = x.wave_index();
+    if (x.group_size() == 1) { if (x.uniform(x.lds().on)) ant_contacts(x, c, x.lds(), qi, items_on); return; }
+    if (w == 0) return;
+    if (x.uniform(x.lds(w).on)) ant_contacts(x, c, x.lds(w), qi, items_on);
+    if (w == 1 && x.uniform(x.lds(0).on)) ant_contacts(x, c, x.lds(0), qi, items_on);
 }
 
 
@@ -1807,28 +1830,30 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             HRL_PIN_INT(qi); /* keep the ping-pong index a run-time value so the body is not cloned per parity */
         }
     } else {
-        x.group_sync(); /* every record of the group is loaded before the leader reads it */
+        x.each([&](int lane) { if (lane == 0) L.on = on ? 1 : 0; });
+        x.group_sync(); /* every record of the group is loaded before another wave reads it */
 #pragma unroll 1
-        for (int s = 0; s <= c.nsub; ++s) { /* trip s: integrate substep s - 1, dynamics of substep s | its constraints */
-            if (s > 0) qi ^= 1;
+        for (int s = 0; s < c.nsub; ++s) { /* substep s: dynamics (leader) next to contacts (the other waves) | rows, solve, integrate */
             x.priority(slot + s); /* scheduling only, no effect on results: see GpuExec::priority */
             HRL_PIN_VGPR(qi); /* run-time value: one copy of the bodies for both parities (a vector register: the compiler does not
                                  know that the waves of a group agree on it) */
-#ifndef HRL_ABLATE_GROUP
-            ant_group_block(x, c, qi, s > 0, s < c.nsub);
+#ifndef HRL_ABLATE_GROUP /* timing-ablation builds only (tools/variants.py): never defined in the product */
+            ant_group_block(x, c, qi);
+#endif
+#ifndef HRL_ABLATE_CONTACTS
+            ant_contact_duty(x, c, qi, items_on);
 #endif
             x.stamp(16);
             x.group_sync();
-            x.stamp(17); /* waiting for the leader (the leader: for the stragglers of the previous env block) */
-            if (s < c.nsub) {
-#ifndef HRL_ABLATE_ENV /* timing-ablation builds only (tools/variants.py): never defined in the product */
-                if (on) n_contacts = ant_env_block(x, c, qi, items_on);
+            x.stamp(17); /* waiting for the slower of the leader and the contact waves */
+#ifndef HRL_ABLATE_ENV
+            if (on) ant_env_block(x, c, qi);
 #endif
-                x.stamp(18);
-                x.group_sync();
-                x.stamp(19); /* waiting for the slowest env block of the group */
-            }
+            x.group_sync();
+            x.stamp(19); /* waiting for the slowest env block of the group */
+            qi ^= 1;
         }
+        if (on) n_contacts = x.uniform(L.nC);
     }
     if (!on) return;
     int eo = e; /* the env index again, opaque: the output addresses are formed here, not kept in registers since the loads */

@@ -40,6 +40,8 @@ struct CpuExec {
     template <class F> void leader(F f) { if (grp.G == 1 || wave == 0) each(f); }
     LaneRegs &reg(int lane) { return regs[lane]; }
     int uniform(int v) { return v; }
+    int wave_index() const { return wave; }
+    int group_size() const { return grp.G; }
     void refresh() {}
     int slot() const { return 0; } /* scheduling hints of the device executor: no effect on results */
     void priority(int) const {}
