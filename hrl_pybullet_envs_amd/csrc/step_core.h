@@ -1114,6 +1114,22 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
         }
     }
     x.stamp(5);
+    x.each([&](int lane) {
+        if (lane == 0) {
+            L.nC = nC; L.nS = nS;
+#ifdef HRL_WGTIME
+            L.dbg_rows += (3 * nC) | (n_cube_passes << 16) | ((nS > 0 ? 1 : 0) << 24);
+#endif
+        }
+    });
+}
+
+/* Limit rows of ONE env's pose into its record (L.nL): like ant_contacts a function of the pose alone, run by whichever wave has
+ * the time. */
+template <class X>
+HRL_DEV void ant_limits(X &x, const DevCfg &c, WaveLds &L, int qi) {
+    const float *q = L.q[qi];
+    x.refresh();
     /* joint limits (lane = joint) */
     int nL = x.each_compact(
         [&](int lane) {
@@ -1130,9 +1146,9 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
     x.stamp(6);
     x.each([&](int lane) {
         if (lane == 0) {
-            L.nC = nC; L.nL = nL; L.nS = nS;
+            L.nL = nL;
 #ifdef HRL_WGTIME
-            L.dbg_rows += (nL + 3 * nC) | (n_cube_passes << 16) | ((nS > 0 ? 1 : 0) << 24);
+            L.dbg_rows += nL;
 #endif
         }
     });
@@ -1162,17 +1178,23 @@ HRL_DEV void ant_env_block(X &x, const DevCfg &c, int qi) {
     x.stamp(20);
 }
 
-/* Who finds the contacts of which env while the leader (wave 0) runs the group block: wave w those of env w, wave 1 those of the
- * leader's env 0 as well.  A group of one does everything itself, in order. */
+/* Who finds the contacts and limit rows of which env while the leader (wave 0) runs the group block: wave w those of its own env w;
+ * the leader's env 0 is shared out -- its contacts to wave 1, its limit rows to wave 2 -- so that no wave is busy for longer than
+ * the leader (tools/stamp_profile.py).  A group of one does everything itself, in order. */
 template <class X>
 HRL_DEV void ant_contact_duty(X &x, const DevCfg &c, int qi, bool items_on) {
     const int w = x.wave_index();
-    if (x.group_size() == 1) { if (x.uniform(x.lds().on)) ant_contacts(x, c, x.lds(), qi, items_on); return; }
+    if (x.group_size() == 1) {
+        if (x.uniform(x.lds().on)) { ant_contacts(x, c, x.lds(), qi, items_on); ant_limits(x, c, x.lds(), qi); }
+        return;
+    }
     if (w == 0) return;
-    if (x.uniform(x.lds(w).on)) ant_contacts(x, c, x.lds(w), qi, items_on);
-    if (w == 1 && x.uniform(x.lds(0).on)) ant_contacts(x, c, x.lds(0), qi, items_on);
+    if (x.uniform(x.lds(w).on)) { ant_contacts(x, c, x.lds(w), qi, items_on); ant_limits(x, c, x.lds(w), qi); }
+    if (x.uniform(x.lds(0).on)) {
+        if (w == 1) ant_contacts(x, c, x.lds(0), qi, items_on);
+        if (w == 2) ant_limits(x, c, x.lds(0), qi);
+    }
 }
-
 
 /* ================================================================================================= POINT SUBSTEP
  * point_bot.py:10-74 + assets/player_cube.xml:8: free 10 kg cube (half extent 0.35).  Solid-cube inertia is
