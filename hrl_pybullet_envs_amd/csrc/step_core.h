@@ -988,15 +988,19 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
 }
 
 /* ------------------------------------------------------------------------------------------------ the ant substep
- * A substep is two blocks.  The GROUP block holds the lane-sparse phases -- position integration of the previous substep,
- * then K1, K2, S, B, V: nine bodies / 14 dofs of distinct work per env -- and is executed ONCE for all the envs of a
- * workgroup by its leader wave, 16 lanes per env (lane >> 4 = env of the group, lane & 15 = body / dof): one instruction
- * stream serves four envs instead of four streams serving one each.  The ENV block (contacts, limits, rows, A, sweeps,
- * velocity reconstruction: up to 44 rows of distinct work) is executed by every env's own wave.  A workgroup barrier
- * separates the blocks; inside a block the phases of a wave are separated by wave-level LDS synchronisation only.
- * With a group of one (executor G = 1) the leader is the env's own wave and the four 16-lane slices compute the same
- * values on the same record, which is the one-wave-per-env form.
- * qi = index of the position buffer the dynamics work on; integration reads q[qi ^ 1] and writes q[qi]. */
+ * A substep is two blocks separated by workgroup barriers.
+ * Block 1, two things side by side:
+ *   - the GROUP block (ant_group_block) -- the lane-sparse dynamics K1, K2, S, B, V: nine bodies / 14 dofs of distinct work per
+ *     env -- executed ONCE for all the envs of a workgroup by its leader wave, 16 lanes per env (lane >> 4 = env of the group,
+ *     lane & 15 = body / dof): one instruction stream serves four envs instead of four streams serving one each;
+ *   - contacts and limit rows (ant_contact_duty) -- functions of the pose alone -- on the waves that would otherwise wait for
+ *     the leader.
+ * Block 2 (ant_env_block), on every env's own wave: rows, A, sweeps, velocity reconstruction (up to 44 rows of distinct
+ * work), then the position integration.
+ * Inside a block the phases of a wave are separated by wave-level LDS synchronisation only.
+ * With a group of one (executor G = 1) the only wave does all of it in order, the four 16-lane slices of the group block
+ * computing the same values on the same record: the one-wave-per-env form.
+ * qi = index of the position buffer the substep works on; its integration writes q[qi ^ 1]. */
 template <class X>
 HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
     x.refresh(); /* keep lane-derived values local to the substep (see GpuExec::refresh) */
