@@ -246,6 +246,25 @@ def test_env_counts_that_do_not_fill_the_last_group(n):
     assert all(bool((v[n:] == 7).all()) for v in big.values())
 
 
+@pytest.mark.parametrize('kind', [K.HRL_ANT_GATHER, K.HRL_ANT_MAZE])
+def test_one_wave_per_env_launch_matches_too(kind, monkeypatch):
+    """HRL_STEP_GROUP=1 (the measurement aid: one 64-thread workgroup per env, the same phases in order on the env's own wave)
+    is the same arithmetic: bit-exact against the oracle like the grouped launch."""
+    monkeypatch.setenv('HRL_STEP_GROUP', '1')
+    n = 96
+    g, o = make(kind, n, seed=13, max_episode_steps=23)
+    monkeypatch.delenv('HRL_STEP_GROUP')
+    g.reset(); o.reset()
+    rng = np.random.RandomState(4)
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state), t
+        assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
+        assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
+
+
 def test_mixed_ant_point_shard():
     """BASELINE config 5 shape on one GPU: first half AntGather, second half PointGather, two launches per step."""
     n = 512
