@@ -30,3 +30,16 @@ def test_phases_under_address_sanitizer():
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0', PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, 'tests'))
     r = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'asan-ok' in r.stdout, r.stderr[-3000:]
+
+
+def test_group_threads_under_thread_sanitizer():
+    """The four host threads of a group share its records the way the four waves of a workgroup share LDS (leader dynamics next to
+    the other waves' contact passes, then every wave's own env): ThreadSanitizer must see no pair of accesses that the barriers of
+    step_core.h leave unordered.  Ragged group included (10 envs = 2.5 groups)."""
+    d = os.path.join(ROOT, 'tests', 'emu')
+    fma = ['-mfma'] if 'fma' in open('/proc/cpuinfo').read().split() else []
+    exe = os.path.join(d, 'tsan_driver')
+    subprocess.check_call(['g++', '-O1', '-g', '-std=c++17', '-ffp-contract=off', *fma, '-fsanitize=thread', '-Wno-unknown-pragmas',
+                           '-I' + os.path.join(ROOT, 'include'), '-o', exe, os.path.join(d, 'tsan_driver.cpp'), '-lm', '-lpthread'], cwd=d)
+    r = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS='halt_on_error=1 exitcode=66'), capture_output=True, text=True, timeout=900, cwd=d)
+    assert r.returncode == 0 and 'tsan-ok' in r.stdout and 'WARNING: ThreadSanitizer' not in r.stderr, (r.stdout[-500:], r.stderr[-3000:])
