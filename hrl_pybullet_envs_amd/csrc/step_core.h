@@ -1182,9 +1182,12 @@ HRL_DEV void ant_env_block(X &x, const DevCfg &c, int qi) {
     x.stamp(20);
 }
 
-/* Who finds the contacts and limit rows of which env while the leader (wave 0) runs the group block: wave w those of its own env w;
- * the leader's env 0 is shared out -- its contacts to wave 1, its limit rows to wave 2 -- so that no wave is busy for longer than
- * the leader (tools/stamp_profile.py).  A group of one does everything itself, in order. */
+/* Who finds the contacts and limit rows of which env while the leader (wave 0) runs the group block.  Four envs' worth of work
+ * (contacts 3.1 k cycles, limit rows 0.65 k each) for three waves, none of which should be busy for longer than the leader (7.5 k):
+ *   wave 1: contacts + limits of env 1, limits of env 3            (4.4 k)
+ *   wave 2: contacts + limits of env 2, limits of env 0            (4.4 k)
+ *   wave 3: contacts of env 0 (the leader's), contacts of env 3    (6.3 k)
+ * (tools/stamp_profile.py).  A group of one does everything itself, in order. */
 template <class X>
 HRL_DEV void ant_contact_duty(X &x, const DevCfg &c, int qi, bool items_on) {
     const int w = x.wave_index();
@@ -1193,11 +1196,10 @@ HRL_DEV void ant_contact_duty(X &x, const DevCfg &c, int qi, bool items_on) {
         return;
     }
     if (w == 0) return;
-    if (x.uniform(x.lds(w).on)) { ant_contacts(x, c, x.lds(w), qi, items_on); ant_limits(x, c, x.lds(w), qi); }
-    if (x.uniform(x.lds(0).on)) {
-        if (w == 1) ant_contacts(x, c, x.lds(0), qi, items_on);
-        if (w == 2) ant_limits(x, c, x.lds(0), qi);
-    }
+    if (w == 3 && x.uniform(x.lds(0).on)) ant_contacts(x, c, x.lds(0), qi, items_on);
+    if (x.uniform(x.lds(w).on)) { ant_contacts(x, c, x.lds(w), qi, items_on); if (w != 3) ant_limits(x, c, x.lds(w), qi); }
+    if (w == 1 && x.uniform(x.lds(3).on)) ant_limits(x, c, x.lds(3), qi);
+    if (w == 2 && x.uniform(x.lds(0).on)) ant_limits(x, c, x.lds(0), qi);
 }
 
 /* ================================================================================================= POINT SUBSTEP
