@@ -204,14 +204,15 @@ def main():
         stream = main_stream if len(parts) == 1 else torch.cuda.Stream(device=dev)  # one HIP stream per sub-shard: the launches overlap
         envs.append((kname, env, acts, stream))
     torch.cuda.synchronize(dev)
-    gatherer = ReturnGatherer([(e, s) for _, e, _, s in envs], world) if world > 1 else None
+    gatherer = ReturnGatherer([(e, s) for _, e, _, s in envs], world, counts=[n] * world) if world > 1 else None
+    gather_every = max(1, min(args.gather_every, args.steps))  # a short run (the driver's --steps 20) still gathers inside the timed region
 
     def run(k0, k):
         for t in range(k0, k0 + k):
             for _, env, acts, stream in envs:
                 with torch.cuda.stream(stream):
                     env.step(acts[t % T])
-            if gatherer is not None and (t + 1) % args.gather_every == 0:
+            if gatherer is not None and (t + 1) % gather_every == 0:
                 gatherer.launch()
 
     run(0, args.warmup)
@@ -241,7 +242,7 @@ def main():
     gathered_ok = None
     if gatherer is not None:
         g = gatherer.latest()
-        gathered_ok = bool(g.numel() == world * n and torch.isfinite(g).all())
+        gathered_ok = bool(g is not None and g.numel() == world * n and torch.isfinite(g).all())
     if world > 1:  # all collectives are done: leave the group before rank 0 spends ~25 s of host time on the CPU baseline
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -269,7 +270,7 @@ def main():
             'config': {'workload': f'{shard}, U(-1,1) actions pre-generated on device, auto-reset, max_episode_steps 2000',
                        'envs_per_gpu': n, 'global_envs': world * n,
                        'substeps_per_step': 4, 'parallelism': f'env-sharded x{world}, no data-path collective; '
-                                                              f'RCCL all-gather of episode returns every {args.gather_every} steps'},
+                                                              f'RCCL all-gather of episode returns every {gather_every} steps'},
             'roofline': roofline(dom_kind, dom_env.num_envs, launch_s),
         }
         if args.kind == 'mixed':

@@ -1,7 +1,7 @@
 """ctypes mirror of include/hrl_envs.h (structs + constants only; no library loading here)."""
 import ctypes as C
 
-HRL_ABI_VERSION = 4
+HRL_ABI_VERSION = 5
 HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER, HRL_ANT_MAZE_MJ, HRL_ANT_FLAGRUN = 0, 1, 2, 3, 4, 5
 HRL_STATE_STRIDE = 32
 HRL_QPOS_OFF, HRL_QVEL_OFF, HRL_EPRET_OFF, HRL_INITZ_OFF, HRL_POTENTIAL_OFF = 0, 15, 29, 30, 31

@@ -11,7 +11,7 @@ _lib = None
 
 # every symbol include/hrl_envs.h declares
 SYMBOLS = ['hrl_default_config', 'hrl_obs_dim', 'hrl_act_dim', 'hrl_create', 'hrl_destroy', 'hrl_reset', 'hrl_step',
-           'hrl_get_state', 'hrl_set_state', 'hrl_set_goals', 'hrl_last_error', 'hrl_backend']
+           'hrl_get_state', 'hrl_set_state', 'hrl_set_goals', 'hrl_next_target', 'hrl_last_error', 'hrl_backend']
 
 
 class HrlError(RuntimeError):
@@ -36,6 +36,7 @@ def lib():
         L.hrl_get_state.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p, C.c_void_p]
         L.hrl_set_state.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p, C.c_void_p]
         L.hrl_set_goals.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.hrl_next_target.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p, C.c_void_p]
         L.hrl_default_config.argtypes = [C.c_int32, C.POINTER(K.hrl_config)]
         L.hrl_obs_dim.argtypes = [C.POINTER(K.hrl_config)]
         L.hrl_act_dim.argtypes = [C.POINTER(K.hrl_config)]

@@ -114,7 +114,7 @@ inline std::string validate(const hrl_config *c) {
     if (c->env_kind == HRL_ANT_FLAGRUN) {
         /* ant_flagrun_env.py:17-18: a goal list (max_targets > 0) or goals near the robot (max_target_dist > 0), never both */
         const bool list_mode = c->flag_max_target_dist == 0.f && c->flag_max_targets > 0, close_mode = c->flag_max_targets <= 0 && c->flag_max_target_dist > 0.f;
-        if (!list_mode && !close_mode && !c->flag_manual_goals) return "exactly one of flag_max_targets > 0 (with flag_max_target_dist == 0) and flag_max_target_dist > 0 (with flag_max_targets <= 0) must hold";
+        if (!list_mode && !close_mode) return "exactly one of flag_max_targets > 0 (with flag_max_target_dist == 0) and flag_max_target_dist > 0 (with flag_max_targets <= 0) must hold";
         if (list_mode && c->flag_max_targets > 65535) return "flag_max_targets must be <= 65535";
         if (close_mode && !(c->flag_max_target_dist / 2 > c->tol)) return "flag_max_target_dist / 2 must exceed tol (the per-axis offset is drawn from U(tol, max_target_dist / 2))";
         if (c->flag_timeout > 32767) return "flag_timeout must be <= 32767";

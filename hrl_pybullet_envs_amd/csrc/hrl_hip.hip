@@ -189,11 +189,11 @@ __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__rest
     GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
     reset_entry<KIND>(x, b, *cp, (int)blockIdx.x);
 }
-__global__ __launch_bounds__(64, 4) void k_set_goals(DevBufs b, const DevCfg *__restrict__ cp, const float *goals_xy, int n_goals) {
+__global__ __launch_bounds__(64, 4) void k_set_goals(DevBufs b, const DevCfg *__restrict__ cp, const float *goals_xy, int n_goals, uint8_t *ok) {
     __shared__ WaveLds L[1];
     LaneRegs regs;
     GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
-    set_goals_entry(x, b, *cp, (int)blockIdx.x, goals_xy, n_goals);
+    set_goals_entry(x, b, *cp, (int)blockIdx.x, goals_xy, n_goals, ok);
 }
 using kernel_fn = void (*)(DevBufs, const DevCfg *);
 /* group = envs per workgroup of the step kernel: 4 for the ant kinds (1 selectable for A/B measurements), 1 for the point bot */
@@ -342,11 +342,20 @@ int hrl_set_state(hrl_handle *h, const hrl_buffers *b, const float *qpos, const 
 
 int hrl_set_goals(hrl_handle *h, const hrl_buffers *b, const float *goals_xy, int32_t n_goals, const uint8_t *mask, void *stream) {
     if (!h || !b || !b->state || !b->aux || !b->obs || !b->items || !goals_xy) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: null handle or buffer");
-    if (h->dc.kind != HRL_ANT_FLAGRUN || !h->dc.flag_manual) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: only for AntFlagrun with flag_manual_goals (manual_goal_creation, ant_flagrun_env.py:24)");
+    if (h->dc.kind != HRL_ANT_FLAGRUN || !h->dc.flag_manual) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: only for AntFlagrun with flag_manual_goals (manual_goal_creation, ant_flagrun_env.py:27)");
+    if (h->dc.flag_mtd > 0.f) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: with flag_max_targets < 1 next_target() draws a goal near the robot and ignores the list (ant_flagrun_env.py:113-114): use hrl_next_target");
     if (n_goals < 1 || n_goals > HRL_MAX_GOALS) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: n_goals must be within 1..15");
-    hipLaunchKernelGGL(k_set_goals, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc, goals_xy, (int)n_goals);
+    hipLaunchKernelGGL(k_set_goals, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc, goals_xy, (int)n_goals, (uint8_t *)nullptr);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_set_goals launch");
+}
+
+int hrl_next_target(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, uint8_t *ok, void *stream) {
+    if (!h || !b || !b->state || !b->aux || !b->obs || !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: null handle or buffer");
+    if (h->dc.kind != HRL_ANT_FLAGRUN || !h->dc.flag_manual) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: only for AntFlagrun with flag_manual_goals (manual_goal_creation, ant_flagrun_env.py:27)");
+    hipLaunchKernelGGL(k_set_goals, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc, (const float *)nullptr, 0, ok);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_next_target launch");
 }
 
 const char *hrl_last_error(void) { return g_err.c_str(); }

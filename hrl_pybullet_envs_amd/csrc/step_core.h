@@ -1797,25 +1797,42 @@ HRL_DEV void reset_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     store_env(x, b, c, e);
 }
 
-/* hrl_set_goals for one env: `env.goals = [...]; env.next_target()` of a manual_goal_creation flagrun env
- * (ant_flagrun_env.py:91-118): goal 0 becomes the current one, the others are stacked behind it so that they are popped in
- * the given order; _rewarded is cleared, the potential is left alone, the observation is calc_state towards the new goal */
+/* hrl_set_goals / hrl_next_target for one env: `env.goals = [...]` (n_goals > 0) and `env.next_target()` of a
+ * manual_goal_creation flagrun env (ant_flagrun_env.py:45,112-120).  The list is kept in list order behind the current goal
+ * (items[2 + 2k..] = goals[k]); next_target() takes the LAST one (`self.goals.pop()`, :116), or with max_targets < 1 draws a
+ * goal near the robot whatever the list holds (:113-114); _rewarded is cleared (:118), the potential is left alone (:119
+ * re-reads the stale walk_target_dist), the observation is calc_state towards the new goal (:120).  ok[e] = 0 where the
+ * reference raises IndexError (empty list): nothing but the observation is written then. */
 template <class X>
-HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, const float *goals_xy, int n_goals) {
+HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, const float *goals_xy, int n_goals, uint8_t *ok) {
     if (b.mask && !b.mask[e]) return;
     WaveLds &L = x.lds();
+    const long long env = c.env_id_offset + e;
     load_env(x, b, c, e, false);
-    x.each([&](int lane) {
-        if (lane < 32) {
-            const int k = lane >> 1, comp = lane & 1; /* items word `lane`: goal slot k (0 current, 1.. pending stack) */
-            float v = 0.f;
-            if (k == 0) v = goals_xy[(size_t)e * n_goals * 2 + comp];
-            else if (k < n_goals) v = goals_xy[((size_t)e * n_goals + (n_goals - k)) * 2 + comp];
-            L.items[lane] = v;
-        }
-        if (lane == 63) L.aux[3] = (int)(((uint32_t)(n_goals - 1) & 0xffffu) | ((uint32_t)L.aux[3] & 0x7fff0000u));
+    if (n_goals > 0) {
+        x.each([&](int lane) {
+            if (lane >= 2 && lane < 32) { /* items word `lane`: pending slot (lane - 2) >> 1 */
+                const int k = (lane - 2) >> 1, comp = lane & 1;
+                L.items[lane] = k < n_goals ? goals_xy[((size_t)e * n_goals + k) * 2 + comp] : 0.f;
+            }
+            if (lane == 63) L.aux[3] = (int)(((uint32_t)n_goals & 0xffffu) | ((uint32_t)L.aux[3] & 0xffff0000u));
+        });
+    }
+    x.each([&](int lane) { /* next_target(): one lane reads and writes the goal words */
+        if (lane != 0) return;
+        const uint32_t a3 = (uint32_t)L.aux[3];
+        uint32_t cur = a3 & 0xffffu;
+        int good = 1;
+        float gx = L.items[0], gy = L.items[1];
+        if (c.flag_mtd > 0.f) {
+            cur = (cur + 1u) & 0xffffu;
+            flag_close_goal(c, env, (uint32_t)L.aux[2], cur, L.st[0], L.st[1], &gx, &gy);
+        } else if (cur == 0u) good = 0;
+        else { cur -= 1u; gx = L.items[2 + 2 * cur]; gy = L.items[3 + 2 * cur]; }
+        if (good) { L.items[0] = gx; L.items[1] = gy; L.aux[3] = (int)(cur | (a3 & 0x7fff0000u)); }
+        if (ok) ok[e] = (uint8_t)good;
     });
-    compute_obs<5>(x, c, c.env_id_offset + e, false);
+    compute_obs<5>(x, c, env, false);
     store_env(x, b, c, e);
 }
 
@@ -1922,9 +1939,10 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             L.red[0] = pot;
             int steps = ((L.aux[3] >> 16) & 0x7fff) + 1, rewarded = (L.aux[3] >> 31) & 1, cur = L.aux[3] & 0xffff, retarget = 0;
             /* goals left: the shared list has flag_max_targets of them, max_target_dist mode never runs out (:111-112), manual
-             * mode counts its pending goals in `cur` (downwards) */
-            const int step_cur = c.flag_manual ? -1 : 1;
-            auto more = [&]() { return c.flag_manual ? cur > 0 : (c.flag_mtd > 0.f || cur < c.flag_max_targets); };
+             * list mode counts its pending goals in `cur` (downwards) */
+            const bool close = c.flag_mtd > 0.f, listed = c.flag_manual && !close; /* max_targets < 1: goals near the robot whoever made the env (:113-114) */
+            const int step_cur = listed ? -1 : 1;
+            auto more = [&]() { return close ? true : (listed ? cur > 0 : cur < c.flag_max_targets); };
             rew = (alive + progress) * 1.f;
             done = idone;
             if (wtd < c.tol) {
@@ -1977,12 +1995,12 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
         if (lane == 8 && KIND == 5) L.aux[3] = L.flags[4];
-        if (lane == 9 && KIND == 5 && c.flag_manual && L.flags[3]) { /* goals.pop() (ant_flagrun_env.py:114): the top of the pending stack */
+        if (lane == 9 && KIND == 5 && c.flag_manual && !(c.flag_mtd > 0.f) && L.flags[3]) { /* goals.pop() (ant_flagrun_env.py:116): the last goal of the pending list */
             const int top = L.flags[4] & 0xffff;
             const float gx = L.items[2 + 2 * top], gy = L.items[3 + 2 * top];
             L.items[0] = gx; L.items[1] = gy;
         }
-        if (lane == 9 && KIND == 5 && !c.flag_manual && c.flag_mtd > 0.f && L.flags[3]) { /* set_target(*create_close_target()) around the robot's xy */
+        if (lane == 9 && KIND == 5 && c.flag_mtd > 0.f && L.flags[3]) { /* set_target(*create_close_target()) around the robot's xy */
             float gx, gy;
             flag_close_goal(c, env, (uint32_t)L.aux[2], (uint32_t)L.flags[4] & 0xffffu, L.st[0], L.st[1], &gx, &gy);
             L.items[0] = gx; L.items[1] = gy;

@@ -20,8 +20,10 @@ def shard_range(total_envs, rank, world):
     return offset, count
 
 
-def init_distributed(expected_world=None, backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  Returns (rank, world, local_rank)."""
+def init_distributed(expected_world=None, backend=None, force=False):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  Returns (rank, world, local_rank).
+    A world of one needs no process group; `force` creates it anyway (a one-rank RCCL communicator: what the `-m gpu`
+    test of the collective path runs on a one-GPU box)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -29,7 +31,7 @@ def init_distributed(expected_world=None, backend=None):
         raise RuntimeError(f'--gpus {expected_world} but WORLD_SIZE={world}: launch with '
                            f'python -m torch.distributed.run --nproc-per-node {expected_world} ... '
                            f'(bench.py spawns the ranks itself when WORLD_SIZE is unset)')
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -49,7 +51,7 @@ def all_gather_returns(local, world, out=None, counts=None):
     `shard_range`) makes uneven shards legal: every rank pads to max(counts), the padding is trimmed after the
     collective.  Without `counts` the shards must be equal, which is checked by the shape of `out` only -- so callers
     with uneven shards MUST pass counts (an unequal all_gather_into_tensor hangs on RCCL)."""
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local.clone() if out is None else out.copy_(local)
     if counts is not None and len(set(counts)) > 1:
         if len(counts) != world or local.numel() != counts[dist.get_rank()]:
@@ -80,28 +82,46 @@ class ReturnGatherer:
     16 KiB per rank at 4096 envs: latency-bound, so only the collective runs on a side stream; `latest()` waits for it.
     The snapshot of info[:, 2] is taken ON THE STEP STREAM of each env (a 16 KiB device copy, ordered before the next
     hrl_step that overwrites `info`), then the side stream waits for that snapshot: the gathered values always belong
-    to one step.  `envs` is one BatchedEnv or a list of (env, stream) pairs (mixed shards step on their own streams)."""
+    to one step.  Snapshot and result buffers are double-buffered: a launch only waits for the collective of TWO
+    launches ago (long done), so the step streams never stall behind a collective in flight.
+    `envs` is one BatchedEnv or a list of (env, stream) pairs (mixed shards step on their own streams).
+    `counts` = every rank's shard size (e.g. from `shard_range`); None = equal shards.  Uneven shards without `counts`
+    would make `all_gather_into_tensor` hang on RCCL, so the sizes are exchanged once here when a group exists."""
 
-    def __init__(self, envs, world):
+    def __init__(self, envs, world, counts=None):
         if not isinstance(envs, (list, tuple)):
             envs = [(envs, None)]
         self.parts, self.world = list(envs), world
         dev = self.parts[0][0].device
         n = sum(e.num_envs for e, _ in self.parts)
+        if counts is None and dist.is_initialized() and dist.get_world_size() == world:
+            sizes = [None] * world
+            dist.all_gather_object(sizes, n)
+            counts = [int(c) for c in sizes]
+        if counts is not None:
+            counts = [int(c) for c in counts]
+            if len(counts) != world or (dist.is_initialized() and counts[dist.get_rank()] != n):
+                raise ValueError(f'counts {counts} do not describe a world of {world} with {n} envs on this rank')
+        self.counts = counts
+        total = sum(counts) if counts is not None else world * n
         self.stream = torch.cuda.Stream(device=dev)
-        self.local = torch.empty(n, dtype=torch.float32, device=dev)
-        self.out = torch.empty(world * n, dtype=torch.float32, device=dev)
-        self.done_event = None
+        self.local = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.out = [torch.empty(total, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.done_event = [None, None]
+        self.k = 0          # launches so far
+        self.last = None    # buffer index of the latest launch
 
     def launch(self):
-        if self.done_event is not None:  # the previous collective still reads self.local: order the new snapshot after it
+        b = self.k & 1
+        self.k += 1
+        if self.done_event[b] is not None:  # the collective of two launches ago read self.local[b]: order the new snapshot after it
             for env, st in self.parts:
-                (st or torch.cuda.current_stream(env.device)).wait_event(self.done_event)
+                (st or torch.cuda.current_stream(env.device)).wait_event(self.done_event[b])
         off, ready = 0, []
         for env, st in self.parts:
             st = st or torch.cuda.current_stream(env.device)
             with torch.cuda.stream(st):
-                self.local[off:off + env.num_envs].copy_(env.info[:, 2])
+                self.local[b][off:off + env.num_envs].copy_(env.info[:, 2])
                 ev = torch.cuda.Event()
                 ev.record(st)
             ready.append(ev)
@@ -109,11 +129,14 @@ class ReturnGatherer:
         with torch.cuda.stream(self.stream):
             for ev in ready:
                 self.stream.wait_event(ev)
-            all_gather_returns(self.local, self.world, self.out)
-            self.done_event = torch.cuda.Event()
-            self.done_event.record(self.stream)
+            all_gather_returns(self.local[b], self.world, self.out[b], counts=self.counts)
+            self.done_event[b] = torch.cuda.Event()
+            self.done_event[b].record(self.stream)
+        self.last = b
 
     def latest(self):
-        if self.done_event is not None:
-            self.done_event.synchronize()
-        return self.out
+        """The result of the most recent launch (waits for it); None before the first launch."""
+        if self.last is None:
+            return None
+        self.done_event[self.last].synchronize()
+        return self.out[self.last]

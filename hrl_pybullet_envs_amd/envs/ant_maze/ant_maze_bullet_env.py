@@ -28,3 +28,27 @@ class AntMazeBulletEnv(BatchedGymEnv):
         self.done_at_target, self.max_steps, self.tol = done_at_target, max_steps, tol
         self.inner_rew_weight, self.targ_dist_rew, self.target_encoding, self.debug = inner_rew_weight, targ_dist_rew, target_encoding, debug
         self._finish_init(cfg, num_envs, device, seed)
+
+    # ant_maze_bullet_env.py:38,46,108-110: attributes a trainer reads between steps, over the state tensors
+    @property
+    def t(self):
+        """Episode step counter (:78, :107)."""
+        t = self._backend().aux[:, 0]
+        return int(t[0]) if self.num_envs == 1 else t
+
+    @property
+    def target(self):
+        """The episode's target (:46, :110): np.ndarray(2) for one env, [N, 2] tensor for a batch."""
+        import torch
+        env = self._backend()
+        tab = torch.tensor([[self._cfg.targets[i][0], self._cfg.targets[i][1]] for i in range(self._cfg.n_targets)], device=env.device)
+        tg = tab[env.aux[:, 3].long().clamp(0, self._cfg.n_targets - 1)]
+        return tg[0].double().cpu().numpy() if self.num_envs == 1 else tg
+
+    def _walk_target(self):
+        import torch
+        tg = self.target
+        return tg[None].astype(np.float64) if self.num_envs == 1 else tg.double().cpu().numpy()
+
+    walk_target_x = property(lambda self: self.robot.walk_target_x)
+    walk_target_y = property(lambda self: self.robot.walk_target_y)

@@ -5,7 +5,7 @@ import numpy as np
 from ... import _capi as K
 from ... import _lib
 from ..base import BatchedGymEnv
-from .ant_maze_bullet_env import PositionEncoding
+from .ant_maze_bullet_env import AntMazeBulletEnv, PositionEncoding
 
 _eval_target = [-2, 4]
 _targets = ([2, -4], [2, 0], [2, 4], [0, 4], _eval_target)  # ant_maze_mj_env.py:13-14
@@ -23,3 +23,9 @@ class AntMazeMjEnv(BatchedGymEnv):
         self.n_bins, self.sensor_range, self.sensor_span = n_bins, float(sensor_range), sensor_span
         self.targets, self.tol, self.inner_rew_weight, self.target_encoding, self.debug = targets, tol, inner_rew_weight, target_encoding, debug
         self._finish_init(cfg, num_envs, device, seed)
+
+    t = AntMazeBulletEnv.t                      # ant_maze_mj_env.py:38,70
+    target = AntMazeBulletEnv.target            # :44,:91
+    _walk_target = AntMazeBulletEnv._walk_target
+    walk_target_x = AntMazeBulletEnv.walk_target_x
+    walk_target_y = AntMazeBulletEnv.walk_target_y

@@ -120,6 +120,16 @@ class BatchedGymEnv:
         return draw_env(self._cfg, st, items, size)
 
     _gather_info = False
+    _centroid_obs = True  # kinds whose walk target distance is measured from upstream's parts centroid (SURVEY A.5)
+
+    def _walk_target(self):
+        """[N, 2] numpy: what `robot.walk_target_x/y` hold.  Default: the constructor's walk target (upstream's (1e3, 0))."""
+        return np.tile(np.array([[self._cfg.walk_target[0], self._cfg.walk_target[1]]], np.float64), (self.num_envs, 1))
+
+    @property
+    def robot(self):
+        from .robot_view import RobotView
+        return RobotView(self)
 
     @property
     def unwrapped(self):

@@ -10,6 +10,7 @@ class AntGatherBulletEnv(BatchedGymEnv):
     FOOD = 'food'
     POISON = 'poison'
     _gather_info = True
+    _centroid_obs = False  # the gather envs drop the target terms (ant_gather_env.py:81): the step never forms the centroid
 
     def __init__(self,
                  n_food=8,

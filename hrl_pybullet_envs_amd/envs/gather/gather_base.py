@@ -14,6 +14,7 @@ class GatherBulletEnv(BatchedGymEnv):
     FOOD = 'food'
     POISON = 'poison'
     _gather_info = True
+    _centroid_obs = False  # the gather envs drop the target terms (ant_gather_env.py:81): the step never forms the centroid
 
     def __init__(self,
                  robot,
@@ -34,7 +35,7 @@ class GatherBulletEnv(BatchedGymEnv):
         kind = getattr(robot, 'env_kind', None)
         if kind not in (K.HRL_POINT_GATHER, K.HRL_ANT_GATHER):
             raise TypeError('GatherBulletEnv needs a robot the batched step knows (PointBot, or env_kind = HRL_ANT_GATHER)')
-        self.robot = robot
+        self._robot = robot
         cfg = _lib.default_config(kind, n_food=int(n_food), n_poison=int(n_poison),
                                   world_size=tuple(float(w) for w in world_size), n_bins=int(n_bins),
                                   sensor_range=float(sensor_range), sensor_span=float(sensor_span),
@@ -47,3 +48,12 @@ class GatherBulletEnv(BatchedGymEnv):
         self.spacing, self.respawn, self.debug = robot_object_spacing, respawn, debug
         self.walk_target_x = self.walk_target_y = 0
         self._finish_init(cfg, num_envs, device, seed)
+
+    @property
+    def robot(self):
+        """The robot object handed to the constructor (gather_base.py:31), with the live pose attributes of the batched state."""
+        from ..robot_view import RobotView
+        view = RobotView(self)
+        for name in ('body_real_xyz', 'body_xyz', 'body_rpy'):
+            setattr(self._robot, name, getattr(view, name))
+        return self._robot

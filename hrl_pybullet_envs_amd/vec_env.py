@@ -87,6 +87,15 @@ class BatchedEnv:
         self._last_goals = goals  # keep alive until the stream has consumed it
         return self.obs
 
+    def next_target(self, mask=None):
+        """AntFlagrun with flag_manual_goals: `env.next_target()` for every (masked) env (include/hrl_envs.h: hrl_next_target).
+        Returns (obs, ok): ok[i] == 0 where the reference raises IndexError (empty list; that env is unchanged)."""
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        ok = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hrl_next_target(self._h, C.byref(self._bufs), None if m is None else m.data_ptr(), ok.data_ptr(), self._stream()))
+        return self.obs, ok
+
     # state access (identical-state parity tests)
     @property
     def qpos(self):

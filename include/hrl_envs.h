@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HRL_ABI_VERSION 4
+#define HRL_ABI_VERSION 5
 
 /* env kinds */
 #define HRL_ANT_FLAT 0     /* AntMjEnv: flat ground, obs 29 (envs/MjAnt.py:31-97)                        */
@@ -49,7 +49,7 @@ extern "C" {
 #define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
 #define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
 #define HRL_MAX_TARGETS 8
-#define HRL_MAX_GOALS 15    /* flagrun manual goals per hrl_set_goals call: items[0..1] current, items[2..31] pending */
+#define HRL_MAX_GOALS 15    /* flagrun manual goals per hrl_set_goals call: items[0..1] current, items[2..31] the pending list in list order */
 
 /* status codes */
 #define HRL_OK 0
@@ -124,9 +124,11 @@ typedef struct hrl_config {
      * its position, redrawn until it lies inside the arena (ant_flagrun_env.py:80-89); the episode then never runs out
      * of goals.  The current goal is kept in items[0..1], so `items` must be provided. */
     float flag_max_target_dist;
-    /* manual_goal_creation (ant_flagrun_env.py:24,149-152): reset neither draws goals nor changes the current one; goals
-     * are pushed from outside with hrl_set_goals().  The current goal lives in items[0..1], the pending ones behind it,
-     * so `items` must be provided.  flag_max_targets / flag_max_target_dist are ignored. */
+    /* manual_goal_creation (ant_flagrun_env.py:27,150-153): reset neither draws goals nor changes the current one; goals
+     * come from outside: hrl_set_goals() (`env.goals = [...]; env.next_target()`) and hrl_next_target().  The current goal
+     * lives in items[0..1], the pending list behind it, so `items` must be provided.  As in the reference, next_target()
+     * pops the list when flag_max_targets > 0 and draws a goal near the robot (ignoring the list) when flag_max_targets < 1
+     * (flag_max_target_dist > 0), :113-116; the constructor's either-or rule (:17-18) holds for manual envs too. */
     int32_t flag_manual_goals;
     hrl_model model;
 } hrl_config;
@@ -174,11 +176,20 @@ int hrl_get_state(hrl_handle *h, const hrl_buffers *bufs, float *qpos, float *qv
 int hrl_set_state(hrl_handle *h, const hrl_buffers *bufs, const float *qpos, const float *qvel, void *stream);
 
 /* AntFlagrunBulletEnv with manual_goal_creation: replaces `env.goals = [...]; env.next_target()`
- * (ant_flagrun_env.py:91-118): goals_xy[N][n_goals][2] (device), visited in the given order; goal 0 becomes the
- * current target at once (set_target + calc_state: bufs->obs is refreshed, the potential is left as it is, :116),
- * the others are taken one by one as goals are reached or time out; the episode ends when they run out (:193-194).
- * 1 <= n_goals <= HRL_MAX_GOALS.  Envs with mask[i] == 0 are left alone (mask == NULL: all). */
+ * (ant_flagrun_env.py:45,112-120): goals_xy[N][n_goals][2] (device) is every env's list.  As in the reference next_target()
+ * is `self.goals.pop()`: the LAST goal of the list becomes the current target at once (set_target + calc_state: bufs->obs is
+ * refreshed, the potential is left as it is, :119), the others follow from the back of the list to its front as goals are
+ * reached or time out; the episode ends when they run out (IndexError, :193-194).  1 <= n_goals <= HRL_MAX_GOALS.
+ * Envs with mask[i] == 0 are left alone (mask == NULL: all).  Rejected when flag_max_targets < 1: next_target() then draws
+ * goals near the robot and never reads the list (:113-114). */
 int hrl_set_goals(hrl_handle *h, const hrl_buffers *bufs, const float *goals_xy, int32_t n_goals, const uint8_t *mask, void *stream);
+
+/* `env.next_target()` alone (ant_flagrun_env.py:112-120) of a manual_goal_creation env: pops the last pending goal, or with
+ * flag_max_targets < 1 draws a goal near the robot (create_close_target, :80-89); clears _rewarded, refreshes bufs->obs.
+ * ok (device, [N], may be NULL): 1, or 0 for an env whose list is empty -- the reference raises IndexError there; such an
+ * env is left unchanged.  (The pending list itself is plain data in the caller's `items` / `aux` tensors: `env.goals = [...]`
+ * without next_target() is items[2 + 2k..] = goals[k], aux[3] low 16 bits = len(goals).) */
+int hrl_next_target(hrl_handle *h, const hrl_buffers *bufs, const uint8_t *mask, uint8_t *ok, void *stream);
 
 /* Last error text of the calling thread ("" if none). */
 const char *hrl_last_error(void);

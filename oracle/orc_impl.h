@@ -1442,15 +1442,47 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     }
 }
 
-/* `env.goals = [...]; env.next_target()` of a manual_goal_creation flagrun env (ant_flagrun_env.py:91-118), see
- * hrl_set_goals() in include/hrl_envs.h: goal 0 becomes the current one, the others are stacked so that they are popped
- * in the given order; _rewarded is cleared (:115), the potential is left alone (:116 re-reads the value step() has just
- * stored), the returned state is calc_state() towards the new goal (:117). */
-void FN(orc_env_set_goals_one)(const FN(orc_env) * E, REAL *st, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals, REAL *obs) {
-    items[0] = goals_xy[0]; items[1] = goals_xy[1];
-    for (int k = 1; k < n_goals; ++k) { items[2 + 2 * (n_goals - 1 - k)] = goals_xy[2 * k]; items[3 + 2 * (n_goals - 1 - k)] = goals_xy[2 * k + 1]; }
-    for (int i = 2 * n_goals; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
-    aux[3] = (int32_t)(((uint32_t)(n_goals - 1) & 0xffffu) | ((uint32_t)aux[3] & 0x7fff0000u));
+/* `env.goals = [...]` of a manual_goal_creation flagrun env (ant_flagrun_env.py:45,96,150): the pending list, in list order,
+ * behind the current goal in the items record (items[2 + 2k..] = goals[k]); its length in the low 16 bits of aux[3]. */
+void FN(orc_flag_goals_assign)(REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals) {
+    for (int k = 0; k < n_goals; ++k) { items[2 + 2 * k] = goals_xy[2 * k]; items[3 + 2 * k] = goals_xy[2 * k + 1]; }
+    for (int i = 2 + 2 * n_goals; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+    aux[3] = (int32_t)(((uint32_t)n_goals & 0xffffu) | ((uint32_t)aux[3] & 0xffff0000u));
+}
+
+/* `env.next_target()` (ant_flagrun_env.py:112-120) called from outside step(): max_targets < 1 -> set_target(*create_close_target())
+ * (:113-114, the list is ignored); else set_target(*self.goals.pop()) -- the LAST element of the list (:116) -- or IndexError
+ * when it is empty (returns 0, nothing changed).  _rewarded is cleared (:118); steps_since_goal_change is not touched; the
+ * potential is left alone (:119 re-reads the walk_target_dist of the last calc_state, which is what the stored potential was
+ * computed from).  Returns 1 on success. */
+int FN(orc_flag_next_target)(const hrl_config *cfg, int64_t env, const REAL *st, REAL *items, int32_t *aux) {
+    uint32_t a3 = (uint32_t)aux[3], cur = a3 & 0xffffu;
+    if (cfg->flag_max_target_dist > 0) { /* max_targets < 1 (:17-18): the goal counter of the episode keys the draw */
+        REAL g2[2];
+        cur = (cur + 1) & 0xffffu;
+        FN(flag_close_goal)(cfg, env, (uint32_t)aux[2], cur, st, g2);
+        items[0] = g2[0]; items[1] = g2[1];
+    } else {
+        if (cur == 0) return 0;
+        cur -= 1;
+        items[0] = items[2 + 2 * cur]; items[1] = items[3 + 2 * cur];
+    }
+    aux[3] = (int32_t)(cur | (a3 & 0x7fff0000u));
+    return 1;
+}
+
+/* hrl_set_goals() of include/hrl_envs.h: `env.goals = [...]; env.next_target()`; the returned state is calc_state() towards
+ * the new goal (:120). */
+void FN(orc_env_set_goals_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals, REAL *obs) {
+    FN(orc_flag_goals_assign)(items, aux, goals_xy, n_goals);
+    FN(orc_flag_next_target)(&E->cfg, env, st, items, aux);
+    REAL feet[4] = {0, 0, 0, 0};
+    FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0);
+}
+/* hrl_next_target() of include/hrl_envs.h: `env.next_target()` alone; ok = 0 where the reference raises IndexError */
+void FN(orc_env_next_target_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, REAL *obs, uint8_t *ok) {
+    const int r = FN(orc_flag_next_target)(&E->cfg, env, st, items, aux);
+    if (ok) *ok = (uint8_t)r;
     REAL feet[4] = {0, 0, 0, 0};
     FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0);
 }
@@ -1507,7 +1539,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
                                                      (ant_flagrun_env.py:133-135), then ant_flagrun_env.py:162-204 */
         REAL wtd, s28[28], rpy[3], tgt[2];
         int nlim, steps = (aux[3] >> 16) & 0x7fff, rewarded = (aux[3] >> 31) & 1, cur = aux[3] & 0xffff, retarget;
-        const int close_mode = cfg->flag_max_target_dist > 0 && !cfg->flag_manual_goals, manual = cfg->flag_manual_goals;
+        const int close_mode = cfg->flag_max_target_dist > 0, manual = cfg->flag_manual_goals && !close_mode; /* manual: the pending list is popped (:116); max_targets < 1: create_close_target whoever made the env (:113-114) */
         FN(flag_current_goal)(cfg, items, aux, tgt);
         FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy, 0);
         REAL alive = (s28[0] + st[HRL_INITZ_OFF] > R_(0.26)) ? R_(1) : R_(-1);
@@ -1589,8 +1621,18 @@ void FN(orc_set_goals_batch)(const hrl_config *cfg, REAL *state, REAL *items, in
     int od = orc_obs_dim(cfg);
     for (int i = 0; i < cfg->num_envs; ++i) {
         if (mask && !mask[i]) continue;
-        FN(orc_env_set_goals_one)(&E, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * HRL_ITEMS_STRIDE, aux + (size_t)i * HRL_AUX_STRIDE,
+        FN(orc_env_set_goals_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * HRL_ITEMS_STRIDE, aux + (size_t)i * HRL_AUX_STRIDE,
                                   goals_xy + (size_t)i * n_goals * 2, n_goals, obs + (size_t)i * od);
+    }
+}
+void FN(orc_next_target_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const uint8_t *mask, REAL *obs, uint8_t *ok) {
+    FN(orc_env) E;
+    FN(orc_env_init)(cfg, &E);
+    int od = orc_obs_dim(cfg);
+    for (int i = 0; i < cfg->num_envs; ++i) {
+        if (mask && !mask[i]) continue;
+        FN(orc_env_next_target_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * HRL_ITEMS_STRIDE, aux + (size_t)i * HRL_AUX_STRIDE,
+                                    obs + (size_t)i * od, ok ? ok + i : 0);
     }
 }
 

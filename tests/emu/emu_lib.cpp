@@ -131,7 +131,15 @@ int emu_set_goals(const hrl_config *cfg, const hrl_buffers *b, const float *goal
     if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN || !cfg->flag_manual_goals || n_goals < 1 || n_goals > HRL_MAX_GOALS) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, mask);
-    for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; set_goals_entry(x, d, c, e, goals_xy, n_goals); }
+    if (cfg->flag_max_target_dist > 0.f) return HRL_ERR_BAD_ARG;
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; set_goals_entry(x, d, c, e, goals_xy, n_goals, nullptr); }
+    return HRL_OK;
+}
+int emu_next_target(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, uint8_t *ok, int reverse) {
+    if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN || !cfg->flag_manual_goals) return HRL_ERR_BAD_ARG;
+    DevCfg c; build_devcfg(*cfg, c);
+    DevBufs d = to_dev(b, mask);
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; set_goals_entry(x, d, c, e, nullptr, 0, ok); }
     return HRL_OK;
 }
 int emu_lds_bytes(void) { return (int)sizeof(WaveLds); }

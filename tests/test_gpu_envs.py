@@ -179,3 +179,69 @@ def test_flagrun_manual_goal_creation_class_api_and_render():
     ob = b.set_goals(torch.rand(32, 3, 2) * 4 - 2)
     assert ob.shape == (32, 28) and ob.is_cuda and b.goal.shape == (32, 2)
     b.close()
+
+
+def test_rccl_world_of_one_return_gather_on_the_side_stream():
+    """The collective path on real hardware with the one GPU a test box has: a ONE-rank RCCL communicator
+    (`init_process_group('nccl')` loads librccl), `ReturnGatherer.launch()` / `latest()` next to stepping -- snapshot on the step
+    stream, `all_gather_into_tensor` on device tensors on the side stream, double-buffered.  Every gathered vector must be the
+    episode returns of exactly the step it was launched after (dist.py:23-119, BASELINE.json configs[4])."""
+    import socket
+    import torch.distributed as dist
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.dist import ReturnGatherer, all_gather_returns, init_distributed
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+    import os
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    saved = {k: os.environ.get(k) for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    try:
+        rank, world, lr = init_distributed(1, backend='nccl', force=True)
+        assert (rank, world, lr) == (0, 1, 0) and dist.is_initialized() and dist.get_backend() == 'nccl'
+        n = 2048
+        ant = BatchedEnv(_lib.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=2, auto_reset=1), 'cuda:0')
+        pt = BatchedEnv(_lib.default_config(K.HRL_POINT_GATHER, num_envs=n, seed=2, auto_reset=1, env_id_offset=n), 'cuda:0')
+        ant.reset(); pt.reset()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        g = ReturnGatherer([(ant, s1), (pt, s2)], world)   # sizes exchanged through the group (all_gather_object)
+        assert g.counts == [2 * n] and g.latest() is None
+        gen = torch.Generator(device='cuda').manual_seed(3)
+        a8 = torch.rand(30, n, 8, device='cuda', generator=gen) * 2 - 1
+        a2 = torch.rand(30, n, 2, device='cuda', generator=gen) * 2 - 1
+        expect = {}
+        for t in range(30):
+            with torch.cuda.stream(s1):
+                ant.step(a8[t])
+            with torch.cuda.stream(s2):
+                pt.step(a2[t])
+            if (t + 1) % 3 == 0:        # far more often than bench.py: consecutive collectives overlap the next steps
+                g.launch()
+                torch.cuda.synchronize()
+                expect[t] = torch.cat([ant.info[:, 2], pt.info[:, 2]]).clone()
+                assert torch.equal(g.latest(), expect[t]), t
+        # without the synchronize in between: the gathered values still belong to the step they were launched after
+        for t in range(6):
+            with torch.cuda.stream(s1):
+                ant.step(a8[t])
+            with torch.cuda.stream(s2):
+                pt.step(a2[t])
+            g.launch()
+        got = g.latest().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, torch.cat([ant.info[:, 2], pt.info[:, 2]]))
+        # the plain function on device tensors through RCCL, and the uneven-shard validation
+        x = torch.arange(100, dtype=torch.float32, device='cuda')
+        assert torch.equal(all_gather_returns(x, 1), x)
+        with pytest.raises(ValueError):
+            ReturnGatherer([(ant, s1)], 1, counts=[n + 1])
+        assert 'librccl' in open('/proc/self/maps').read()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -209,6 +209,62 @@ def test_mixed_shard_full_size_two_streams():
     assert returns.shape == (2 * n,) and bool(torch.isfinite(returns).all())
 
 
+def test_rank7_shard_of_config5_global_ids():
+    """BASELINE.json configs[4] = 32768 global ids over 8 ranks; rank 7 owns ids 28672..32767: its first half AntGather, its
+    second half PointGather (bench.py --kind mixed).  One GPU runs that shard with `env_id_offset` as rank 7 would; 256 sampled
+    rows of each half are re-run on the oracle at their GLOBAL ids (resets and respawns draw from streams keyed by them)."""
+    n, off = 2048, 7 * 4096
+    ant, _ = make(K.HRL_ANT_GATHER, n, seed=0, env_id_offset=off, max_episode_steps=25)
+    pt, _ = make(K.HRL_POINT_GATHER, n, seed=0, env_id_offset=off + n, max_episode_steps=25)
+    ant.reset(); pt.reset()
+    # reset parity at the global ids (the oracle as one shard at the same offset)
+    _, oa = make(K.HRL_ANT_GATHER, 64, seed=0, env_id_offset=off + 1000, max_episode_steps=25)
+    oa.reset()
+    assert np.array_equal(ant.state[1000:1064].cpu().numpy(), oa.state) and np.array_equal(ant.items[1000:1064].cpu().numpy(), oa.items)
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    a8 = torch.rand(31, n, 8, device='cuda', generator=gen) * 2 - 1
+    a2 = torch.rand(31, n, 2, device='cuda', generator=gen) * 2 - 1
+    for t in range(30):  # past the 25-step time limit: every env has been auto-reset from its global-id stream
+        ant.step(a8[t]); pt.step(a2[t])
+    rows = np.random.RandomState(6).choice(n, 256, replace=False)
+    pre = [(e.state.cpu().numpy(), e.items.cpu().numpy(), e.aux.cpu().numpy()) for e in (ant, pt)]
+    assert pre[0][2][:, 2].min() >= 2
+    _, ra, da, _ = ant.step(a8[30])
+    _, rp, dp, _ = pt.step(a2[30])
+    torch.cuda.synchronize()
+    sampled_row_parity(K.HRL_ANT_GATHER, ant, rows, *pre[0], a8[30].cpu().numpy(), ra, da, seed=0, max_episode_steps=25)
+    sampled_row_parity(K.HRL_POINT_GATHER, pt, rows, *pre[1], a2[30].cpu().numpy(), rp, dp, seed=0, max_episode_steps=25)
+    # the same ids inside a 32768-env single-GPU launch give the same trajectories (shard invariance at the top of the range)
+    small, _ = make(K.HRL_ANT_GATHER, 128, seed=0, env_id_offset=off + 500, max_episode_steps=25)
+    small.reset()
+    for t in range(31):
+        small.step(a8[t][500:628].contiguous())
+    assert torch.equal(small.state, ant.state[500:628]) and torch.equal(small.items, ant.items[500:628])
+
+
+def test_32768_envs_on_one_gpu():
+    """All of config 5's ids in one launch (8192 workgroups of four env-waves): size-independent properties + 256 sampled rows
+    against the oracle at their own global ids, including rows of the last rank's range."""
+    n = 32768
+    g, o0 = make(K.HRL_ANT_GATHER, n, seed=4)
+    g.reset()
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    acts = torch.rand(8, n, 8, device='cuda', generator=gen) * 2 - 1
+    for t in range(40):
+        g.step(acts[t % 8])
+    rows = np.concatenate([np.random.RandomState(8).choice(n, 192, replace=False), np.arange(n - 64, n)])
+    st, it, au = g.state.cpu().numpy(), g.items.cpu().numpy(), g.aux.cpu().numpy()
+    obs, rew, done, _ = g.step(acts[3])
+    torch.cuda.synchronize()
+    sampled_row_parity(K.HRL_ANT_GATHER, g, rows, st, it, au, acts[3].cpu().numpy(), rew, done, seed=4)
+    s = g.state.cpu().numpy()
+    assert np.isfinite(s).all() and np.abs(np.linalg.norm(s[:, 3:7], axis=1) - 1).max() < 1e-5
+    assert np.all(np.abs(s[:, 21:29]) <= 100.0) and np.all(np.abs(s[:, 0:2]) < 7.6)
+    ob = obs.cpu().numpy()
+    assert np.isfinite(ob).all() and np.all(ob[:, 26:] >= 0) and np.all(ob[:, 26:] <= 1) and np.all(np.abs(ob[:, :26]) <= 5)
+    assert np.all(np.abs(g.items.cpu().numpy()) <= 7.0)
+
+
 def test_batch_composition_invariance():
     """Env i's trajectory does not depend on which other envs share the launch (global-id RNG, no cross-env state)."""
     big, _ = make(K.HRL_ANT_GATHER, 4096, seed=5)
