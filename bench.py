@@ -150,12 +150,17 @@ def roofline(kind, n, launch_s):
           i.e. the fraction of the chip's peak VALU issue rate the launch used.  insts_per_env, wave cycles and the
           clock the chip held come from the committed PMC pass of the same kernel (profiles/)."""
     s = pmc_summary(kind)
+    from hrl_pybullet_envs_amd.build import kernel_source_hash
+    stale = bool(s) and s.get('source_sha256') != kernel_source_hash()
+    if stale:  # the committed counters describe other code than the one benched: report none rather than stale ones
+        s = {}
     alg = ALG_BYTES[kind] * n
     achieved = alg / launch_s / 1e9
     traffic = (s['fetch_bytes_per_env'] + s['write_bytes_per_env']) * n if 'fetch_bytes_per_env' in s else None
     out = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
            'traffic': traffic, 'kernel': f'k_step<{kind}>', 'kernel_avg_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg,
            'note': 'the path is VALU-issue/latency bound (~170 flop/B, serial recursion): `valu` is the roofline that binds, DESIGN.md 5'}
+    out['pmc_stale'] = stale  # True: profiles/pmc_summary.json was collected from different kernel sources; traffic / valu withheld
     if 'valu_insts_per_env' in s:
         per_simd = s['valu_insts_per_env'] * n / N_SIMD * VALU_ISSUE_CYCLES
         v = {'insts_per_env': s['valu_insts_per_env'], 'issue_cycles_per_simd': per_simd,
@@ -267,6 +272,8 @@ def main():
             'value': total_steps / wall, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            # False: the timed window starts less than 50 steps after the reset, ants still settling (launches are ~5 % shorter there)
+            'steady_state': args.warmup >= 50,
             'config': {'workload': f'{shard}, U(-1,1) actions pre-generated on device, auto-reset, max_episode_steps 2000',
                        'envs_per_gpu': n, 'global_envs': world * n,
                        'substeps_per_step': 4, 'parallelism': f'env-sharded x{world}, no data-path collective; '

@@ -24,17 +24,29 @@ def make(env_id, **kwargs):
 def register_with(gym_module):
     """The reference's registration (hrl_pybullet_envs/__init__.py:11-16): the same ids, `<ClassName>-v0`, each with
     max_episode_steps=2000, so that `gym.make('AntGatherBulletEnv-v0')` of a user script resolves to this package when it
-    is imported in place of hrl_pybullet_envs.  AntMjEnv is importable but, as in the reference (:9), not registered."""
+    is imported in place of hrl_pybullet_envs.  AntMjEnv is importable but, as in the reference (:9), not registered.
+    Ids the registry already holds (the reference imported in the same process for an A/B run) are left alone."""
     ids = []
+    registry = getattr(getattr(gym_module.envs, 'registry', None), 'env_specs', getattr(gym_module.envs, 'registry', None))
     for cls in (AntGatherBulletEnv, AntMazeMjEnv, AntMazeBulletEnv, AntFlagrunBulletEnv, PointGatherBulletEnv):
-        gym_module.envs.register(id=f'{cls.__name__}-v0', entry_point=f'{cls.__module__}:{cls.__name__}', max_episode_steps=2000)
-        ids.append(f'{cls.__name__}-v0')
+        env_id = f'{cls.__name__}-v0'
+        try:
+            if registry is not None and env_id in registry:
+                continue
+        except TypeError:
+            pass
+        gym_module.envs.register(id=env_id, entry_point=f'{cls.__module__}:{cls.__name__}', max_episode_steps=2000)
+        ids.append(env_id)
     return ids
 
 
 try:
     import gym as _gym
-except ImportError:  # gym is optional (absent in the build image): make() above serves the same ids
+except Exception:  # gym is optional (absent in the build image; a broken install must not break this package): make() serves the same ids
     _gym = None
 if _gym is not None:  # pragma: no cover
-    register_with(_gym)
+    try:
+        register_with(_gym)
+    except Exception as _e:  # duplicate ids on gym versions that reject them, API drift: make() stays the guaranteed path
+        import warnings as _w
+        _w.warn(f'hrl_pybullet_envs_amd: gym registration skipped ({type(_e).__name__}: {_e}); use hrl_pybullet_envs_amd.make(id)')

@@ -13,6 +13,17 @@ SOURCES = ['hrl_hip.hip', 'step_core.h', 'host_cfg.h']
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared']
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (csrc/step_core.h + csrc/hrl_hip.hip): ties a committed counter summary
+    (profiles/pmc_summary.json, tools/summarize_profile.py) to the code it was collected from (bench.py: roofline.pmc_stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ('step_core.h', 'hrl_hip.hip'):
+        with open(os.path.join(CSRC, name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

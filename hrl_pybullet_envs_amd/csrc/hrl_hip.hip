@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * G, 4) void k_step(DevBufs b, const DevCfg *__r
     step_entry<KIND>(x, b, *cp, (int)blockIdx.x * G + ((int)threadIdx.x >> 6));
 #ifdef HRL_WGTIME
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1)::"memory");
-    if (b.stamps && (threadIdx.x & 63) == 0) {
+    if (b.stamps && (threadIdx.x & 63) == 0 && (int)blockIdx.x * G + ((int)threadIdx.x >> 6) < cp->n_envs) { /* a wave of a ragged last group has no row in the buffer */
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

@@ -1742,7 +1742,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
         }
         if (lane < 16) L.u[lane] = 0.f;
         if (lane < 8) L.tau[lane] = 0.f;
-        if (lane == 63 && KIND == 5) L.aux[3] = c.flag_manual ? 0 : 1; /* first goal popped (manual: none pending), steps_since_goal_change = 0, not rewarded */
+        if (lane == 63 && KIND == 5) L.aux[3] = (int)((c.flag_manual ? 0u : 1u) | ((uint32_t)L.aux[3] & 0x7fff0000u)); /* first goal popped (manual: none pending), not rewarded; steps_since_goal_change survives a reset (ant_flagrun_env.py:132-155 never assigns it) */
         if (lane == 63 && (KIND == 2 || KIND == 4)) {
             uint32_t r[4];
             philox4x32(c, env, ep, (3u << 16), 0u, r);

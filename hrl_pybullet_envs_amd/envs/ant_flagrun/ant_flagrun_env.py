@@ -26,19 +26,87 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
                                   n_bins=int(sensor_bins), sensor_span=float(sensor_span), sensor_range=float(sensor_range),
                                   flag_switch_on_collision=int(bool(switch_flag_on_collision)),
                                   world_size=(float(size) + 2, float(size) + 2))
-        cfg.centroid_static_sum[0] = -(float(size) + 2) / 2
+        if enclosed or use_sensor:  # ant_flagrun_env.py:59-64: the arena's floor and last wall join upstream's parts dict
+            cfg.centroid_n_static = 2
+            cfg.centroid_static_sum[0] = -(float(size) + 2) / 2
+        else:                       # upstream stadium scene: only its `floor` at the origin
+            cfg.centroid_n_static = 1
+            cfg.centroid_static_sum[0] = 0.0
         self.size, self.tol, self.max_targets, self.timeout, self.enclosed = size, tolerance, max_targets, timeout, enclosed
         self.max_target_dist, self.manual_goal_creation = max_target_dist, manual_goal_creation
+        self.switch_flag_on_collision = switch_flag_on_collision
         self.use_sensor, self.n_bins, self.sensor_span, self.sensor_range, self.debug = use_sensor, sensor_bins, sensor_span, sensor_range, debug
         self._finish_init(cfg, num_envs, device, seed)
 
-    def set_goals(self, goals, mask=None):
-        """manual_goal_creation: the reference's `env.goals = [...]; env.next_target()` (ant_flagrun_env.py:91-118).
-        goals: [n_goals, 2] (one list for every env) or [num_envs, n_goals, 2], visited in the given order, at most 15.
-        Returns the observation towards the first goal, like next_target()."""
+    # ---- the goal list (ant_flagrun_env.py:45,91-120) over the env's `items` / `aux` tensors (include/hrl_envs.h) ----
+    def _listed(self):
+        return self.manual_goal_creation and not self.max_target_dist > 0
+
+    @property
+    def goals(self):
+        """`env.goals`: the goals still to come, in the reference's list order (next_target() pops the LAST one).
+        One env: a list of (x, y); batched: ([N, n_max, 2] tensor, [N] lengths).  With max_targets < 1 the list is never
+        read (goals are drawn near the robot, :113-114) and stays []."""
         import torch
-        if not self.manual_goal_creation:
-            raise RuntimeError('set_goals needs manual_goal_creation=True; otherwise reset() draws the goals (ant_flagrun_env.py:149-152)')
+        env = self._backend()
+        if self.max_target_dist > 0:
+            return [] if self.num_envs == 1 else (torch.zeros(self.num_envs, 0, 2, device=env.device), torch.zeros(self.num_envs, dtype=torch.int32, device=env.device))
+        cur = (env.aux[:, 3] & 0xffff)
+        if self._listed():
+            pend = env.items[:, 2:].reshape(self.num_envs, K.HRL_MAX_GOALS, 2)
+            if self.num_envs == 1:
+                return [tuple(g) for g in pend[0, :int(cur[0])].tolist()]
+            return pend, cur
+        # shared list (:91-96): goal k of the episode is a function of (seed, episode, k); `cur` of them are used up.
+        # create_targets() fills the list front to back and pop() empties it from the back: goal number k sits at index
+        # max_targets - k
+        from ..._philox import flag_goal
+        ep = env.aux[:, 2].cpu().numpy()
+        ks = np.arange(self.max_targets, 0, -1)                   # list index i holds goal number max_targets - i
+        allg = flag_goal(self._cfg.seed, self._cfg.flag_size, ep[:, None], ks[None, :])  # [N, max_targets, 2]
+        left = (self.max_targets - cur.cpu().numpy()).clip(0)
+        if self.num_envs == 1:
+            return [tuple(map(float, g)) for g in allg[0, :int(left[0])]]
+        return torch.from_numpy(allg).to(env.device), torch.from_numpy(left.astype(np.int32)).to(env.device)
+
+    @goals.setter
+    def goals(self, goals):
+        """`env.goals = [...]` of a manual_goal_creation env: stores the list (one for every env: [n, 2]; or [N, n, 2]), at
+        most 15 goals; nothing else changes until next_target() / a goal is reached."""
+        import torch
+        if not self._listed():
+            raise AttributeError('env.goals can only be assigned with manual_goal_creation=True and max_targets > 0 '
+                                 '(otherwise reset() fills the list, or next_target() ignores it: ant_flagrun_env.py:113-116,150-153)')
+        env = self._backend()
+        g = torch.as_tensor(np.asarray(goals, dtype=np.float32).reshape(-1, 2) if len(goals) == 0 else np.asarray(goals, dtype=np.float32), device=env.device)
+        if g.dim() == 2:
+            g = g.unsqueeze(0).expand(self.num_envs, -1, -1)
+        n = int(g.shape[1])
+        if g.shape[0] != self.num_envs or g.shape[2] != 2 or n > K.HRL_MAX_GOALS:
+            raise ValueError(f'goals must be [n <= {K.HRL_MAX_GOALS}, 2] or [num_envs, n, 2]')
+        env.items[:, 2:] = 0
+        env.items[:, 2:2 + 2 * n] = g.reshape(self.num_envs, 2 * n)
+        env.aux[:, 3] = (env.aux[:, 3] & ~0xffff) | n
+
+    def next_target(self, mask=None):
+        """`env.next_target()` (ant_flagrun_env.py:112-120): the last goal of the list (or, with max_targets < 1, a goal near
+        the robot) becomes the target; returns calc_state towards it.  One env: IndexError when the list is empty, as in
+        the reference; batched: returns (obs, ok) with ok[i] = 0 for such envs (left unchanged)."""
+        obs, ok = self._backend().next_target(mask)
+        if self.num_envs == 1:
+            if not bool(ok[0]):
+                raise IndexError('pop from empty list')
+            return obs[0].double().cpu().numpy()[:28]
+        return obs, ok
+
+    def set_goals(self, goals, mask=None):
+        """`env.goals = [...]; env.next_target()` in one call (one kernel launch): goals [n_goals, 2] (one list for every env)
+        or [num_envs, n_goals, 2], at most 15.  As in the reference the list is consumed from its BACK: goals[-1] becomes the
+        target now, goals[-2] next, ... (`self.goals.pop()`, :116).  Returns the observation towards the new target."""
+        import torch
+        if not self._listed():
+            raise RuntimeError('set_goals needs manual_goal_creation=True and max_targets > 0; otherwise reset() draws the goals '
+                               '(ant_flagrun_env.py:150-153) or next_target() ignores the list (:113-114)')
         env = self._backend()
         g = torch.as_tensor(np.asarray(goals, dtype=np.float32), device=env.device)
         if g.dim() == 2:
@@ -46,4 +114,35 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         obs = env.set_goals(g.contiguous(), mask)
         return obs[0].double().cpu().numpy() if self.num_envs == 1 else obs
 
-    goal = property(lambda self: tuple(self._backend().items[0, 0:2].tolist()) if self.num_envs == 1 else self._backend().items[:, 0:2])
+    def create_targets(self, n):
+        """ant_flagrun_env.py:91-96 refills the list from the shared RandomState; here the shared list is a function of
+        (seed, episode, k) that reset() arms, so only the length the env was built with can be asked for."""
+        if self.manual_goal_creation or n != self.max_targets:
+            raise NotImplementedError('the shared goal list has max_targets goals per episode, armed by reset(); with '
+                                      'manual_goal_creation assign env.goals instead')
+
+    @property
+    def steps_since_goal_change(self):  # :43,171,192,200
+        s = (self._backend().aux[:, 3] >> 16) & 0x7fff
+        return int(s[0]) if self.num_envs == 1 else s
+
+    @property
+    def _rewarded(self):  # :51
+        r = (self._backend().aux[:, 3] >> 31) & 1
+        return bool(r[0]) if self.num_envs == 1 else r.bool()
+
+    def _walk_target(self):
+        env = self._backend()
+        if self.max_target_dist > 0 or self.manual_goal_creation:
+            return env.items[:, 0:2].double().cpu().numpy()
+        from ..._philox import flag_goal
+        aux = env.aux.cpu().numpy()
+        return flag_goal(self._cfg.seed, self._cfg.flag_size, aux[:, 2], aux[:, 3] & 0xffff).astype(np.float64)
+
+    @property
+    def goal(self):  # :57
+        t = self._walk_target()
+        return (float(t[0, 0]), float(t[0, 1])) if self.num_envs == 1 else t
+
+    walk_target_x = property(lambda self: self.robot.walk_target_x)
+    walk_target_y = property(lambda self: self.robot.walk_target_y)

@@ -51,9 +51,13 @@ class GatherBulletEnv(BatchedGymEnv):
 
     @property
     def robot(self):
-        """The robot object handed to the constructor (gather_base.py:31), with the live pose attributes of the batched state."""
-        from ..robot_view import RobotView
-        view = RobotView(self)
-        for name in ('body_real_xyz', 'body_xyz', 'body_rpy'):
-            setattr(self._robot, name, getattr(view, name))
+        """The robot object handed to the constructor (gather_base.py:31); a PointBot reads its live pose attributes
+        (body_real_xyz, body_xyz, body_rpy) from this env's state through `_view`."""
+        if getattr(self, '_cfg', None) is not None and hasattr(self._robot, '_view'):
+            from ..robot_view import RobotView
+            self._robot._view = RobotView(self)
         return self._robot
+
+    @robot.setter
+    def robot(self, r):
+        self._robot = r

@@ -20,6 +20,12 @@ class PointBot:
         self.initial_z = 1                 # point_bot.py:18
         self.walk_target_x = 0
         self.walk_target_y = 0
+        self._view = None                  # set by the env that simulates this robot: live pose of the batched state
+
+    # point_bot.py:50-53: pose attributes calc_state leaves on the robot
+    body_real_xyz = property(lambda self: self._view.body_real_xyz if self._view else np.array(self.start_pos, dtype=float))
+    body_xyz = property(lambda self: self._view.body_xyz if self._view else np.array(self.start_pos, dtype=float))
+    body_rpy = property(lambda self: self._view.body_rpy if self._view else np.zeros(3))
 
     def alive_bonus(self, z, pitch):
         return 1                           # point_bot.py:73-74: cannot die

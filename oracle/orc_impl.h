@@ -1401,7 +1401,9 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     if (cfg->env_kind == HRL_POINT_GATHER) { st[2] = R_(0.5); st[HRL_INITZ_OFF] = 1; } /* point_bot.py:12,18 */
     else {
         if (cfg->env_kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:132-155: start (0,0,0.25), first goal popped */
-            aux[3] = cfg->flag_manual_goals ? 0 : 1; /* manual: goals.clear() (:149), nothing popped */
+            /* manual: goals.clear() (:150), nothing popped; else the first goal of the new list; _rewarded cleared (:137);
+             * steps_since_goal_change is NOT reset by reset() (:132-155 never assigns it) */
+            aux[3] = (int32_t)((cfg->flag_manual_goals ? 0u : 1u) | ((uint32_t)aux[3] & 0x7fff0000u));
             st[0] = R_(cfg->start_pos[0]); st[1] = R_(cfg->start_pos[1]); st[2] = R_(cfg->start_pos[2]);
         } else if (maze_kind) { /* ant_maze_bullet_env.py:108-118, ant_maze_mj_env.py:85-101 */
             uint32_t r[4];
@@ -1547,17 +1549,14 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
         REAL pot = -wtd / (K->h * R_(K->nsub)), progress = pot - st[HRL_POTENTIAL_OFF];
         st[HRL_POTENTIAL_OFF] = pot; /* next_target() re-reads the same stale potential (:116), i.e. leaves it unchanged */
-        const int budget = close_mode ? (1 << 20) : cfg->flag_max_targets; /* max_target_dist mode never runs out (:111-112) */
+        const int budget = close_mode ? (1 << 20) : cfg->flag_max_targets; /* max_target_dist mode never runs out (:113-114) */
         int goals_left = manual ? cur : budget - cur; /* manual: `cur` counts the pending goals */
         FN(orc_flagrun_task)(cfg, alive + progress, idone, wtd, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
         if (steps > 0x7fff) steps = 0x7fff; /* steps_since_goal_change saturates in its 15-bit field (only reachable with the timeout off) */
-        cur = manual ? goals_left : budget - goals_left;
-        if (manual && retarget) { items[0] = items[2 + 2 * cur]; items[1] = items[3 + 2 * cur]; } /* goals.pop() (:114) */
-        if (close_mode && retarget) { /* set_target(*create_close_target()): around the robot's current xy (:80-89, :112) */
-            REAL g2[2];
-            FN(flag_close_goal)(cfg, env, (uint32_t)aux[2], (uint32_t)cur, st, g2);
-            items[0] = g2[0]; items[1] = g2[1];
-        }
+        if (retarget && (manual || close_mode)) { /* the next_target() of :190 / :198: goals.pop() (:116) or create_close_target around the robot's xy (:113-114) */
+            FN(orc_flag_next_target)(cfg, env, st, items, aux);
+            cur = aux[3] & 0xffff;
+        } else cur = manual ? goals_left : budget - goals_left;
         aux[3] = (int32_t)(((uint32_t)cur & 0xffffu) | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
         FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0); /* calc_state w.r.t. the (possibly new) goal */
     } else if (cfg->env_kind == HRL_ANT_MAZE_MJ) { /* MjAnt.py:36-97 then ant_maze_mj_env.py:66-78 */

@@ -737,6 +737,97 @@ def main():
         seq['maze'].append(events)
     G['reset_potential_seq'] = seq
 
+    # ---------------------------------------------------------------- manual_goal_creation (ant_flagrun_env.py:27,45,112-120,150-153)
+    # reset() / `env.goals = [...]` / next_target() / step() run IN-TREE on the sequence robot above: which goal of the list
+    # next_target() takes (goals.pop(): the LAST), goals running out (IndexError -> done), the timeout, what a reset keeps
+    # (the walk target) and drops (the list); with max_targets < 1 next_target() ignores the list and calls
+    # create_close_target (the uniforms / randint results it consumed are logged).
+    man = {'dt': DT, 'list': [], 'close': []}
+    for k in range(8):
+        lrs = np.random.RandomState(19000 + k)
+        robot = SeqRobot([0.0, 0.0, 0.75])
+        timeout = 200 if k % 2 == 0 else 2
+        env = AntFlagrunBulletEnv.__new__(AntFlagrunBulletEnv)
+        env.__dict__.update(dict(robot=robot, _p=SeqClient(robot), scene=NS(_p=None), _bookkeeping=True, tol=0.5, timeout=timeout,
+                                 switch_flag_on_collision=(k != 5), max_targets=100, max_target_dist=0, manual_goal_creation=True,
+                                 size=10, mpi_common_rand=np.random.RandomState(19100 + k), goals=[], steps_since_goal_change=0,
+                                 _rewarded=False, debug=False, use_sensor=False, isRender=False, flag=None,
+                                 walk_target_x=1e3, walk_target_y=0.0, _sq_dist_goal=0, _goal_start_pos=np.array([0, 0])))
+        events = []
+
+        def snap(op, **kw):
+            e = {'op': op, 'pos': list(map(float, robot._pos)), 'target': [float(env.walk_target_x), float(env.walk_target_y)],
+                 'potential': float(env.potential), 'goals_left': [list(map(float, g)) for g in env.goals],
+                 'steps': int(env.steps_since_goal_change), 'rewarded': bool(env._rewarded)}
+            e.update(kw)
+            events.append(e)
+
+        for ep in range(2):
+            AntFlagrunBulletEnv.reset(env)
+            snap('reset')
+            n_goals = int(lrs.randint(1, 5))
+            goals = [tuple(map(float, lrs.uniform(-4, 4, 2))) for _ in range(n_goals)]
+            env.goals = list(goals)
+            AntFlagrunBulletEnv.next_target(env)
+            snap('set_goals', goals=[list(g) for g in goals])
+            for t in range(3 * n_goals + 3):
+                robot._pos = [float(v) for v in (np.array(robot._pos) + np.r_[lrs.uniform(-0.3, 0.3, 2), 0.0])]
+                if t % 3 == 1:  # jump onto the goal: +5000, retarget (or IndexError -> done when the list is empty)
+                    robot._pos = [float(env.walk_target_x) + 0.1, float(env.walk_target_y) - 0.2, 0.5]
+                _, r, d, info = AntFlagrunBulletEnv.step(env, np.zeros(8))
+                snap('step', rew=float(r), done=bool(d), retargeted='target' in info)
+                if d:
+                    break
+            if ep == 0:  # next_target() from outside on an empty / a one-goal list
+                env.goals = []
+                try:
+                    AntFlagrunBulletEnv.next_target(env)
+                    raised = False
+                except IndexError:
+                    raised = True
+                snap('next_target', raised=raised, goals=[])
+                g1 = [tuple(map(float, lrs.uniform(-4, 4, 2)))]
+                env.goals = list(g1)
+                AntFlagrunBulletEnv.next_target(env)
+                snap('next_target', raised=False, goals=[list(g1[0])])
+        man['list'].append({'timeout': timeout, 'switch': bool(env.switch_flag_on_collision), 'events': events})
+    for k in range(6):
+        lrs = np.random.RandomState(19500 + k)
+        robot = SeqRobot([0.0, 0.0, 0.75])
+        rnd = LogR(19600 + k)
+        env = AntFlagrunBulletEnv.__new__(AntFlagrunBulletEnv)
+        env.__dict__.update(dict(robot=robot, _p=SeqClient(robot), scene=NS(_p=None), _bookkeeping=True, tol=0.5, timeout=3,
+                                 switch_flag_on_collision=True, max_targets=0, max_target_dist=3.0, manual_goal_creation=True,
+                                 size=10, mpi_common_rand=rnd, goals=[], steps_since_goal_change=0,
+                                 _rewarded=False, debug=False, use_sensor=False, isRender=False, flag=None,
+                                 walk_target_x=1e3, walk_target_y=0.0, _sq_dist_goal=0, _goal_start_pos=np.array([0, 0])))
+        events = []
+
+        def snapc(op, nu, nb, **kw):
+            e = {'op': op, 'pos': list(map(float, robot._pos)), 'target': [float(env.walk_target_x), float(env.walk_target_y)],
+                 'potential': float(env.potential), 'steps': int(env.steps_since_goal_change), 'rewarded': bool(env._rewarded),
+                 'u': rnd.u[nu:], 'b': rnd.b[nb:]}
+            e.update(kw)
+            events.append(e)
+
+        for ep in range(2):
+            nu, nb = len(rnd.u), len(rnd.b)
+            AntFlagrunBulletEnv.reset(env)
+            snapc('reset', nu, nb)
+            nu, nb = len(rnd.u), len(rnd.b)
+            env.goals = [(9.0, 9.0)]          # ignored: max_targets < 1
+            AntFlagrunBulletEnv.next_target(env)
+            snapc('next_target', nu, nb, list_len_after=len(env.goals))
+            for t in range(7):
+                robot._pos = [float(v) for v in (np.array(robot._pos) + np.r_[lrs.uniform(-0.3, 0.3, 2), 0.0])]
+                if t == 4:
+                    robot._pos = [float(env.walk_target_x) - 0.1, float(env.walk_target_y) + 0.1, 0.5]
+                nu, nb = len(rnd.u), len(rnd.b)
+                _, r, d, info = AntFlagrunBulletEnv.step(env, np.zeros(8))
+                snapc('step', nu, nb, rew=float(r), done=bool(d), retargeted='target' in info)
+        man['close'].append({'timeout': 3, 'max_target_dist': 3.0, 'size': 10, 'tol': 0.5, 'events': events})
+    G['flagrun_manual_seq'] = man
+
     only = set(sys.argv[1:])  # optional: names of the fixtures to (re)write; default all
     for name, val in G.items():
         if only and name not in only:

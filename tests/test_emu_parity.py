@@ -2,6 +2,8 @@
 (tests/emu) against the independent scalar oracle.  Same compiler flags (-ffp-contract=off), same libm, and the
 algorithm pins every operation order, so the two implementations must agree BIT FOR BIT.  This is what lets the GPU
 tests attribute any difference to device arithmetic rather than to kernel logic."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -206,6 +208,8 @@ def test_product_defaults_equal_oracle_defaults():
     (K.HRL_POINT_GATHER, 6, dict(robot_coll_dist=-1.0, respawn=0)),
     (K.HRL_ANT_MAZE, 5, dict(inner_rew_weight=1.0)),
     (K.HRL_ANT_FLAGRUN, 7, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
+    (K.HRL_ANT_FLAGRUN, 6, dict(flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0), flag_timeout=8, flag_max_targets=5)),
+    (K.HRL_ANT_FLAGRUN, 6, dict(flag_switch_on_collision=0, flag_timeout=7, flag_max_targets=4)),
 ])
 def test_non_default_configs_bit_exact(kind, n, kw):
     cfg = orc.default_config(kind, num_envs=n, seed=17, auto_reset=1, max_episode_steps=25, **kw)
@@ -323,11 +327,12 @@ def test_self_collision_broad_phase_is_exact():
 
 
 def test_flagrun_manual_goals():
-    """manual_goal_creation (ant_flagrun_env.py:24,149-152): reset draws no goal, goals come through hrl_set_goals
-    (emu_set_goals here), are visited in the given order and the episode ends when they run out."""
+    """manual_goal_creation (ant_flagrun_env.py:27,150-153): reset draws no goal; `env.goals = [...]; env.next_target()` comes
+    through hrl_set_goals (emu_set_goals here): as in the reference the list is consumed from its BACK (`goals.pop()`, :116) and
+    the episode ends when it runs out; next_target() alone (hrl_next_target) pops one more, IndexError -> ok = 0."""
     import ctypes as C
     n, G = 8, 3
-    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=6, auto_reset=0, flag_manual_goals=1, flag_max_targets=0, flag_timeout=0)
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=6, auto_reset=0, flag_manual_goals=1, flag_timeout=0)
     o, e = both(cfg)
     o.reset(); e.reset()
     same(o, e, 'reset')
@@ -337,7 +342,8 @@ def test_flagrun_manual_goals():
     b = e._bufs()
     assert emu_env.lib().emu_set_goals(C.byref(cfg), C.byref(b), orc.ptr(goals), G, None, 0) == 0
     same(o, e, 'set_goals')
-    assert np.array_equal(o.items[:, 0:2], goals[:, 0]) and np.all((o.aux[:, 3] & 0xffff) == G - 1)
+    assert np.array_equal(o.items[:, 0:2], goals[:, G - 1]) and np.all((o.aux[:, 3] & 0xffff) == G - 1)  # the LAST goal first
+    assert np.array_equal(o.items[:, 2:2 + 2 * (G - 1)], goals[:, :G - 1].reshape(n, -1))                # the rest, in list order
     rng = np.random.RandomState(1)
     visited = np.zeros(n, int); done_at = np.full(n, -1)
     for t in range(12):
@@ -354,10 +360,96 @@ def test_flagrun_manual_goals():
                 if o.rew[i] > 1000:
                     visited[i] += 1
                 if visited[i] <= G - 1 and o.rew[i] > 1000 and not o.done[i]:
-                    assert np.array_equal(o.items[i, 0:2], goals[i, visited[i]])  # the next goal in the given order
+                    assert np.array_equal(o.items[i, 0:2], goals[i, G - 1 - visited[i]])  # back to front
                 if o.done[i]:
                     done_at[i] = t
     assert np.all(visited >= G) and np.all(done_at >= 0)  # all goals reached, then the episode ends for lack of goals
+    # next_target() alone: one more goal assigned as plain data (env.goals = [g]), popped by hrl_next_target; then IndexError
+    extra = np.random.RandomState(3).uniform(-4, 4, (n, 2)).astype(np.float32)
+    ok_o = np.full(n, 7, np.uint8); ok_e = np.full(n, 7, np.uint8)
+    mask = np.ones(n, np.uint8); mask[5] = 0
+    for env in (o, e):
+        env.items[:, 2:4] = extra; env.aux[:, 3] = (env.aux[:, 3] & ~0xffff) | 1
+    for rep, want in ((0, 1), (1, 0)):
+        orc.lib().orc_next_target_batch_f32(C.byref(cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(mask), orc.ptr(o.obs), orc.ptr(ok_o))
+        b = e._bufs()
+        assert emu_env.lib().emu_next_target(C.byref(cfg), C.byref(b), orc.ptr(mask), orc.ptr(ok_e), rep) == 0  # (second call: lanes in reverse order)
+        same(o, e, ('next_target', rep))
+        assert np.array_equal(ok_o, ok_e) and np.all(ok_o[mask == 1] == want) and ok_o[5] == 7
+        assert np.array_equal(o.items[mask == 1, 0:2], extra[mask == 1]) and np.all((o.aux[mask == 1, 3] & 0xffff) == 0)
+    assert not np.array_equal(o.items[5, 0:2], extra[5])  # the masked-out env kept its target
+
+
+def test_flagrun_manual_close_targets():
+    """manual_goal_creation with max_targets < 1 (ant_flagrun_env.py:113-114): next_target() -- from step() on reaching the goal /
+    timing out, or from outside -- draws a goal near the robot whatever env.goals holds; reset() draws nothing (:150-153) and
+    the episode never runs out of goals.  hrl_set_goals is refused there (the list would never be read)."""
+    import ctypes as C
+    n = 8
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=9, auto_reset=0, flag_manual_goals=1, flag_max_targets=0,
+                             flag_max_target_dist=3.0, flag_timeout=4)
+    o, e = both(cfg)
+    o.reset(); e.reset()
+    same(o, e, 'reset')
+    assert np.all(o.items[:, 0] == 1000) and np.all(o.aux[:, 3] == 0)
+    ok_o = np.zeros(n, np.uint8); ok_e = np.zeros(n, np.uint8)
+    orc.lib().orc_next_target_batch_f32(C.byref(cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), None, orc.ptr(o.obs), orc.ptr(ok_o))
+    b = e._bufs()
+    assert emu_env.lib().emu_next_target(C.byref(cfg), C.byref(b), None, orc.ptr(ok_e), 0) == 0
+    same(o, e, 'next_target')
+    assert np.all(ok_o == 1) and np.all(ok_e == 1) and np.all((o.aux[:, 3] & 0xffff) == 1)
+    d = np.abs(o.items[:, 0:2] - o.state[:, 0:2])
+    assert np.all(d >= 0.5 - 1e-6) and np.all(d <= 1.5 + 1e-6) and np.all(np.abs(o.items[:, 0:2]) < 5)   # +-U(tol, mtd / 2) per axis, inside the arena
+    goals = np.zeros((n, 2, 2), np.float32)
+    assert emu_env.lib().emu_set_goals(C.byref(cfg), C.byref(b), orc.ptr(goals), 2, None, 0) != 0
+    rng = np.random.RandomState(2)
+    seen = [set() for _ in range(n)]
+    for t in range(14):  # the 4-step timeout retargets three times; nobody runs out of goals
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        same(o, e, t)
+        for i in range(n):
+            seen[i].add(tuple(o.items[i, 0:2]))
+    assert not o.done.any() and all(len(sx) >= 3 for sx in seen) and np.all((o.aux[:, 3] & 0xffff) >= 4)
+
+
+def test_flagrun_open_field_and_no_switch_on_collision():
+    """ant_flagrun_env.py:59-64 `enclosed=False` (and no sensor): upstream's stadium scene, no walls -- an ant beyond where the
+    arena's walls would stand meets nothing lateral; :183-194 `switch_flag_on_collision=False`: reaching the goal pays the +5000
+    once and keeps the goal until the timeout moves it."""
+    n = 8
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=3, auto_reset=0, flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0),
+                             flag_switch_on_collision=0, flag_timeout=6, flag_max_targets=3)
+    walled = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=3, auto_reset=0, flag_switch_on_collision=0, flag_timeout=6, flag_max_targets=3)
+    o, e = both(cfg)
+    ow = orc.OracleEnv(walled, np.float32)
+    o.reset(); e.reset(); ow.reset()
+    same(o, e, 'reset')
+    for env in (o, e, ow):   # astride the line x = 6 where the enclosed arena's wall stands (world 12 x 12), feet on the ground
+        env.state[:, 0] = 6.0; env.state[:, 2] = 0.3
+    rng = np.random.RandomState(0)
+    for t in range(5):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a); ow.step(a)
+        same(o, e, ('open', t))
+    assert np.isfinite(o.state).all() and np.all(np.abs(o.state[:, 0] - 6.0) < 0.5)   # nothing pushed it away
+    assert np.abs(ow.state[:, 0] - o.state[:, 0]).max() > 0.05                         # the walled arena did
+    o.reset(); e.reset()
+    paid = np.zeros(n, int); goals_seen = [set() for _ in range(n)]
+    for t in range(14):
+        g = np.zeros((n, 2), np.float32)
+        for i in range(n):
+            orc.lib().orc_flag_goal_f32(C.byref(cfg), int(o.aux[i, 2]), int(o.aux[i, 3] & 0xffff), orc.ptr(g[i:i + 1]))
+            goals_seen[i].add(tuple(g[i]))
+        xy = ((14 * g) / 13).astype(np.float32)   # centroid = (13 robot parts + the stadium's floor at the origin) / 14
+        for env in (o, e):
+            env.state[:, 0:2] = xy; env.state[:, 2] = 0.5
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        same(o, e, ('noswitch', t))
+        paid += (o.rew > 1000).astype(int)
+    # on the goal every step: paid once per goal, the goal only moves with the 6-step timeout (14 steps -> 3 goals), never `done` for it
+    assert np.all(paid == np.array([len(sx) for sx in goals_seen])) and all(len(sx) == 3 for sx in goals_seen), (paid, goals_seen)
 
 
 def test_reset_potential_is_taken_before_the_target_switch():

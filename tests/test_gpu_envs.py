@@ -245,3 +245,80 @@ def test_rccl_world_of_one_return_gather_on_the_side_stream():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_attributes_a_trainer_reads_between_steps():
+    """ant_maze_bullet_env.py:38,46 (`t`, `target`), ant_flagrun_env.py:43-57 (`goals`, `steps_since_goal_change`, `goal`) and the
+    upstream robot attributes (`walk_target_x/y`, `body_xyz`, `body_real_xyz`, `walk_target_dist`) as views over the state
+    tensors: one env gives python / numpy values like the reference, a batch gives one row per env."""
+    import hrl_pybullet_envs_amd as H
+    dt = np.float32(0.0165 / 4) * 4
+    # maze, one env
+    m = H.AntMazeBulletEnv(seed=5)
+    m.reset()
+    assert m.t == 0 and isinstance(m.target, np.ndarray) and list(m.target) in [list(map(float, t)) for t in m.targets]
+    for _ in range(3):
+        m.step(np.zeros(8))
+    assert m.t == 3 and (m.walk_target_x, m.walk_target_y) == tuple(m.target) == (m.robot.walk_target_x, m.robot.walk_target_y)
+    st = m._backend().state[0].cpu().numpy()
+    assert np.allclose(m.robot.body_real_xyz, st[0:3]) and m.robot.body_xyz.shape == (3,) and m.robot.body_xyz[2] == st[2]
+    assert abs(m.robot.walk_target_dist - float(-st[31] * dt)) < 1e-4     # the potential the step stored = -walk_target_dist / dt
+    assert abs(m.robot.initial_z - 0.25) < 1e-6 and m.robot.body_rpy.shape == (3,)
+    m.close()
+    # maze Mj + flat, batched
+    for cls in (H.AntMazeMjEnv, H.AntMjEnv):
+        b = cls(num_envs=64, seed=2)
+        b.reset()
+        for _ in range(4):
+            b.step(torch.rand(64, 8, device='cuda') * 2 - 1)
+        st = b._backend().state.cpu().numpy()
+        assert np.allclose(b.robot.walk_target_dist, -st[:, 31] * dt, atol=2e-4) and b.robot.body_xyz.shape == (64, 3)
+        if cls is H.AntMazeMjEnv:
+            assert b.target.shape == (64, 2) and int(b.t[0]) == 4 and b.robot.walk_target_x.shape == (64,)
+        else:
+            assert np.all(b.robot.walk_target_x == 1000.0)                 # upstream's default walk target
+        b.close()
+    # flagrun, shared list: goals still to come; goal = the one being chased; consumed as goals are reached / time out
+    f = H.AntFlagrunBulletEnv(max_targets=6, timeout=3, seed=9)
+    f.reset()
+    g0 = f.goals
+    assert len(g0) == 5 and f.steps_since_goal_change == 0 and not f._rewarded
+    first = f.goal
+    st = f._backend().state[0].cpu().numpy()
+    for _ in range(3):
+        f.step(np.zeros(8))
+    assert f.goal == pytest.approx(g0[-1]) and f.goals == g0[:-1] and f.steps_since_goal_change == 0   # timeout: the LAST goal of the list is next
+    assert f.goal != first and (f.walk_target_x, f.walk_target_y) == f.goal
+    st = f._backend().state[0].cpu().numpy()
+    f.step(np.zeros(8))
+    st = f._backend().state[0].cpu().numpy()
+    assert abs(f.robot.walk_target_dist - float(-st[31] * dt)) < 1e-4 and f.steps_since_goal_change == 1
+    f.close()
+    fb = H.AntFlagrunBulletEnv(max_targets=4, num_envs=16, seed=9)
+    fb.reset()
+    gl, left = fb.goals
+    assert gl.shape == (16, 4, 2) and bool((left == 3).all()) and fb.goal.shape == (16, 2)
+    fb.close()
+    # flagrun, manual list: env.goals = [...] is plain data; next_target() pops the last; IndexError on an empty list
+    e = H.AntFlagrunBulletEnv(manual_goal_creation=True, seed=3)
+    e.reset()
+    assert e.goals == [] and e.goal == (1000.0, 0.0)
+    with pytest.raises(IndexError):
+        e.next_target()
+    e.goals = [(1.0, 2.0), (-2.0, 0.5), (3.0, 3.0)]
+    assert e.goals == [(1.0, 2.0), (-2.0, 0.5), (3.0, 3.0)] and e.goal == (1000.0, 0.0)
+    ob = e.next_target()
+    assert ob.shape == (28,) and e.goal == (3.0, 3.0) and e.goals == [(1.0, 2.0), (-2.0, 0.5)]
+    ob2 = e.set_goals([(0.5, 0.5), (4.0, -4.0)])
+    assert e.goal == (4.0, -4.0) and e.goals == [(0.5, 0.5)] and ob2.shape == (28,)
+    e.close()
+    # gather kinds: the robot object of the constructor with live pose attributes
+    p = H.PointGatherBulletEnv(seed=1)
+    p.reset()
+    p.step(np.array([1.0, 0.0]))
+    assert np.allclose(p.robot.body_real_xyz, p._backend().state[0, 0:3].cpu().numpy()) and p.robot.alive_bonus(0, 0) == 1
+    p.close()
+    a = H.AntGatherBulletEnv(num_envs=8, seed=1)
+    a.reset()
+    assert a.robot.body_xyz.shape == (8, 3) and a.robot.body_real_xyz.shape == (8, 3)
+    a.close()

@@ -378,6 +378,9 @@ CONFIG_MATRIX = [
     (K.HRL_POINT_GATHER, 45, dict(robot_coll_dist=-1.0, respawn=0)),
     (K.HRL_ANT_MAZE, 33, dict(inner_rew_weight=1.0)),
     (K.HRL_ANT_MAZE_MJ, 17, dict(inner_rew_weight=1.0)),
+    (K.HRL_ANT_FLAGRUN, 35, dict(flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0), flag_timeout=8, flag_max_targets=5)),  # ant_flagrun_env.py:59-64: open field
+    (K.HRL_ANT_FLAGRUN, 29, dict(flag_switch_on_collision=0, flag_timeout=7, flag_max_targets=4)),                                           # :183-194
+    (K.HRL_ANT_FLAGRUN, 19, dict(flag_manual_goals=1, flag_max_targets=0, flag_max_target_dist=3.0, flag_timeout=5)),                        # manual + close targets (:113-114)
 ]
 
 
@@ -450,10 +453,11 @@ def test_self_collision_rows_on_device():
 
 
 def test_flagrun_manual_goals_through_the_c_abi():
-    """hrl_set_goals (manual_goal_creation, ant_flagrun_env.py:91-118): goals visited in order, episode over when they run out."""
+    """hrl_set_goals / hrl_next_target (manual_goal_creation, ant_flagrun_env.py:45,112-120): the list is consumed from its back
+    (`goals.pop()`), the episode is over when it runs out; next_target() alone pops one goal, ok = 0 on an empty list."""
     import ctypes as C
     n, G = 64, 4
-    g, o = make(K.HRL_ANT_FLAGRUN, n, seed=6, flag_manual_goals=1, flag_max_targets=0, flag_timeout=0)
+    g, o = make(K.HRL_ANT_FLAGRUN, n, seed=6, flag_manual_goals=1, flag_timeout=0)
     g.cfg.auto_reset = 0
     g.reset(); o.reset()
     assert np.array_equal(g.items.cpu().numpy(), o.items)
@@ -462,6 +466,7 @@ def test_flagrun_manual_goals_through_the_c_abi():
     gobs = g.set_goals(torch.from_numpy(goals).cuda(), torch.from_numpy(mask).cuda())
     orc.lib().orc_set_goals_batch_f32(C.byref(o.cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(goals), G, orc.ptr(mask), orc.ptr(o.obs))
     assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux)
+    assert np.array_equal(o.items[mask == 1, 0:2], goals[mask == 1, G - 1])   # the LAST goal of the list is the first target
     assert obs_bad_rows(gobs.cpu().numpy(), o.obs).sum() == 0
     rng = np.random.RandomState(1)
     for t in range(10):
@@ -473,7 +478,63 @@ def test_flagrun_manual_goals_through_the_c_abi():
         assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux), t
         # (the masked-out envs still chase (1e3, 0): teleported outside the arena they blow up to NaN on both sides alike)
         assert np.array_equal(gr.cpu().numpy(), o.rew, equal_nan=True) and np.array_equal(gd.cpu().numpy(), o.done), t
+    # next_target() alone: envs 0..31 get one more goal as plain data, the others have an empty list (-> ok 0, unchanged)
+    o.state[:, 0:3] = np.array([0.5, -0.5, 0.5], np.float32)
+    o.items[:32, 2:4] = 1.25; o.aux[:32, 3] = (o.aux[:32, 3] & ~0xffff) | 1
+    o.aux[32:, 3] &= ~0xffff
+    push(g, o)
+    gobs, ok = g.next_target()
+    ok_o = np.zeros(n, np.uint8)
+    orc.lib().orc_next_target_batch_f32(C.byref(o.cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), None, orc.ptr(o.obs), orc.ptr(ok_o))
+    assert np.array_equal(ok.cpu().numpy(), ok_o) and ok_o[:32].all() and not ok_o[32:].any()
+    assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux)
+    assert obs_bad_rows(gobs.cpu().numpy(), o.obs).sum() == 0
     from hrl_pybullet_envs_amd import _lib
     bad, _ = make(K.HRL_ANT_FLAGRUN, 4)
     with pytest.raises(_lib.HrlError, match='manual'):
         bad.set_goals(torch.zeros(4, 2, 2).cuda())
+    close, oc = make(K.HRL_ANT_FLAGRUN, 32, seed=4, flag_manual_goals=1, flag_max_targets=0, flag_max_target_dist=3.0, flag_timeout=5)
+    with pytest.raises(_lib.HrlError, match='hrl_next_target'):   # max_targets < 1: next_target() never reads the list (:113-114)
+        close.set_goals(torch.zeros(32, 2, 2).cuda())
+    close.reset(); oc.reset()
+    gobs, ok = close.next_target()
+    orc.lib().orc_next_target_batch_f32(C.byref(oc.cfg), orc.ptr(oc.state), orc.ptr(oc.items), orc.ptr(oc.aux), None, orc.ptr(oc.obs), None)
+    assert bool(ok.all()) and np.array_equal(close.items.cpu().numpy(), oc.items) and obs_bad_rows(gobs.cpu().numpy(), oc.obs).sum() == 0
+    for t in range(12):
+        a = rng.uniform(-1, 1, (32, 8)).astype(np.float32)
+        close.step(torch.from_numpy(a).cuda()); oc.step(a)
+        assert np.array_equal(close.items.cpu().numpy(), oc.items) and np.array_equal(close.aux.cpu().numpy(), oc.aux), t
+        assert np.array_equal(close.state.cpu().numpy(), oc.state), t
+
+
+def test_flagrun_open_field_and_no_switch_on_device():
+    """The two flagrun branches the device had not run (ant_flagrun_env.py:59-64 `enclosed=False`, :183-194
+    `switch_flag_on_collision=False`), with the robots put where the branches matter: astride the absent wall, and on the goal."""
+    import ctypes as C
+    n = 64
+    kw = dict(flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0), flag_switch_on_collision=0, flag_timeout=6, flag_max_targets=3)
+    g, o = make(K.HRL_ANT_FLAGRUN, n, seed=3, **kw)
+    g.reset(); o.reset()
+    o.state[:, 0] = 6.0; o.state[:, 2] = 0.3
+    rng = np.random.RandomState(0)
+    for t in range(5):
+        push(g, o)
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state) and obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
+    assert np.all(np.abs(o.state[:, 0] - 6.0) < 0.5)
+    g.reset(); o.reset()
+    paid = np.zeros(n, int)
+    for t in range(14):
+        gl = np.zeros((n, 2), np.float32)
+        for i in range(n):
+            orc.lib().orc_flag_goal_f32(C.byref(o.cfg), int(o.aux[i, 2]), int(o.aux[i, 3] & 0xffff), orc.ptr(gl[i:i + 1]))
+        o.state[:, 0:2] = ((14 * gl) / 13).astype(np.float32); o.state[:, 2] = 0.5
+        push(g, o)
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state) and np.array_equal(g.aux.cpu().numpy(), o.aux), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
+        assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
+        paid += (o.rew > 1000).astype(int)
+    assert np.all(paid == 3)   # once per goal; the goal only moves with the timeout

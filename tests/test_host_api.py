@@ -165,8 +165,12 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert 'torch' not in bench.__dict__  # the parent's module level never imports torch
 
 
-def test_bench_roofline_reports_hbm_and_valu():
+def test_bench_roofline_reports_hbm_and_valu(monkeypatch):
     import bench
+    from hrl_pybullet_envs_amd.build import kernel_source_hash
+    monkeypatch.setattr(bench, 'pmc_summary', lambda kind: {'tag': 't', 'source_sha256': kernel_source_hash(), 'fetch_bytes_per_env': 250.0,
+                                                            'write_bytes_per_env': 480.0, 'valu_insts_per_env': 6000.0,
+                                                            'wave_cycles_per_env': 100000.0, 'kernel_us_profiled': 50.0})
     r = bench.roofline('gather', 4096, 70e-6)
     assert r['bound'] == 'hbm' and abs(r['achieved'] - 581 * 4096 / 70e-6 / 1e9) < 1e-9 and r['peak'] == 8000.0
     v = r['valu']
@@ -211,6 +215,18 @@ def test_mirrored_module_paths_and_reference_ids():
     mod, cls = FakeGym.envs.calls[0]['entry_point'].split(':')
     import importlib
     assert getattr(importlib.import_module(mod), cls) is H.AntGatherBulletEnv
+    # the reference imported in the same process has registered its ids already (an A/B script): those are skipped, nothing raises
+    class TakenGym:
+        class envs:
+            registry = {'AntGatherBulletEnv-v0': object(), 'PointGatherBulletEnv-v0': object()}
+            calls = []
+
+            @staticmethod
+            def register(**kw):
+                if kw['id'] in TakenGym.envs.registry:
+                    raise RuntimeError('Cannot re-register id: ' + kw['id'])
+                TakenGym.envs.calls.append(kw)
+    assert H.register_with(TakenGym) == ['AntMazeMjEnv-v0', 'AntMazeBulletEnv-v0', 'AntFlagrunBulletEnv-v0']
     # contact-based pickup and manual goals are constructor options now, as in the reference
     assert H.AntGatherBulletEnv(robot_coll_dist=0)._cfg.robot_coll_dist == 0.0
     f = H.AntFlagrunBulletEnv(manual_goal_creation=True)
@@ -232,3 +248,41 @@ def test_rgb_array_render_draws_the_scene():
     assert abs(np.linalg.norm(legs[0][2] - legs[0][1]) - 0.4 * np.sqrt(2)) < 1e-6  # the float32 quaternion is not exactly unit
     assert draw_env(H.AntMazeBulletEnv()._cfg, st, None, 64).shape == (64, 64, 3)
     assert draw_env(H.PointGatherBulletEnv()._cfg, st, items, 64).shape == (64, 64, 3)
+
+
+def test_host_philox_restates_the_shared_goal_list():
+    """`env.goals` / `env.goal` of a non-manual flagrun env evaluate the kernel's goal function on the host
+    (hrl_pybullet_envs_amd/_philox.py): same bits as the oracle's flag_goal for every (seed, episode, k) tried."""
+    import ctypes as C
+    import orc
+    from hrl_pybullet_envs_amd._philox import flag_goal
+    for seed, size in ((123, 10.0), (0, 1.2), (2 ** 40 + 17, 6.0)):
+        cfg = orc.default_config(K.HRL_ANT_FLAGRUN, seed=seed, flag_size=size)
+        ep, k = np.meshgrid(np.arange(1, 6), np.arange(1, 41), indexing='ij')
+        got = flag_goal(seed, size, ep, k)
+        want = np.zeros(got.shape, np.float32)
+        for i in range(ep.shape[0]):
+            for j in range(ep.shape[1]):
+                g = np.zeros(2, np.float32)
+                orc.lib().orc_flag_goal_f32(C.byref(cfg), int(ep[i, j]), int(k[i, j]), orc.ptr(g))
+                want[i, j] = g
+        assert np.array_equal(got, want)
+        assert np.all(np.linalg.norm(got, axis=-1) >= 0.5 - 1e-6) and np.all(np.abs(got) <= size / 2)
+
+
+def test_bench_withholds_counters_of_other_code(monkeypatch):
+    """bench.py reports `traffic` / `valu` from the committed PMC summary only while the summary's source hash equals the kernel
+    sources being benched (roofline.pmc_stale otherwise, counters withheld)."""
+    import bench
+    from hrl_pybullet_envs_amd.build import kernel_source_hash
+    fresh = {'tag': 't', 'source_sha256': kernel_source_hash(), 'fetch_bytes_per_env': 250.0, 'write_bytes_per_env': 480.0,
+             'valu_insts_per_env': 6000.0, 'wave_cycles_per_env': 100000.0, 'kernel_us_profiled': 50.0}
+    monkeypatch.setattr(bench, 'pmc_summary', lambda kind: dict(fresh))
+    r = bench.roofline('gather', 4096, 50e-6)
+    assert r['pmc_stale'] is False and r['traffic'] == (250.0 + 480.0) * 4096 and r['valu']['insts_per_env'] == 6000.0
+    assert r['achieved'] == pytest.approx(581 * 4096 / 50e-6 / 1e9) and r['frac'] == pytest.approx(r['achieved'] / 8000.0)
+    monkeypatch.setattr(bench, 'pmc_summary', lambda kind: dict(fresh, source_sha256='0' * 64))
+    r = bench.roofline('gather', 4096, 50e-6)
+    assert r['pmc_stale'] is True and r['traffic'] is None and 'valu' not in r
+    monkeypatch.setattr(bench, 'pmc_summary', lambda kind: {})
+    assert bench.roofline('gather', 4096, 50e-6)['pmc_stale'] is False   # no summary committed for this kernel: nothing to be stale

@@ -281,6 +281,100 @@ def test_flagrun_close_targets():
 
 
 
+def test_flagrun_manual_goal_sequences():
+    """manual_goal_creation sequences run on the reference itself (make_golden.py `flagrun_manual_seq`): `env.goals = [...];
+    env.next_target()` takes the LAST goal of the list (goals.pop(), ant_flagrun_env.py:116), the list is consumed back to front,
+    an empty list ends the episode (IndexError, :193-194) or raises from next_target(); a reset keeps the walk target and
+    steps_since_goal_change and drops the list (:132-155); with max_targets < 1 next_target() ignores the list and draws near
+    the robot (:113-114).  The oracle's record functions -- the ones orc_env_step_one / orc_env_set_goals_one call -- replay
+    every event."""
+    g = load('flagrun_manual_seq')
+    dt = g['dt']
+    L = orc.lib()
+    n_pops = n_raise = 0
+    for seq in g['list']:
+        cfg = orc.default_config(K.HRL_ANT_FLAGRUN, flag_manual_goals=1, flag_timeout=seq['timeout'], flag_switch_on_collision=int(seq['switch']))
+        o = orc.OracleEnv(cfg, np.float64)
+        st, items, aux = o.state[0], o.items[0], o.aux[0]
+        items[0] = 1000.0   # the walk target before the first episode: upstream's default (what a fresh record holds after reset)
+        prev = None
+        for e in seq['events']:
+            if e['op'] == 'reset':
+                before = items[0:2].copy(); steps_before = (aux[3] >> 16) & 0x7fff
+                o.reset()
+                assert np.array_equal(items[0:2], before) and np.all(items[2:] == 0) and (aux[3] & 0xffff) == 0   # target kept, list dropped
+                assert ((aux[3] >> 16) & 0x7fff) == steps_before == e['steps'] and not (aux[3] >> 31) & 1
+                np.testing.assert_allclose(items[0:2], e['target'], atol=1e-12)
+            elif e['op'] in ('set_goals', 'next_target'):
+                gl = arr(e['goals']).reshape(-1, 2)
+                L.orc_flag_goals_assign_f64(orc.ptr(items), orc.ptr(aux), orc.ptr(gl), len(gl))
+                ok = L.orc_flag_next_target_f64(C.byref(cfg), C.c_int64(0), orc.ptr(st), orc.ptr(items), orc.ptr(aux))
+                assert bool(ok) == (not e.get('raised', False))
+                n_raise += int(not ok)
+                np.testing.assert_allclose(items[0:2], e['target'], atol=1e-12)
+                if ok:
+                    np.testing.assert_allclose(items[0:2], gl[-1], atol=1e-12)   # goals.pop(): the LAST goal
+                    assert not (aux[3] >> 31) & 1
+                assert (aux[3] & 0xffff) == len(e['goals_left']) and ((aux[3] >> 16) & 0x7fff) == e['steps']
+                np.testing.assert_allclose(items[2:2 + 2 * len(e['goals_left'])].reshape(-1, 2), arr(e['goals_left']).reshape(-1, 2), atol=1e-12)
+            else:
+                wtd = float(np.linalg.norm(arr(e['pos'][:2]) - items[0:2]))
+                base = 1.0 + (e['potential'] - prev['potential'])
+                assert e['potential'] == pytest.approx(-wtd / dt, abs=1e-9)    # measured against the target in effect before the step
+                steps = C.c_int((aux[3] >> 16) & 0x7fff); rewarded = C.c_int((aux[3] >> 31) & 1); left = C.c_int(aux[3] & 0xffff)
+                rew = C.c_double(); done = C.c_int(); retarget = C.c_int()
+                L.orc_flagrun_task_f64(C.byref(cfg), C.c_double(base), 0, C.c_double(wtd), C.byref(steps), C.byref(rewarded), C.byref(left),
+                                       C.byref(rew), C.byref(done), C.byref(retarget))
+                if retarget.value:   # exactly what orc_env_step_one does next
+                    assert L.orc_flag_next_target_f64(C.byref(cfg), C.c_int64(0), orc.ptr(st), orc.ptr(items), orc.ptr(aux)) == 1
+                    n_pops += 1
+                aux[3] = np.array([(int(aux[3]) & 0xffff) | (steps.value << 16) | (rewarded.value << 31)], np.uint32).view(np.int32)[0]
+                assert rew.value == pytest.approx(e['rew'], abs=1e-6) and bool(done.value) == e['done'] and bool(retarget.value) == e['retargeted']
+                assert steps.value == e['steps'] and bool(rewarded.value) == e['rewarded'] and (aux[3] & 0xffff) == len(e['goals_left'])
+                np.testing.assert_allclose(items[0:2], e['target'], atol=1e-12)
+            prev = e
+    assert n_pops >= 8 and n_raise >= 8
+    n_draws = 0
+    for seq in g['close']:
+        cfg = orc.default_config(K.HRL_ANT_FLAGRUN, flag_manual_goals=1, flag_max_targets=0, flag_max_target_dist=seq['max_target_dist'],
+                                 flag_timeout=seq['timeout'], tol=seq['tol'], flag_size=seq['size'])
+        o = orc.OracleEnv(cfg, np.float64)
+        st, items, aux = o.state[0], o.items[0], o.aux[0]
+        items[0] = 1000.0
+        target, prev = [1000.0, 0.0], None
+        for e in seq['events']:
+            drew = len(e['u']) > 0
+            if e['op'] == 'reset':
+                o.reset()
+                assert not drew and e['target'] == target and np.array_equal(items[0:2], target) and (aux[3] & 0xffff) == 0  # reset draws nothing (:150-153)
+            elif e['op'] == 'next_target':
+                assert drew and e['list_len_after'] == 1   # the list was not touched: create_close_target (:113-114)
+                before = aux[3] & 0xffff
+                assert L.orc_flag_next_target_f64(C.byref(cfg), C.c_int64(0), orc.ptr(st), orc.ptr(items), orc.ptr(aux)) == 1
+                assert (aux[3] & 0xffff) == before + 1   # the goal counter of the episode keys the draw
+                d = np.abs(items[0:2] - st[0:2])
+                assert np.all(d >= seq['tol'] - 1e-9) and np.all(d <= seq['max_target_dist'] / 2 + 1e-9) and np.all(np.abs(items[0:2]) < seq['size'] / 2)
+            else:
+                wtd = float(np.linalg.norm(arr(e['pos'][:2]) - arr(target)))
+                base = 1.0 + (e['potential'] - prev['potential'])
+                steps = C.c_int(prev['steps']); rewarded = C.c_int(int(prev['rewarded'])); left = C.c_int(1 << 20)
+                rew = C.c_double(); done = C.c_int(); retarget = C.c_int()
+                L.orc_flagrun_task_f64(C.byref(cfg), C.c_double(base), 0, C.c_double(wtd), C.byref(steps), C.byref(rewarded), C.byref(left),
+                                       C.byref(rew), C.byref(done), C.byref(retarget))
+                assert rew.value == pytest.approx(e['rew'], abs=1e-6) and not done.value and not e['done'] and bool(retarget.value) == e['retargeted'] == drew
+                assert steps.value == e['steps'] and bool(rewarded.value) == e['rewarded']
+            if drew:   # the reference's draw, replayed with the uniforms / sign bits it consumed
+                n_draws += 1
+                gg = np.zeros(2); nat = len(e['u']) // 2
+                used = L.orc_flag_create_close_target_f64(C.c_double(seq['size']), C.c_double(seq['tol']), C.c_double(seq['max_target_dist']),
+                                                          orc.ptr(arr(e['pos'][:2])), orc.ptr(arr(e['u'])), np.asarray(e['b'], np.int32).ctypes.data_as(C.c_void_p), nat, orc.ptr(gg))
+                assert used == nat
+                np.testing.assert_allclose(gg, e['target'], atol=1e-12)
+            target, prev = e['target'], e
+            items[0:2] = target   # the record follows the reference's RandomState draws (the streams are not reproduced)
+    assert n_draws >= 20
+
+
 def test_gather_contact_pickup_step():
     """robot_coll_dist <= 0 (ant_gather_env.py:113-116, gather_base.py:103-106): one reward_collision() per contact point of
     the robot, AFTER the observation was assembled; items touched several times are paid and moved several times."""

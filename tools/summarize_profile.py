@@ -12,6 +12,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hrl_pybullet_envs_amd.build import kernel_source_hash  # noqa: E402
 
 
 def main():
@@ -41,7 +43,7 @@ def main():
                     acc[r['Counter_Name']].append(float(r['Counter_Value']))
             for k, v in acc.items():
                 counters[k] = {'launches': len(v), 'mean_per_launch': sum(v) / len(v), 'mean_per_wave': sum(v) / len(v) / n_envs}
-    meta = {'source': src, 'kernel': f'k_step<{kind}>', 'envs_per_launch': n_envs,
+    meta = {'source': src, 'kernel': f'k_step<{kind}>', 'envs_per_launch': n_envs, 'source_sha256': kernel_source_hash(),
             'command': 'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline',
             'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (rocprofv3); on gfx950 FETCH_SIZE is calibrated (x2) only for 16-B/lane '
                      'streams (MI355X_MICROARCH.md, HBM): the dword-per-lane scratch traffic and 4-B/lane record loads here are '
@@ -51,7 +53,7 @@ def main():
     if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
         path = os.path.join(out_dir, 'pmc_summary.json')
         summ = json.load(open(path)) if os.path.exists(path) else {}
-        summ[kind] = {'tag': tag, 'envs_per_launch': n_envs,
+        summ[kind] = {'tag': tag, 'envs_per_launch': n_envs, 'source_sha256': kernel_source_hash(),
                       'fetch_bytes_per_env': counters['FETCH_SIZE']['mean_per_launch'] * 1024 / n_envs,
                       'write_bytes_per_env': counters['WRITE_SIZE']['mean_per_launch'] * 1024 / n_envs}
         if 'SQ_INSTS_VALU' in counters:  # one wave per env: per-wave counters are per-env counters
