@@ -167,7 +167,7 @@ def test_flagrun_manual_goal_creation_class_api_and_render():
     env.reset()
     assert env.goal == (1000.0, 0.0)                      # upstream's default walk target until goals are pushed
     ob = env.set_goals([[1.0, 2.0], [-2.0, 0.5]])
-    assert ob.shape == (28,) and env.goal == (1.0, 2.0)
+    assert ob.shape == (28,) and env.goal == (-2.0, 0.5)     # goals.pop(): the LAST goal of the list first (ant_flagrun_env.py:116)
     ob, rew, done, info = env.step(np.zeros(8))
     assert ob.shape == (28,) and not done
     img = env.render('rgb_array')

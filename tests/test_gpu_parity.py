@@ -537,4 +537,4 @@ def test_flagrun_open_field_and_no_switch_on_device():
         assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
         assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
         paid += (o.rew > 1000).astype(int)
-    assert np.all(paid == 3)   # once per goal; the goal only moves with the timeout
+    assert np.all(paid >= 3) and np.all(paid <= 4)   # once per goal (the goal only moves with the timeout); out of goals -> done -> auto-reset -> a new list
