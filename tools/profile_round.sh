@@ -11,4 +11,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
   --kernel-trace --output-format csv -d $O/pmc_sq1 -- $B > $O/s1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
   --kernel-trace --output-format csv -d $O/pmc_sq2 -- $B > $O/s2.log 2>&1 || exit 1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU \
+  --kernel-trace --output-format csv -d $O/pmc_sq3 -- $B > $O/s3.log 2>&1 || exit 1
 echo profiled into $O
