@@ -65,7 +65,7 @@ struct GpuExec {
     /* 1.0 on lane r (wave-uniform), 0.0 elsewhere: one v_cndmask on a scalar lane mask */
     __device__ __forceinline__ float lane_one(int, int r) {
         float d;
-        const unsigned long long m = 1ull << __builtin_amdgcn_readfirstlane(r); /* r is wave-uniform; said so, the shift stays scalar */
+        const unsigned long long m = 1ull << r;
         asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(d) : "s"(m));
         return d;
     }
@@ -142,71 +142,6 @@ struct GpuExec {
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r.lam) : "v"(r.lam), "v"(v.ln), "s"(owner));
         apply(lane, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.dl), src)));
     }
-    /* A block of solver rows as ONE unrolled slot sequence entered by a computed jump (no per-row count test: s_cmp + s_cbranch
-     * cost 14 of a row's 46 cycles, tools/micro/issue_cost.hip).  Slot J holds what each_row does for the row in register slot J
-     * (step_core.h, build_An_group: the registers are end-aligned, so the last n slots are the block's n rows in order):
-     *   candidate impulse = med3(c, lo, hi); its change; the row's lane index is a scalar counter, the owner's lane mask a scalar
-     *   pair shifted along; the owner keeps its candidate (v_cndmask), its change is read into a scalar (v_readlane, lane select
-     *   from the counter) and every lane applies c += C[.][row] * change (v_fmac with the scalar operand).
-     * Spacing: SALU write -> v_readlane lane select needs no wait (only VALU-written selects do); v_readlane -> VALU read of the
-     * scalar has the two required wait states (v_cndmask, s_lshl) in between.  first = lane of the block's first row. */
-#ifdef HRL_ROW_SWEEPS /* A/B builds only: rows one at a time through each_row, as in round 2 */
-    static constexpr bool block_sweeps = false;
-#else
-    static constexpr bool block_sweeps = true;
-#endif
-#define HRL_SLOT(A) \
-    "v_med3_f32 %[ln], %[c], %[lo], %[hi]\n\t" \
-    "v_sub_f32 %[dl], %[ln], %[lam]\n\t" \
-    "s_add_u32 s23, s23, 1\n\t" \
-    "v_readlane_b32 s22, %[dl], s23\n\t" \
-    "v_cndmask_b32_e64 %[lam], %[lam], %[ln], s[24:25]\n\t" \
-    "s_lshl_b64 s[24:25], s[24:25], 1\n\t" \
-    "v_fmac_f32 %[c], s22, %[" A "]\n\t"
-#define HRL_SWEEP_ENTRY \
-    "s_sub_u32 s23, %[first], 1\n\t" \
-    "s_lshl_b64 s[24:25], 1, %[first]\n\t" \
-    "s_getpc_b64 s[20:21]\n\t" \
-    ".Lbase_%=:\n\t" \
-    "s_mul_i32 s26, %[skip], (.Ls1_%= - .Ls0_%=)\n\t" \
-    "s_add_u32 s20, s20, s26\n\t" \
-    "s_addc_u32 s21, s21, 0\n\t" \
-    "s_add_u32 s20, s20, (.Ls0_%= - .Lbase_%=)\n\t" \
-    "s_addc_u32 s21, s21, 0\n\t" \
-    "s_setpc_b64 s[20:21]\n\t"
-    __device__ __forceinline__ void sweep_bounded(int nB) {
-        float ln, dl;
-        const int skip = __builtin_amdgcn_readfirstlane(MAXB - nB), first = 0;
-        asm volatile(HRL_SWEEP_ENTRY
-            ".Ls0_%=:\n\t" HRL_SLOT("a0") ".Ls1_%=:\n\t" HRL_SLOT("a1") HRL_SLOT("a2") HRL_SLOT("a3") HRL_SLOT("a4") HRL_SLOT("a5") HRL_SLOT("a6") HRL_SLOT("a7")
-            HRL_SLOT("a8") HRL_SLOT("a9") HRL_SLOT("a10") HRL_SLOT("a11") HRL_SLOT("a12") HRL_SLOT("a13") HRL_SLOT("a14") HRL_SLOT("a15")
-            HRL_SLOT("a16") HRL_SLOT("a17") HRL_SLOT("a18") HRL_SLOT("a19")
-            : [c] "+v"(r.c), [lam] "+v"(r.lam), [ln] "=&v"(ln), [dl] "=&v"(dl)
-            : [lo] "v"(r.lo), [hi] "v"(r.hi), [skip] "s"(skip), [first] "s"(first),
-              [a0] "v"(r.An[0]), [a1] "v"(r.An[1]), [a2] "v"(r.An[2]), [a3] "v"(r.An[3]), [a4] "v"(r.An[4]), [a5] "v"(r.An[5]), [a6] "v"(r.An[6]),
-              [a7] "v"(r.An[7]), [a8] "v"(r.An[8]), [a9] "v"(r.An[9]), [a10] "v"(r.An[10]), [a11] "v"(r.An[11]), [a12] "v"(r.An[12]), [a13] "v"(r.An[13]),
-              [a14] "v"(r.An[14]), [a15] "v"(r.An[15]), [a16] "v"(r.An[16]), [a17] "v"(r.An[17]), [a18] "v"(r.An[18]), [a19] "v"(r.An[19])
-            : "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26");
-        static_assert(MAXB == 20, "one slot per register of LaneRegs::An");
-    }
-    __device__ __forceinline__ void sweep_friction(int nB, int nF) {
-        float ln, dl;
-        const int skip = __builtin_amdgcn_readfirstlane(MAXF - nF), first = __builtin_amdgcn_readfirstlane(nB);
-        asm volatile(HRL_SWEEP_ENTRY
-            ".Ls0_%=:\n\t" HRL_SLOT("a0") ".Ls1_%=:\n\t" HRL_SLOT("a1") HRL_SLOT("a2") HRL_SLOT("a3") HRL_SLOT("a4") HRL_SLOT("a5") HRL_SLOT("a6") HRL_SLOT("a7")
-            HRL_SLOT("a8") HRL_SLOT("a9") HRL_SLOT("a10") HRL_SLOT("a11") HRL_SLOT("a12") HRL_SLOT("a13") HRL_SLOT("a14") HRL_SLOT("a15")
-            HRL_SLOT("a16") HRL_SLOT("a17") HRL_SLOT("a18") HRL_SLOT("a19") HRL_SLOT("a20") HRL_SLOT("a21") HRL_SLOT("a22") HRL_SLOT("a23")
-            : [c] "+v"(r.c), [lam] "+v"(r.lam), [ln] "=&v"(ln), [dl] "=&v"(dl)
-            : [lo] "v"(r.lo), [hi] "v"(r.hi), [skip] "s"(skip), [first] "s"(first),
-              [a0] "v"(r.Af[0]), [a1] "v"(r.Af[1]), [a2] "v"(r.Af[2]), [a3] "v"(r.Af[3]), [a4] "v"(r.Af[4]), [a5] "v"(r.Af[5]), [a6] "v"(r.Af[6]),
-              [a7] "v"(r.Af[7]), [a8] "v"(r.Af[8]), [a9] "v"(r.Af[9]), [a10] "v"(r.Af[10]), [a11] "v"(r.Af[11]), [a12] "v"(r.Af[12]), [a13] "v"(r.Af[13]),
-              [a14] "v"(r.Af[14]), [a15] "v"(r.Af[15]), [a16] "v"(r.Af[16]), [a17] "v"(r.Af[17]), [a18] "v"(r.Af[18]), [a19] "v"(r.Af[19]),
-              [a20] "v"(r.Af[20]), [a21] "v"(r.Af[21]), [a22] "v"(r.Af[22]), [a23] "v"(r.Af[23])
-            : "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26");
-        static_assert(MAXF == 24, "one slot per register of LaneRegs::Af");
-    }
-#undef HRL_SLOT
-#undef HRL_SWEEP_ENTRY
     /* every lane fetches the value of the lane it names (ds_bpermute_b32: LDS crossbar, no memory) */
     template <class V, class I, class C>
     __device__ __forceinline__ void each_shuffle(V value, I index, C consume) {

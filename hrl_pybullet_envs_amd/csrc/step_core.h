@@ -101,8 +101,6 @@ struct DevBufs {
  * block: the K1 -> K2 hand-off of a substep, the velocity responses B of the solver rows (written in phase R1, read
  * until the end of the substep) and the task scratch of the epilogue (observation packing, after the substeps). */
 struct alignas(16) WaveLds {
-    float Bfront[3][16]; /* readable rows in front of Bt: the end-aligned column build (build_An_group) reads up to three rows before the
-                            block's first row inside its first group of four; those values are never used */
     union {
         float Bt[MAXR + 2][16];  /* B[r][d] = (M^-1 J_r^T)[d]: velocity response of every solver row (+2: the last
                                     group of four friction columns may read two rows past the end, values unused) */
@@ -164,7 +162,7 @@ struct LaneRegs {
     float Jb[6], Jh, Ja;             /* row map: the row's Jacobian, sparse: torso twist part + the hip / ankle entries */
     int jslot;                       /* row map: dof slot of Jh (Ja is the next slot): 6 + 2 * leg, | (6 + 2 * leg2) << 8 for WaveLds::J2 */
     float mu;                        /* row map: friction rows: friction coefficient of their contact */
-    float An[MAXB], Af[MAXF];        /* row map: the row's line of C = I - D^-1 A (A = J M^-1 J^T): limit/normal columns, friction columns; END-aligned (build_An_group) */
+    float An[MAXB], Af[MAXF];        /* row map: the row's line of C = I - D^-1 A (A = J M^-1 J^T): limit/normal columns, friction columns */
     float c, lam, bias, lo, hi;      /* row map: unclamped impulse candidate lam - w / A_ii, impulse, bias, bounds */
     int fn;                          /* row map: friction rows: index of their normal row, else -1 */
 };
@@ -841,65 +839,32 @@ HRL_DEV float row_dot(const LaneRegs &g, const float *Brow, const J2pair &j2) {
     }
     return a;
 }
-/* The same product for the row at float offset `off` (compile-time) from three bases: B0 = the block's first register slot's row,
- * B1 = B0 + the lane's first joint slot, B2 = B0 + its second (SELF): every LDS access is then base register + immediate offset. */
-template <bool SELF>
-HRL_DEV float row_dot_at(const LaneRegs &g, const float *B0, const float *B1, const float *B2, int off, const J2pair &j2) {
-    float a = g.Jb[0] * B0[off];
-#pragma unroll
-    for (int d = 1; d < 6; ++d) a = fma_(g.Jb[d], B0[off + d], a);
-    a = fma_(g.Jh, B1[off], a);
-    a = fma_(g.Ja, B1[off + 1], a);
-    if (SELF) {
-        a = fma_(j2.h, B2[off], a);
-        a = fma_(j2.a, B2[off + 1], a);
-    }
-    return a;
-}
-/* The registers are END-ALIGNED: An[MAXB - nB + r] holds the column of bounded row r and Af[MAXF - nF + k] that of friction row
- * nB + k, so that a sweep is a straight run through the LAST nB (nF) register slots -- the device enters its unrolled slot
- * sequence at slot MAXB - nB by a computed jump and needs no per-row count test (GpuExec::sweep_*).
- * Registers 4G..4G+3 of a block behind one wave-uniform test (flat sequence of groups, no nesting).  Slots in front of the
- * block's first row inside its first group are computed from the (readable, WaveLds::Bfront) rows in front and never read. */
-struct Bbases { const float *b0, *b1, *b2; int first; }; /* register slot j <-> LDS row at b0 + 16 j, solver row first + j */
+/* columns 4G..4G+3 of a block behind one wave-uniform test (flat sequence of groups, no nesting).  Columns past the
+ * block's end inside its last group are computed from whatever LDS holds and never read by the sweeps. */
 template <bool SELF, int G, class One>
-HRL_DEV void build_An_group(const Bbases &B, LaneRegs &g, int nB, float ninvd, One one, const J2pair &j2) {
-    if (4 * G + 3 >= MAXB - nB) {
+HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, One one, const J2pair &j2) {
+    if (4 * G < nB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot_at<SELF>(g, B.b0, B.b1, B.b2, 16 * (4 * G + i), j2), one(B.first + 4 * G + i));
+        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[4 * G + i], j2), one(4 * G + i));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.An[4 * G + i] = 0.f;
     }
 }
 template <bool SELF, int G, class One>
-HRL_DEV void build_Af_group(const Bbases &B, LaneRegs &g, int nF, float ninvd, One one, const J2pair &j2) {
-    if (4 * G + 3 >= MAXF - nF) {
+HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, const J2pair &j2) {
+    if (4 * G < nF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot_at<SELF>(g, B.b0, B.b1, B.b2, 16 * (4 * G + i), j2), one(B.first + 4 * G + i));
+        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[nB + 4 * G + i], j2), one(nB + 4 * G + i));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = 0.f;
     }
 }
-template <bool SELF>
-HRL_DEV Bbases row_bases(const WaveLds &L, const LaneRegs &g, int first) {
-    Bbases B;
-    B.first = first;
-    /* first may be as low as -3: WaveLds::Bfront.  The bases as they are, in registers: the compiler otherwise re-bases on something with
-     * negative offsets (one address add per access).  What is pinned are the row index and the HALVED joint slots, so that the 64-byte /
-     * 8-byte alignment of the addresses stays visible (ds_read_b128 / ds_read_b64) and the pointers stay LDS pointers. */
-    int f = first, h1 = (g.jslot & 0xff) >> 1, h2 = SELF ? (g.jslot >> 9) : 0;
-    HRL_PIN_VGPR(f); HRL_PIN_VGPR(h1); HRL_PIN_VGPR(h2);
-    B.b0 = &L.Bt[0][0] + 16 * f; B.b1 = B.b0 + 2 * h1; B.b2 = B.b0 + 2 * h2;
-    return B;
-}
 template <bool SELF, class One, int... Gn, int... Gf>
 HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, const J2pair &j2, std::integer_sequence<int, Gn...>, std::integer_sequence<int, Gf...>) {
-    const Bbases Bn = row_bases<SELF>(L, g, -(MAXB - nB));
-    (build_An_group<SELF, Gn>(Bn, g, nB, ninvd, one, j2), ...);
-    const Bbases Bf = row_bases<SELF>(L, g, nB - (MAXF - nF));
-    (build_Af_group<SELF, Gf>(Bf, g, nF, ninvd, one, j2), ...);
+    (build_An_group<SELF, Gn>(L, g, nB, ninvd, one, j2), ...);
+    (build_Af_group<SELF, Gf>(L, g, nB, nF, ninvd, one, j2), ...);
 }
 template <bool SELF, class One>
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
@@ -970,27 +935,24 @@ HRL_DEV F2b pgs_candidate(const LaneRegs &g) {
     o.dl = o.ln - g.lam;
     return o;
 }
-template <int J, class X>
-HRL_DEV void pgs_row_bounded(X &x, int nB) { /* register slot J (compile-time index: An[J] is a register) = limit or normal row J - (MAXB - nB) */
-    const int r = J - (MAXB - nB);
-    if (r < 0) return; /* wave-uniform: a slot in front of the block */
-    x.each_row(r, [&](int lane) { return pgs_candidate(x.reg(lane)); },
-               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.An[J], dl, g.c); });
+template <int R, class X>
+HRL_DEV bool pgs_row_bounded(X &x, int nB) { /* limit or normal row R (compile-time index: An[R] is a register) */
+    if (R >= nB) return false; /* wave-uniform: ends the block (the fold below short-circuits) */
+    x.each_row(R, [&](int lane) { return pgs_candidate(x.reg(lane)); },
+               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.An[R], dl, g.c); });
+    return true;
 }
-template <int J, class X>
-HRL_DEV void pgs_row_friction(X &x, int nB, int nF) { /* register slot J = friction row nB + J - (MAXF - nF) */
-    const int k = J - (MAXF - nF);
-    if (k < 0) return;
-    x.each_row(nB + k, [&](int lane) { return pgs_candidate(x.reg(lane)); },
-               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.Af[J], dl, g.c); });
+template <int K, class X>
+HRL_DEV bool pgs_row_friction(X &x, int nB, int nF) { /* friction row nB + K */
+    if (K >= nF) return false;
+    x.each_row(nB + K, [&](int lane) { return pgs_candidate(x.reg(lane)); },
+               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.Af[K], dl, g.c); });
+    return true;
 }
-template <class X, int... Js, int... Ks>
-HRL_DEV void pgs_sweep(X &x, int nB, int nF, std::integer_sequence<int, Js...>, std::integer_sequence<int, Ks...>) {
-    /* rows in order: the bounded block, the friction bounds from the normal impulses as they stand now, the friction block.
-     * An executor may run a block of rows as one unit (the device: a computed jump into an unrolled slot sequence). */
-    if constexpr (X::block_sweeps) x.sweep_bounded(nB);
-    else (pgs_row_bounded<Js>(x, nB), ...);
-    x.stamp(10); /* (diagnostic builds: the bounded block; ids 10 / 11 are the point kernel's otherwise) */
+template <class X, int... Rs, int... Ks>
+HRL_DEV void pgs_sweep(X &x, int nB, int nF, std::integer_sequence<int, Rs...>, std::integer_sequence<int, Ks...>) {
+    /* rows in order as flat sequences with one forward exit each (no nesting: nested wave-uniform ifs cost an SGPR pair each) */
+    (void)(pgs_row_bounded<Rs>(x, nB) && ...);
     if (nF <= 0) return;
     x.each_shuffle([&](int lane) { return x.reg(lane).lam; },
                    [&](int lane) { const int fn = x.reg(lane).fn; return fn >= 0 ? fn : lane; },
@@ -998,9 +960,7 @@ HRL_DEV void pgs_sweep(X &x, int nB, int nF, std::integer_sequence<int, Js...>, 
                        LaneRegs &g = x.reg(lane);
                        if (g.fn >= 0) { g.hi = g.mu * ln; g.lo = -g.hi; }
                    });
-    x.stamp(11); /* the friction bounds */
-    if constexpr (X::block_sweeps) x.sweep_friction(nB, nF);
-    else (pgs_row_friction<Ks>(x, nB, nF), ...);
+    (void)(pgs_row_friction<Ks>(x, nB, nF) && ...);
 }
 template <class X>
 HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool self) {
@@ -1014,8 +974,8 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
     for (int it = 0; it < iters; ++it) {
         int nb = nB, nf = nF;
         x.refresh();
-        x.refresh_uniform(nb); /* run-time values inside the loop: nothing derived from them is hoisted out of it and kept live */
-        x.refresh_uniform(nf);
+        x.refresh_uniform(nb); /* keeps the 44 row-count tests inside the sweep as scalar compares (hoisted out of */
+        x.refresh_uniform(nf); /* the loop they become 44 live lane-mask pairs, most of them spilled)             */
         pgs_sweep(x, nb, nf, std::make_integer_sequence<int, MAXB>{}, std::make_integer_sequence<int, MAXF>{});
     }
     x.stamp(9);
@@ -1053,9 +1013,6 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_leg_sum(L, lane & 15); phase_leg_sum(L, (lane & 15) + 16); });
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_base(L, x.reg(lane), (lane & 15) << 2); });
     x.stamp(3);
-    /* (measured, profiles/r3_variants_ab.txt: the forward pass on every env's own wave, in one instruction stream with its row build,
-     * takes it off this block -- the group's critical path -- but costs 1.0 - 1.7 us per launch: four copies of it contend for more
-     * than the leader saves) */
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); const float v = phase_forward_vel(c, L, lane & 15); L.ustar[lane & 15] = v; });
     x.stamp(4);
 }

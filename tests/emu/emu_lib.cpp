@@ -46,7 +46,6 @@ struct CpuExec {
     int slot() const { return 0; } /* scheduling hints of the device executor: no effect on results */
     void priority(int) const {}
     void refresh_uniform(int &) {}
-    static constexpr bool block_sweeps = false; /* rows one at a time through each_row */
     float lane_one(int lane, int r) { return lane == r ? 1.f : 0.f; }
     void stamp(int) {}
     void flush_stamps(const DevBufs &) {}

@@ -15,7 +15,7 @@ from hrl_pybullet_envs_amd import _capi as K  # noqa: E402
 from hrl_pybullet_envs_amd import _lib  # noqa: E402
 
 NAMES = ['(block entry)', 'K1 kin+ankle', 'K2 hip', 'S+B base', 'V forward/vel', 'C contacts', 'L limits', 'R1 rows J,B',
-         'R2 A,w', 'PGS friction block (+loop)', 'PGS bounded block | point: final u', 'PGS friction bounds | point: integrate', 'load/init', '(substeps->obs)', 'obs: pack (+reset copy)', 'reward+store',
+         'R2 A,w', 'PGS sweeps', 'point: final u', 'point: integrate', 'load/init', '(substeps->obs)', 'obs: pack (+reset copy)', 'reward+store',
          '(group block end)', 'WAIT for leader', 'recon+clamp', 'WAIT for env blocks', 'I integrate', 'obs: calc_state', 'obs: items', '']
 
 
