@@ -38,6 +38,21 @@ __global__ __launch_bounds__(64, 1) void k(unsigned long long *out, float *sink,
                   REP256(asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_sub_f32 %3, %2, %1\n\tv_cndmask_b32_e64 %1, %1, %2, %7\n\t"
                                      "ds_bpermute_b32 %8, %9, %3\n\ts_waitcnt lgkmcnt(0)\n\tv_fmac_f32 %0, %8, %6"
                                      : "+v"(c), "+v"(lam), "+v"(t), "+v"(u) : "v"(lo), "v"(hi), "v"(C), "s"(mask), "v"(t2), "v"(addr));) }
+    // the slot of round 3's first attempt: scalar lane counter and shifted mask (two SALU per row), no branch
+    if (P == 5) { asm volatile("s_mov_b32 s23, 2\n\ts_mov_b64 s[24:25], 8" ::: "s23", "s24", "s25");
+                  REP256(asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_sub_f32 %3, %2, %1\n\ts_add_u32 s23, s23, 0\n\tv_readlane_b32 s22, %3, s23\n\t"
+                                     "v_cndmask_b32_e64 %1, %1, %2, s[24:25]\n\ts_lshl_b64 s[24:25], s[24:25], 0\n\tv_fmac_f32 %0, s22, %6"
+                                     : "+v"(c), "+v"(lam), "+v"(t), "+v"(u) : "v"(lo), "v"(hi), "v"(C) : "s22", "s23", "s24", "s25", "scc");) }
+    // compile-time lane: owner select by v_cmp on the lane id (VCC), no scalar instruction, no branch
+    if (P == 6) { int lid = threadIdx.x;
+                  REP256(asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_sub_f32 %3, %2, %1\n\tv_readlane_b32 s22, %3, 3\n\tv_cmp_eq_u32_e32 vcc, 3, %7\n\t"
+                                     "v_cndmask_b32_e32 %1, %1, %2, vcc\n\tv_fmac_f32 %0, s22, %6"
+                                     : "+v"(c), "+v"(lam), "+v"(t), "+v"(u) : "v"(lo), "v"(hi), "v"(C), "v"(lid) : "s22", "vcc");) }
+    // round 2's row as compiled: count test and not-taken branch, mask in an SGPR pair
+    if (P == 7) { int sc = 5;
+                  REP256(asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_sub_f32 %3, %2, %1\n\ts_cmp_lt_u32 %8, 3\n\tv_readlane_b32 s22, %3, 3\n\t"
+                                     "v_cndmask_b32_e64 %1, %1, %2, %7\n\ts_nop 1\n\tv_fmac_f32 %0, s22, %6\n\ts_cbranch_scc1 1f\n1:"
+                                     : "+v"(c), "+v"(lam), "+v"(t), "+v"(u) : "v"(lo), "v"(hi), "v"(C), "s"(mask), "s"(sc) : "s22", "scc");) }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
     sink[blockIdx.x * 64 + threadIdx.x] = c + lam + t + u + t2;
@@ -74,6 +89,9 @@ int main() {
     for (int r = 0; r < 3; ++r) { printf(r == 0 ? "newbcast:3 x2 + permlane16_swap, vdst : " : r == 1 ? "                                 src  : " : "100 + fmac_dpp row_newbcast:5 of lane id: ");
         for (int i = 0; i < 64; i += 4) printf("%g ", h[64 * r + i]); printf("\n"); }
     for (int blocks : {256, 1024, 4096}) {
+        run<7>("1 env/wave, round 2's row: + s_cmp, s_nop 1, not-taken s_cbranch", blocks, 8);
+        run<5>("1 env/wave, scalar lane counter + shifted mask (2 SALU), no branch", blocks, 7);
+        run<6>("1 env/wave, compile-time lane, v_cmp + v_cndmask vcc, no SALU, no branch", blocks, 6);
         run<3>("1 env/wave: med3 sub readlane cndmask nop fmac", blocks, 6);
         run<0>("4 envs/wave (16 lanes): med3 sub cndmask fmac_dpp newbcast", blocks, 4);
         run<1>("2 envs/wave (32 lanes): med3 sub cndmask 2 x mov_dpp permlane16_swap fmac", blocks, 8);
