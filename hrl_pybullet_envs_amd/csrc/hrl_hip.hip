@@ -129,6 +129,17 @@ struct GpuExec {
         wave_sync();
         return __popcll(m);
     }
+    /* the same per 16-lane slice (four envs per wave): rank and count within the lane's slice; post also gets the slice's count */
+    template <class P, class W, class Q>
+    __device__ __forceinline__ void each_compact16(P pred, W write, Q post) {
+        auto h = pred(lane);
+        const unsigned long long m = __ballot(h.ok);
+        const unsigned sub = (unsigned)(m >> (lane & 48)) & 0xffffu;
+        const int rank = __popc(sub & ((1u << (lane & 15)) - 1u));
+        if (h.ok) write(lane, rank, h);
+        post(lane, h, __popc(sub));
+        wave_sync();
+    }
     /* lane mask of a predicate (v_cmp into an SGPR pair) */
     template <class P>
     __device__ __forceinline__ unsigned long long each_ballot(P pred) { return __ballot(pred(lane)); }

@@ -148,6 +148,7 @@ struct alignas(16) WaveLds {
     float lsign[NJ], ldist[NJ];
     int gtouch[16];
     int nC, nL, nS, on; /* contacts / limit rows / self contacts found by ant_contacts for this env's substep; on = the record holds an env */
+    int ncnt;           /* ant_contacts_group: contacts a packed pass found for this env (added to nC by the next phase) */
     float planes[4][4];  /* lateral half-spaces (n, d), copied from the constants when the env is loaded: the collision passes index them per lane */
 #ifdef HRL_WGTIME
     int dbg_rows; /* diagnostic build (tools/wg_times.py): solver rows | cube passes << 16 | self-contact substeps << 24, summed over the step */
@@ -649,13 +650,13 @@ HRL_DEV float sphere_vs_box(const float *p, float rad, const float *lo, const fl
  * to surface f: 0 ground, 1..n_planes lateral half-spaces, n_planes+1.. world boxes; item >= 0: the item cube `item` */
 HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q, int sph, int f, int item) {
     Hit h;
+    float r_torso = c.r_torso, r_caps = c.r_caps, ctr[3] = {0.f, 0.f, 0.f};
+    HRL_PIN_SCALAR(r_torso); /* two scalar loads and a select: left alone, the compiler selects the ADDRESS per lane and */
+    HRL_PIN_SCALAR(r_caps);  /* fetches the radius with a vector memory load in the middle of the collision pass           */
     h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu;
     h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.r[0] = h.r[1] = h.r[2] = 0.f;
     if (sph < 0 || sph >= 13) return h;
     int level = 0, leg = 0;
-    float r_torso = c.r_torso, r_caps = c.r_caps, ctr[3] = {0.f, 0.f, 0.f};
-    HRL_PIN_SCALAR(r_torso); /* two scalar loads and a select: left alone, the compiler selects the ADDRESS per lane and */
-    HRL_PIN_SCALAR(r_caps);  /* fetches the radius with a vector memory load in the middle of the collision pass           */
     const float rad = sph > 0 ? r_caps : r_torso;
     if (sph > 0) {
         leg = (sph - 1) / 3; level = (sph - 1) % 3;
@@ -1158,6 +1159,153 @@ HRL_DEV void ant_limits(X &x, const DevCfg &c, WaveLds &L, int qi) {
     });
 }
 
+/* One kept contact into the record (contact index i < MAXC). */
+HRL_DEV void store_contact(WaveLds &L, int i, const Hit &h, bool up) {
+    if (i < MAXC) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) L.cr[i][k] = h.r[k];
+        store_contact_frame(L, i, h.n, up);
+        L.cdist_[i] = h.dist; L.clink[i] = h.link; L.clink2[i] = h.link2; L.csurf[i] = h.surf; L.cmu[i] = h.mu;
+    }
+}
+
+/* Contacts of ALL FOUR envs of a group by ONE wave, 16 lanes per env (lane >> 4 = env of the group, lane & 15 = sphere / item / joint):
+ * the passes every substep runs -- leg points, the ground pass (13 spheres), the near-cube ballot and one cube per env and pass -- are
+ * one instruction stream for the four envs instead of four streams (the group's vector-instruction count, which is what four workgroups per
+ * CU contend for, falls by the contact phase of three envs); the passes that only envs near a wall / the maze box / with legs out of their
+ * safe range need run env by env with all 64 lanes, as in ant_contacts.  Per env the candidate order is unchanged: ground, walls, box,
+ * cubes in slot order -- each sphere-minor -- then the capsule pairs.  Results per record: the contact list, nC, nS, gtouch. */
+template <class X>
+HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
+    x.refresh();
+    x.each([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_kin_ankle<true>(c, L, x.reg(lane), L.q[qi], (lane & 15) << 2); });
+    const float reach = 0.2f * 1.41421356f + c.L1 + c.L2 + c.r_caps + c.cdist + 0.02f;
+    /* ground pass of the four envs; its count starts the env's list */
+    x.each_compact16(
+        [&](int lane) { WaveLds &L = x.lds(lane >> 4); const int s = lane & 15; return sphere_vs_surface(c, L, L.q[qi], s < 13 ? s : -1, 0, -1); },
+        [&](int lane, int rank, const Hit &h) { store_contact(x.lds(lane >> 4), rank, h, true); },
+        [&](int lane, const Hit &h, int count) {
+            WaveLds &L = x.lds(lane >> 4);
+            L.gtouch[lane & 15] = h.ok ? 1 : 0;
+            if ((lane & 15) == 0) { L.nC = count > MAXC ? MAXC : count; L.nS = 0; }
+        });
+    /* lateral surfaces and the maze box: the envs within reach of one, one after the other (wave-uniform loop, all 64 lanes per env) */
+    if (c.n_planes > 0 || c.n_boxes > 0) {
+        const unsigned long long need = x.each_ballot([&](int lane) {
+            const float *q = x.lds(lane >> 4).q[qi];
+            bool near = false;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                near = near | ((f < c.n_planes) & ((c.plane_n[f][0] * q[0] + c.plane_n[f][1] * q[1] + c.plane_n[f][2] * q[2]) - c.plane_d[f] < reach));
+            if (c.n_boxes > 0) {
+                float d2 = 0.f;
+                for (int k = 0; k < 3; ++k) { const float cp = clampf(q[k], c.box_lo[k], c.box_hi[k]); d2 += (q[k] - cp) * (q[k] - cp); }
+                near = near | (d2 < reach * reach);
+            }
+            return ((lane & 15) == 0) & near;
+        });
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {
+            if (!((need >> (16 * e)) & 1ull)) continue;
+            WaveLds &L = x.lds(e);
+            const float *q = L.q[qi];
+            int nC = x.uniform(L.nC);
+            for (int pass = 1; pass < 3; ++pass) { /* the pass tests every surface of its kind: a surface out of reach yields no contact */
+                const int nsurf = pass == 1 ? c.n_planes : c.n_boxes;
+                if (nsurf == 0) continue;
+                const int f0 = pass == 1 ? 1 : 1 + c.n_planes;
+                int cnt = x.each_compact(
+                    [&](int lane) { const int fi = lane / 13, sph = lane - 13 * fi; return sphere_vs_surface(c, L, q, fi < nsurf ? sph : -1, f0 + fi, -1); },
+                    [&L, nC](int, int rank, const Hit &h) { store_contact(L, nC + rank, h, false); },
+                    [&](int, const Hit &) {});
+                nC += cnt;
+                if (nC > MAXC) nC = MAXC;
+            }
+            x.each([&](int lane) { if (lane == 0) L.nC = nC; });
+        }
+    }
+    if (items_on) { /* lane = (env, item): cubes within reach of any sphere of their env's ant; then one near cube per env and pass */
+        const float R = reach + ITEM_HALF;
+        unsigned long long near = x.each_ballot([&](int lane) {
+            const WaveLds &L = x.lds(lane >> 4);
+            const float *q = L.q[qi];
+            const int it = lane & 15;
+            return (it < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * it]) < R) & (fabsf(q[1] - L.items[2 * it + 1]) < R);
+        });
+        while (near) {
+            const unsigned long long cur = near;
+            x.each_compact16(
+                [&](int lane) {
+                    WaveLds &L = x.lds(lane >> 4);
+                    const unsigned sub = (unsigned)(cur >> (lane & 48)) & 0xffffu;
+                    const int s = lane & 15, item = sub ? __builtin_ctz(sub) : -1;
+                    return sphere_vs_surface(c, L, L.q[qi], (item >= 0 && s < 13) ? s : -1, 0, item);
+                },
+                [&](int lane, int rank, const Hit &h) { WaveLds &L = x.lds(lane >> 4); store_contact(L, L.nC + rank, h, false); },
+                [&](int lane, const Hit &, int count) { if ((lane & 15) == 0) x.lds(lane >> 4).ncnt = count; });
+            x.each([&](int lane) {
+                if ((lane & 15) == 0) { WaveLds &L = x.lds(lane >> 4); const int n = L.nC + L.ncnt; L.nC = n > MAXC ? MAXC : n; }
+            });
+            unsigned long long low = 0; /* every env's lowest set bit is done */
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const unsigned sub = (unsigned)(near >> (16 * e)) & 0xffffu; low |= (unsigned long long)(sub & (0u - sub)) << (16 * e); }
+            near &= ~low;
+        }
+    }
+    if (c.self_collision) { /* the envs with a joint outside the range in which no two legs can meet (see ant_contacts), one after the other */
+        const bool thin = (c.r_caps + c.r_caps) + c.cdist < 0.2f;
+        const unsigned long long unsafe = x.each_ballot([&](int lane) { /* lane = (env, joint) */
+            const float *q = x.lds(lane >> 4).q[qi];
+            const int j = lane & 15;
+            return (j < NJ) & !(thin & (fabsf(q[7 + (j & 7)]) <= ((j & 1) ? 2.0f : 0.75f)));
+        });
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {
+            if (!((unsafe >> (16 * e)) & 0xffffull)) continue;
+            WaveLds &L = x.lds(e);
+            const int nC = x.uniform(L.nC);
+            int cnt = x.each_compact([&](int lane) { return capsule_pair(c, L, lane < 48 ? lane : -1); },
+                                     [&L, nC](int, int rank, const Hit &h) { store_contact(L, nC + rank, h, false); }, [&](int, const Hit &) {});
+            const int nS = nC + cnt > MAXC ? MAXC - nC : cnt;
+            x.each([&](int lane) { if (lane == 0) { L.nC = nC + nS; L.nS = nS; } });
+        }
+    }
+    x.stamp(5);
+#ifdef HRL_WGTIME
+    x.each([&](int lane) { if ((lane & 15) == 0) { WaveLds &L = x.lds(lane >> 4); L.dbg_rows += 3 * L.nC | ((L.nS > 0 ? 1 : 0) << 24); } });
+#endif
+}
+
+/* Limit rows of all four envs of a group by one wave: lane = (env, joint). */
+template <class X>
+HRL_DEV void ant_limits_group(X &x, const DevCfg &c, int qi) {
+    x.refresh();
+    x.each_compact16(
+        [&](int lane) {
+            const WaveLds &L = x.lds(lane >> 4);
+            const float *q = L.q[qi];
+            const int j = lane & 15;
+            LimitHit r; r.ok = false; r.sgn = 0.f; r.dist = 0.f;
+            if (j < NJ) {
+                float dlo = q[7 + j] - L.jlim[0][j], dhi = L.jlim[1][j] - q[7 + j];
+                if (dlo < c.lmargin) { r.ok = true; r.sgn = 1.f; r.dist = dlo; }
+                else if (dhi < c.lmargin) { r.ok = true; r.sgn = -1.f; r.dist = dhi; }
+            }
+            return r;
+        },
+        [&](int lane, int rank, const LimitHit &r) { WaveLds &L = x.lds(lane >> 4); L.ljoint[rank] = lane & 15; L.lsign[rank] = r.sgn; L.ldist[rank] = r.dist; },
+        [&](int lane, const LimitHit &, int count) {
+            if ((lane & 15) == 0) {
+                WaveLds &L = x.lds(lane >> 4);
+                L.nL = count;
+#ifdef HRL_WGTIME
+                L.dbg_rows += count;
+#endif
+            }
+        });
+    x.stamp(6);
+}
+
 /* ENV block of a substep, on the env's own wave: on entry L.q[qi] / L.u / L.ustar, the articulated-body quantities of the group
  * block and the lists of ant_contacts are in the env's record; rows, sweeps, velocity reconstruction and clamp, then the
  * positions are integrated into L.q[qi ^ 1]. */
@@ -1182,12 +1330,9 @@ HRL_DEV void ant_env_block(X &x, const DevCfg &c, int qi) {
     x.stamp(20);
 }
 
-/* Who finds the contacts and limit rows of which env while the leader (wave 0) runs the group block.  Four envs' worth of work
- * (contacts 3.1 k cycles, limit rows 0.65 k each) for three waves, none of which should be busy for longer than the leader (7.5 k):
- *   wave 1: contacts + limits of env 1, limits of env 3            (4.4 k)
- *   wave 2: contacts + limits of env 2, limits of env 0            (4.4 k)
- *   wave 3: contacts of env 0 (the leader's), contacts of env 3    (6.3 k)
- * (tools/stamp_profile.py).  A group of one does everything itself, in order. */
+/* Who finds the contacts and limit rows while the leader (wave 0) runs the group block (7.5 k cycles): wave 1 the contacts of all four
+ * envs, lane-packed (ant_contacts_group), wave 2 their limit rows (ant_limits_group); wave 3 waits at the barrier.  Records of a ragged
+ * last group that hold no env are computed along (their results are never used).  A group of one does everything itself, in order. */
 template <class X>
 HRL_DEV void ant_contact_duty(X &x, const DevCfg &c, int qi, bool items_on) {
     const int w = x.wave_index();
@@ -1195,11 +1340,8 @@ HRL_DEV void ant_contact_duty(X &x, const DevCfg &c, int qi, bool items_on) {
         if (x.uniform(x.lds().on)) { ant_contacts(x, c, x.lds(), qi, items_on); ant_limits(x, c, x.lds(), qi); }
         return;
     }
-    if (w == 0) return;
-    if (w == 3 && x.uniform(x.lds(0).on)) ant_contacts(x, c, x.lds(0), qi, items_on);
-    if (x.uniform(x.lds(w).on)) { ant_contacts(x, c, x.lds(w), qi, items_on); if (w != 3) ant_limits(x, c, x.lds(w), qi); }
-    if (w == 1 && x.uniform(x.lds(3).on)) ant_limits(x, c, x.lds(3), qi);
-    if (w == 2 && x.uniform(x.lds(0).on)) ant_limits(x, c, x.lds(0), qi);
+    if (w == 1) ant_contacts_group(x, c, qi, items_on);
+    if (w == 2) ant_limits_group(x, c, qi);
 }
 
 /* ================================================================================================= POINT SUBSTEP

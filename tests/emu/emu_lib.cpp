@@ -63,6 +63,15 @@ struct CpuExec {
         else { for (int lane = 63; lane >= 0; --lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane]); } }
         return n;
     }
+    template <class P, class W, class Q> void each_compact16(P pred, W write, Q post) {
+        decltype(pred(0)) r[64];
+        if (!reverse) for (int lane = 0; lane < 64; ++lane) r[lane] = pred(lane);
+        else for (int lane = 63; lane >= 0; --lane) r[lane] = pred(lane);
+        int rank[64], cnt[4] = {0, 0, 0, 0};
+        for (int lane = 0; lane < 64; ++lane) { rank[lane] = cnt[lane >> 4]; if (r[lane].ok) ++cnt[lane >> 4]; }
+        if (!reverse) { for (int lane = 0; lane < 64; ++lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane], cnt[lane >> 4]); } }
+        else { for (int lane = 63; lane >= 0; --lane) { if (r[lane].ok) write(lane, rank[lane], r[lane]); post(lane, r[lane], cnt[lane >> 4]); } }
+    }
     template <class P> unsigned long long each_ballot(P pred) {
         unsigned long long m = 0;
         if (!reverse) { for (int lane = 0; lane < 64; ++lane) if (pred(lane)) m |= 1ull << lane; }
