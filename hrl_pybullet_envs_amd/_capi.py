@@ -21,7 +21,7 @@ class hrl_model(C.Structure):
                 ('contact_erp', C.c_float), ('limit_erp', C.c_float), ('friction_ground', C.c_float),
                 ('friction_robot', C.c_float), ('contact_dist', C.c_float), ('limit_margin', C.c_float),
                 ('max_joint_vel', C.c_float), ('limit_max_impulse', C.c_float), ('ground_z', C.c_float),
-                ('point_force', C.c_float), ('self_collision', C.c_int32), ('item_collision', C.c_int32)]
+                ('point_force', C.c_float), ('self_collision', C.c_int32), ('item_collision', C.c_int32), ('step_group', C.c_int32)]
 
 
 class hrl_config(C.Structure):

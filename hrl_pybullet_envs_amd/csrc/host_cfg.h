@@ -126,6 +126,7 @@ inline std::string validate(const hrl_config *c) {
     const hrl_model &m = c->model;
     if (!(m.timestep > 0) || m.frame_skip < 1 || m.frame_skip > 64 || m.solver_iters < 1 || m.solver_iters > 64) return "bad timestep / frame_skip / solver_iters";
     if (!(m.density > 0)) return "density must be positive";
+    if (m.step_group != 0 && m.step_group != 1) return "model.step_group must be 0 (four env-waves per workgroup) or 1 (one wave per env)";
     return "";
 }
 

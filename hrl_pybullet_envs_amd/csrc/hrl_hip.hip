@@ -296,7 +296,7 @@ int hrl_create(const hrl_config *cfg, hrl_handle **out) {
     build_devcfg(*cfg, h->dc);
     h->d_dc = nullptr;
     h->group = cfg->env_kind == HRL_POINT_GATHER ? 1 : 4;
-    if (const char *g = getenv("HRL_STEP_GROUP")) { if (g[0] == '1') h->group = 1; } /* measurement aid: the one-wave-per-env launch */
+    if (cfg->model.step_group == 1) h->group = 1; /* measurement reference: the one-wave-per-env launch (hrl_model.step_group) */
     hipError_t e2 = hipGetDevice(&h->device);
     if (e2 == hipSuccess) e2 = hipMalloc((void **)&h->d_dc, sizeof(DevCfg));
     if (e2 == hipSuccess) e2 = hipMemcpy(h->d_dc, &h->dc, sizeof(DevCfg), hipMemcpyHostToDevice);

@@ -86,6 +86,10 @@ typedef struct hrl_model {
     /* 1: the food / poison cubes are static colliders (assets/food.xml:12,19: 0.25 m boxes, centre z = 0.1,
      * gather_scene.py:62).  Default 1 for the gather kinds. */
     int32_t item_collision;
+    /* Launch shape of hrl_step for the ant kinds -- no effect on results.  0 (default): four env-waves per 256-thread workgroup, the
+     * articulated-body phases and the contact phase of the four envs lane-packed on one wave each.  1: one 64-thread workgroup per env,
+     * every phase on the env's own wave (the measurement reference of DESIGN.md 4; same arithmetic, bit for bit). */
+    int32_t step_group;
 } hrl_model;
 
 typedef struct hrl_config {

@@ -93,6 +93,29 @@ def test_free_running_stays_bit_exact():
     assert np.array_equal(g.state.cpu().numpy(), o.state) and np.array_equal(g.items.cpu().numpy(), o.items)
 
 
+@pytest.mark.parametrize('kind,n,steps', [(K.HRL_ANT_GATHER, 512, 2000), (K.HRL_ANT_MAZE, 256, 1200), (K.HRL_POINT_GATHER, 512, 2000)])
+def test_long_free_run_stays_bit_exact(kind, n, steps):
+    """A whole episode's worth of steps (the 2000-step time limit of the registration for the gather kinds) with no state copying: device and
+    oracle each run on their own from the same seed -- pickups, respawns, deaths, time-limit resets on the way -- and end bit-identical
+    (over a million env-steps for the gather kinds)."""
+    g, o = make(kind, n, seed=23)
+    g.reset(); o.reset()
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    acts = torch.rand(64, n, o.ad, device='cuda', generator=gen) * 2 - 1
+    acts_np = acts.cpu().numpy()
+    for t in range(steps):
+        g.step(acts[t % 64]); o.step(acts_np[t % 64])
+        if t % 500 == 499:
+            torch.cuda.synchronize()
+            assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True), t
+    torch.cuda.synchronize()
+    assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(g.items.cpu().numpy(), o.items)
+    assert np.array_equal(g.aux.cpu().numpy(), o.aux) and obs_bad_rows(g.obs.cpu().numpy(), o.obs).sum() == 0
+    assert np.array_equal(g.info.cpu().numpy(), o.info)
+    if kind != K.HRL_ANT_MAZE:
+        assert o.aux[:, 2].min() >= 2   # every env ran into the time limit at least once
+
+
 def test_pickups_and_respawn_match():
     n = 256
     g, o = make(K.HRL_ANT_GATHER, n, seed=11)
@@ -303,13 +326,11 @@ def test_env_counts_that_do_not_fill_the_last_group(n):
 
 
 @pytest.mark.parametrize('kind', [K.HRL_ANT_GATHER, K.HRL_ANT_MAZE])
-def test_one_wave_per_env_launch_matches_too(kind, monkeypatch):
-    """HRL_STEP_GROUP=1 (the measurement aid: one 64-thread workgroup per env, the same phases in order on the env's own wave)
-    is the same arithmetic: bit-exact against the oracle like the grouped launch."""
-    monkeypatch.setenv('HRL_STEP_GROUP', '1')
+def test_one_wave_per_env_launch_matches_too(kind):
+    """hrl_model.step_group = 1 (the measurement reference: one 64-thread workgroup per env, the same phases in order on the env's own
+    wave) is the same arithmetic: bit-exact against the oracle like the grouped launch."""
     n = 96
-    g, o = make(kind, n, seed=13, max_episode_steps=23)
-    monkeypatch.delenv('HRL_STEP_GROUP')
+    g, o = make(kind, n, seed=13, max_episode_steps=23, model_step_group=1)
     g.reset(); o.reset()
     rng = np.random.RandomState(4)
     for t in range(40):
