@@ -286,3 +286,16 @@ def test_bench_withholds_counters_of_other_code(monkeypatch):
     assert r['pmc_stale'] is True and r['traffic'] is None and 'valu' not in r
     monkeypatch.setattr(bench, 'pmc_summary', lambda kind: {})
     assert bench.roofline('gather', 4096, 50e-6)['pmc_stale'] is False   # no summary committed for this kernel: nothing to be stale
+
+
+def test_committed_counter_summary_describes_the_committed_kernels():
+    """profiles/pmc_summary.json (what bench.py reports as roofline.traffic / roofline.valu) was collected from exactly the kernel sources in the
+    tree: every kind's entry carries the sha256 of csrc/step_core.h + csrc/hrl_hip.hip (tools/summarize_profile.py), equal to the tree's."""
+    import json
+    import os
+    from hrl_pybullet_envs_amd.build import kernel_source_hash
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    summ = json.load(open(os.path.join(root, 'profiles', 'pmc_summary.json')))
+    assert {'gather', 'flat', 'maze', 'point', 'maze_mj', 'flagrun'} <= set(summ)
+    stale = [k for k, v in summ.items() if v.get('source_sha256') != kernel_source_hash()]
+    assert not stale, f're-profile (tools/profile_round.sh + tools/summarize_profile.py): stale counter summaries for {stale}'
