@@ -867,12 +867,12 @@ HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, float
     (build_An_group<SELF, Gn>(L, g, nB, ninvd, one, j2), ...);
     (build_Af_group<SELF, Gf>(L, g, nB, nF, ninvd, one, j2), ...);
 }
-template <bool SELF, class One>
+template <bool SELF, int MB, class One> /* MB = most bounded rows the caller can have (a multiple of four): columns past it are not built */
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
     J2pair j2{0.f, 0.f};
     if (SELF && lane < MAXR) { j2.h = L.J2[lane][0]; j2.a = L.J2[lane][1]; }
     const float invd = 1.f / row_dot<SELF>(g, L.Bt[lane < nB + nF ? lane : 0], j2); /* 1 / A_ii; idle lanes carry row 0's registers */
-    build_A_blocks<SELF>(L, g, nB, nF, -invd, one, j2, std::make_integer_sequence<int, MAXB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
+    build_A_blocks<SELF>(L, g, nB, nF, -invd, one, j2, std::make_integer_sequence<int, MB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
     g.c = -(invd * (row_dot<SELF>(g, L.ustar, j2) + g.bias));
 }
 
@@ -963,13 +963,23 @@ HRL_DEV void pgs_sweep(X &x, int nB, int nF, std::integer_sequence<int, Rs...>, 
                    });
     (void)(pgs_row_friction<Ks>(x, nB, nF) && ...);
 }
-template <class X>
+template <int MB = MAXB, class X>
 HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool self) {
+    static_assert(MB % 4 == 0 && MB <= MAXB, "bounded rows are built in groups of four");
     WaveLds &L = x.lds();
     const int nB = ant ? nL + nC : nC, nF = 2 * nC, nR = nB + nF;
     if (nR <= 0) return;
-    if (self) x.each([&](int lane) { phase_build_A<true>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
-    else x.each([&](int lane) { phase_build_A<false>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
+    if (self) x.each([&](int lane) { phase_build_A<true, MB>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
+    else x.each([&](int lane) { phase_build_A<false, MB>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
+    if (MB != MAXB) /* the point bot's kernel sits at its register cap: lines spilled around the build are reloaded HERE, not inside the sweeps */
+        x.each([&](int lane) {
+            LaneRegs &g = x.reg(lane);
+            (void)g;
+#pragma unroll
+            for (int k = 0; k < MB; ++k) HRL_PIN_VGPR(g.An[k]);
+#pragma unroll
+            for (int k = 0; k < MAXF; ++k) HRL_PIN_VGPR(g.Af[k]);
+        });
     x.stamp(8);
     const int iters = c.iters;
     for (int it = 0; it < iters; ++it) {
@@ -977,7 +987,7 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
         x.refresh();
         x.refresh_uniform(nb); /* keeps the 44 row-count tests inside the sweep as scalar compares (hoisted out of */
         x.refresh_uniform(nf); /* the loop they become 44 live lane-mask pairs, most of them spilled)             */
-        pgs_sweep(x, nb, nf, std::make_integer_sequence<int, MAXB>{}, std::make_integer_sequence<int, MAXF>{});
+        pgs_sweep(x, nb, nf, std::make_integer_sequence<int, MB>{}, std::make_integer_sequence<int, MAXF>{});
     }
     x.stamp(9);
     x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });
@@ -1412,6 +1422,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
         unsigned long long near = x.each_ballot([&](int lane) {
             return (lane < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * (lane & 15)]) < R) & (fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R);
         });
+        const unsigned long long near0 = near;
         while (near) {
             int it[4];
 #pragma unroll
@@ -1424,6 +1435,44 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
                     const int slot = lane >> 3;
                     const int item = slot == 0 ? it[0] : (slot == 1 ? it[1] : (slot == 2 ? it[2] : (slot == 3 ? it[3] : -1)));
                     return corner(lane, item >= 0, 0, item);
+                },
+                keep(nC), [&](int, const CornerHit &) {});
+            nC += cnt;
+            if (nC > MAXC) nC = MAXC;
+        }
+        /* then the near cubes' own 8 corners against the player's oriented box -- what catches a cube under the middle of a face --,
+           eight cubes per pass: the corner in the box frame, its closest surface point, the normal turned back to the world and
+           towards the player */
+        near = near0;
+        x.refresh();
+        while (near) {
+            const unsigned group = (unsigned)near; /* at most 16 items: slot `lane >> 3` takes the group's slot-th near cube */
+#pragma unroll
+            for (int k = 0; k < 8; ++k) near &= near - 1;
+            int cnt = x.each_compact(
+                [&](int lane) {
+                    const int slot = lane >> 3;
+                    unsigned m = group;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) m = k < slot ? (m & (m - 1)) : m;
+                    const int item = m ? (int)__builtin_ctz(m) : -1;
+                    CornerHit h; h.ok = false; h.dist = 0.f; h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f; h.surf = 0;
+                    if (item >= 0) {
+                        const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
+                        const float pc[3] = {(lane & 1) ? ix + ITEM_HALF : ix - ITEM_HALF, (lane & 2) ? iy + ITEM_HALF : iy - ITEM_HALF,
+                                             (lane & 4) ? ITEM_Z + ITEM_HALF : ITEM_Z - ITEM_HALF};
+                        const float d[3] = {pc[0] - q[0], pc[1] - q[1], pc[2] - q[2]};
+                        const float l[3] = {dot3(d, &L.XYZ[0]), dot3(d, &L.XYZ[3]), dot3(d, &L.XYZ[6])}, blo[3] = {-he, -he, -he}, bhi[3] = {he, he, he};
+                        float nl[3];
+                        h.dist = sphere_vs_box(l, 0.f, blo, bhi, nl); h.surf = SURF_ITEM + item;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float nw = fma_(nl[2], L.XYZ[6 + k], fma_(nl[1], L.XYZ[3 + k], nl[0] * L.XYZ[k]));
+                            h.n[k] = -nw; h.c[k] = fma_(-h.dist, nw, d[k]);
+                        }
+                        h.ok = h.dist < c.cdist;
+                    }
+                    return h;
                 },
                 keep(nC), [&](int, const CornerHit &) {});
             nC += cnt;
@@ -1455,7 +1504,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
         g.bias = which == 0 ? (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h : 0.f;
         g.fn = which == 0 ? -1 : ci; g.lam = 0.f; g.lo = 0.f; g.hi = which == 0 ? 1e30f : 0.f;
     });
-    pgs_solve(x, c, 0, nC, false, false);
+    pgs_solve<MAXC>(x, c, 0, nC, false, false); /* no limit rows: at most MAXC bounded rows */
     x.each([&](int lane) { if (lane < 16) L.u[lane] = x.reg(lane).ud; });
     x.stamp(10);
     x.each([&](int lane) { phase_integrate(c, L, q, qn, lane); });

@@ -1123,7 +1123,8 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
     REAL un[6];
     for (int k = 0; k < 3; ++k) un[k] = u[k];
     un[3] = FMA_(h, force[0] / m, u[3]); un[4] = FMA_(h, force[1] / m, u[4]); un[5] = FMA_(h, force[2] / m - K->g, u[5]);
-    /* contacts: 8 corners vs ground, lateral planes and item cubes, surface-major order, at most MAXC */
+    /* contacts: 8 corners vs ground, lateral planes and item cubes in surface-major order, then every cube's 8 corners vs the
+     * player's oriented box -- the half that catches a cube under the middle of a face --, at most MAXC in all */
     REAL Jr[3 * MAXC][16], Br[3 * MAXC][16], bias[3 * MAXC], hic[3 * MAXC], lam[3 * MAXC], mu_row[3 * MAXC];
     int frn[3 * MAXC], nc = 0, ncand = 0, csurf[MAXC];
     REAL cr[MAXC][3], cn[MAXC][3], cd[MAXC];
@@ -1150,6 +1151,29 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
                 if (nc < MAXC) {
                     for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
                     cd[nc] = dist; csurf[nc] = surface; ++nc;
+                }
+            }
+        }
+    /* then the cubes' own corners against the player's box: corner s of item f in the box frame, closest surface point, normal
+     * turned back to the world and towards the player */
+    for (int f = 0; f < use_items; ++f)
+        for (int s = 0; s < 8; ++s) {
+            const REAL *ixy = items_xy + 2 * f;
+            REAL pc[3] = {(s & 1) ? ixy[0] + ORC_ITEM_HALF : ixy[0] - ORC_ITEM_HALF, (s & 2) ? ixy[1] + ORC_ITEM_HALF : ixy[1] - ORC_ITEM_HALF,
+                          (s & 4) ? ORC_ITEM_Z + ORC_ITEM_HALF : ORC_ITEM_Z - ORC_ITEM_HALF};
+            REAL d[3] = {pc[0] - q[0], pc[1] - q[1], pc[2] - q[2]};
+            REAL l[3] = {FN(v3dot)(d, X), FN(v3dot)(d, Y), FN(v3dot)(d, Z)}, nl[3], c[3], n[3];
+            const REAL blo[3] = {-he, -he, -he}, bhi[3] = {he, he, he};
+            REAL dist = FN(sphere_vs_box)(l, 0, blo, bhi, nl);
+            for (int k = 0; k < 3; ++k) {
+                REAL nw = FMA_(nl[2], Z[k], FMA_(nl[1], Y[k], nl[0] * X[k]));
+                n[k] = -nw; c[k] = FMA_(-dist, nw, d[k]);
+            }
+            if (dist < K->cdist) {
+                ++ncand;
+                if (nc < MAXC) {
+                    for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
+                    cd[nc] = dist; csurf[nc] = ORC_SURF_ITEM + f; ++nc;
                 }
             }
         }
@@ -1730,6 +1754,18 @@ void FN(orc_point_substeps)(const hrl_config *cfg, REAL *q, REAL *u, const REAL 
     FN(orc_env) E;
     FN(orc_env_init)(cfg, &E);
     for (int s = 0; s < n; ++s) FN(orc_point_substep)(&E.K, &E.W, q, u, force, 0, 0, 0);
+}
+/* the same among static item cubes; info3 = rows, contacts with item cubes, contacts of the last substep (tests) */
+void FN(orc_point_substeps_items)(const hrl_config *cfg, REAL *q, REAL *u, const REAL *force, int n, const REAL *items_xy, int n_items, int *info3) {
+    FN(orc_env) E;
+    FN(orc_substep_dbg) dbg;
+    FN(orc_env_init)(cfg, &E);
+    memset(&dbg, 0, sizeof(dbg));
+    for (int s = 0; s < n; ++s) FN(orc_point_substep)(&E.K, &E.W, q, u, force, items_xy, n_items, &dbg);
+    if (info3) {
+        info3[0] = dbg.n_rows; info3[1] = 0; info3[2] = dbg.n_contacts;
+        for (int c = 0; c < dbg.n_contacts; ++c) info3[1] += dbg.surface[c] >= ORC_SURF_ITEM;
+    }
 }
 
 #undef NJ

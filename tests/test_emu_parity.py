@@ -251,6 +251,14 @@ def test_item_cubes_collide_and_contact_pickup(kind):
                 xy = o.items.reshape(n, 16, 2)[np.arange(n), k] + off
                 for env in (o, e, er):
                     env.state[:, 0:2] = xy
+                if kind == K.HRL_POINT_GATHER:
+                    # a player teleported INTO a cube is thrown out within a substep and touches nothing at the step's last collision
+                    # pass: park it at rest, unturned, with a face against the cube (gap -4 .. 12 mm) at any offset along that face
+                    side = rng.randint(0, 4, n); d = np.array([[1, 0], [-1, 0], [0, 1], [0, -1]], np.float32)[side]
+                    lat = rng.uniform(-0.42, 0.42, n).astype(np.float32); gap = rng.uniform(-0.004, 0.012, n).astype(np.float32)
+                    xy = o.items.reshape(n, 16, 2)[np.arange(n), k] - d * (np.float32(0.475) + gap)[:, None] + d[:, ::-1] * lat[:, None]
+                    for env in (o, e, er):
+                        env.state[:, 0:2] = xy; env.state[:, 2] = 0.35; env.state[:, 3:7] = [0, 0, 0, 1]; env.state[:, 7:13] = 0
             a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
             it0 = o.items.copy()
             o.step(a); e.step(a); er.step(a)
@@ -271,6 +279,42 @@ def test_item_cubes_collide_and_contact_pickup(kind):
     a = np.zeros((n, o1.ad), np.float32) + np.float32(0.3)
     o1.step(a); o0.step(a)
     assert np.abs(o1.state[:, :15] - o0.state[:, :15]).max() > 1e-3
+
+
+def test_pointbot_cube_corners_against_the_turned_player_box_bit_exact():
+    """The second half of the player-vs-cube contacts (the cube's corners against the player's oriented box, orc_impl.h
+    orc_point_substep): players turned by any yaw and slightly tipped, parked so that cubes sit under the middle of a face, under
+    the body or beside an edge; both lane orders of the wave phases equal the oracle bit for bit, and such contacts do occur."""
+    import ctypes as C
+    n = 48
+    cfg = orc.default_config(K.HRL_POINT_GATHER, num_envs=n, seed=21, auto_reset=1, robot_coll_dist=0.0)
+    (o, e), er = both(cfg), emu_env.EmuEnv(cfg, reverse=True)
+    o.reset(); e.reset(); er.reset()
+    rng = np.random.RandomState(6)
+    face_only = 0
+    for t in range(40):
+        if t % 2 == 0:
+            k = rng.randint(0, 16, n)
+            ang = rng.uniform(-np.pi, np.pi, n); dist = rng.uniform(0.0, 0.62, n)
+            xy = o.items.reshape(n, 16, 2)[np.arange(n), k] + (np.stack([np.cos(ang), np.sin(ang)], 1) * dist[:, None]).astype(np.float32)
+            yaw = rng.uniform(-np.pi, np.pi, n); tip = rng.uniform(-0.05, 0.05, (n, 2))
+            quat = np.stack([tip[:, 0], tip[:, 1], np.sin(yaw / 2), np.cos(yaw / 2)], 1); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+            for env in (o, e, er):
+                env.state[:, 0:2] = xy; env.state[:, 3:7] = quat.astype(np.float32)
+            # contacts that only the cube's corners can make: the oracle sees contacts with this cube, yet no player corner is near it
+            for i in range(0, n, 4):
+                q = o.state[i, :7].astype(np.float64); info = np.zeros(3, np.int32)
+                c0 = orc.default_config(K.HRL_POINT_GATHER, num_envs=1, seed=0)
+                orc.lib().orc_point_substeps_items_f64(C.byref(c0), orc.ptr(q.copy()), orc.ptr(np.zeros(6)), orc.ptr(np.zeros(3)), 1,
+                                                      orc.ptr(o.items[i].astype(np.float64)), 16, orc.ptr(info))
+                R = np.array([[np.cos(yaw[i]), -np.sin(yaw[i])], [np.sin(yaw[i]), np.cos(yaw[i])]])
+                corners = q[:2] + (R @ (np.array([[1, 1], [1, -1], [-1, 1], [-1, -1]]).T * 0.35)).T
+                far = np.all(np.abs(corners - o.items.reshape(n, 16, 2)[i, k[i]]).max(1) > 0.125 + 0.06)
+                face_only += int(info[1] > 0 and far)
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        o.step(a); e.step(a); er.step(a)
+        same(o, e, t); same(e, er, (t, 'lane order'))
+    assert face_only > 10, face_only
 
 
 def test_self_collision_rows_bit_exact_and_keep_legs_apart():

@@ -436,6 +436,17 @@ def test_contact_pickup_on_item_cubes(kind):
         k = rng.randint(0, 16, n)
         off = rng.uniform(-1.0, 1.0, (n, 2)).astype(np.float32) * (1.4 if kind == K.HRL_ANT_GATHER else 0.45)
         o.state[:, 0:2] = o.items.reshape(n, 16, 2)[np.arange(n), k] + off
+        if kind == K.HRL_POINT_GATHER and t % 2 == 0:
+            # parked at rest with a face against the cube (gap -4 .. 12 mm) anywhere along that face: contacts that last until the
+            # step's final collision pass, most of them made by the CUBE's corners against the player's box
+            side = rng.randint(0, 4, n); d = np.array([[1, 0], [-1, 0], [0, 1], [0, -1]], np.float32)[side]
+            lat = rng.uniform(-0.42, 0.42, n).astype(np.float32); gap = rng.uniform(-0.004, 0.012, n).astype(np.float32)
+            o.state[:, 0:2] = o.items.reshape(n, 16, 2)[np.arange(n), k] - d * (np.float32(0.475) + gap)[:, None] + d[:, ::-1] * lat[:, None]
+            o.state[:, 2] = 0.35; o.state[:, 3:7] = [0, 0, 0, 1]; o.state[:, 7:13] = 0
+        elif kind == K.HRL_POINT_GATHER:  # any yaw, slightly tipped, the cube under the body, under a face or beside an edge
+            yaw = rng.uniform(-np.pi, np.pi, n); tip = rng.uniform(-0.05, 0.05, (n, 2))
+            quat = np.stack([tip[:, 0], tip[:, 1], np.sin(yaw / 2), np.cos(yaw / 2)], 1); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+            o.state[:, 3:7] = quat.astype(np.float32); o.state[:, 2] = 0.35; o.state[:, 7:13] = 0
         push(g, o)
         a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
         go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)

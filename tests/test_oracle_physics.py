@@ -218,3 +218,32 @@ def test_pointbot_zero_action_is_nan_done():
     a = np.array([[0, 0], [1, 0]], np.float32)
     o, r, d, i = env.step(a)
     assert d[0] == 1 and d[1] == 0 and not np.isfinite(o[0]).all() and np.isfinite(o[1]).all()
+
+
+def test_pointbot_is_stopped_by_a_cube_under_the_middle_of_a_face():
+    """The player cube (half extent 0.35) pushed face-on into an item cube (half extent 0.125) that sits opposite the MIDDLE of
+    its +x face: none of the player's 8 corners comes near the cube, it is the cube's own corners against the player's box that
+    stop it.  Same for a player turned 30 degrees about z, and a cube beside the path changes nothing."""
+    import ctypes as C
+    cfg = orc.default_config(K.HRL_POINT_GATHER, num_envs=1, seed=0)
+    f = np.array([40.0, 0.0, 0.0])  # 4 m/s^2: would carry it 0.5 m in half a second
+
+    def run(yaw, items, n=240):
+        q = np.array([0, 0, 0.35, 0, 0, np.sin(yaw / 2), np.cos(yaw / 2)], np.float64); u = np.zeros(6); info = np.zeros(3, np.int32)
+        it = np.asarray(items, np.float64)
+        orc.lib().orc_point_substeps_items_f64(C.byref(cfg), orc.ptr(q), orc.ptr(u), orc.ptr(f), n, orc.ptr(it), len(it) // 2, orc.ptr(info))
+        return q, u, info
+
+    gap = 0.1
+    q, u, info = run(0.0, [0.35 + gap + 0.125, 0.0])
+    assert abs(q[0] - gap) < 0.01 and abs(u[3]) < 0.02 and abs(q[1]) < 5e-3 and info[2] >= 6 and info[1] >= 2  # 4 ground corners + the cube's near corners
+    assert abs(q[2] - 0.35) < 0.01 and np.abs(q[3:6]).max() < 0.02  # and it neither climbs nor tips
+    qf, uf, _ = run(0.0, [0.35 + gap + 0.125, 3.0])  # the same cube out of the way: the player sails on
+    assert qf[0] > 0.4 and uf[3] > 1.0
+    # turned by 30 degrees the leading edge is a corner line; a cube at 20 degrees off it meets the oblique +x face
+    yaw = np.pi / 6
+    nx, ny = np.cos(yaw), np.sin(yaw)
+    c = np.array([nx, ny]) * (0.35 + gap + 0.125 * (abs(nx) + abs(ny)))  # its nearest corner `gap` in front of the face
+    f[:] = [40.0 * nx, 40.0 * ny, 0.0]
+    q, u, info = run(yaw, c)
+    assert abs(q[0] * nx + q[1] * ny - gap) < 0.015 and abs(u[3] * nx + u[4] * ny) < 0.03 and info[1] >= 1
