@@ -170,6 +170,14 @@ def roofline(kind, n, launch_s):
             v['held_clock_ghz'] = s['wave_cycles_per_env'] / (s['kernel_us_profiled'] * 1e3)  # lower bound: a wave lives at most the launch
             v['frac_at_held_clock'] = per_simd / (launch_s * v['held_clock_ghz'] * 1e9)
         out['valu'] = v
+        # What four waves on one SIMD can issue was MEASURED (tools/micro/simd_share.hip, profiles/r3_simd_share_microbench.txt): VALU-only
+        # streams 830 - 908 instructions per microsecond per SIMD, streams that mix in scalar instructions 370 - 620 VALU per microsecond.
+        per_us = s['valu_insts_per_env'] * n / N_SIMD / (launch_s * 1e6)
+        out['issue'] = {'valu_per_us_per_simd': per_us, 'measured_ceiling_valu_only': [830.0, 908.0], 'frac_of_measured_ceiling': per_us / 908.0,
+                        'measured_ceiling_solver_row_mix': [598.0, 624.0], 'source': 'profiles/r3_simd_share_microbench.txt'}
+        if 'insts_per_env' in s:
+            out['issue']['all_insts_per_us_per_simd'] = s['insts_per_env'] * n / N_SIMD / (launch_s * 1e6)
+            out['issue']['insts_per_env'] = s['insts_per_env']
     return out
 
 

@@ -58,6 +58,10 @@ def main():
                       'write_bytes_per_env': counters['WRITE_SIZE']['mean_per_launch'] * 1024 / n_envs}
         if 'SQ_INSTS_VALU' in counters:  # one wave per env: per-wave counters are per-env counters
             summ[kind]['valu_insts_per_env'] = counters['SQ_INSTS_VALU']['mean_per_wave']
+        other = ['SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR']
+        if 'SQ_INSTS_VALU' in counters and all(k in counters for k in other):  # everything a wave issues (s_nop / s_waitcnt are not counted by these)
+            summ[kind]['insts_per_env'] = counters['SQ_INSTS_VALU']['mean_per_wave'] + sum(counters[k]['mean_per_wave'] for k in other)
+            summ[kind]['salu_insts_per_env'] = counters['SQ_INSTS_SALU']['mean_per_wave']
         if 'SQ_WAVE_CYCLES' in counters:  # quad-cycles -> cycles (MI355X_MICROARCH.md, cycle constants)
             summ[kind]['wave_cycles_per_env'] = counters['SQ_WAVE_CYCLES']['mean_per_wave'] * 4
         if kernel_us is not None:
