@@ -87,19 +87,16 @@ class BatchedGymEnv:
         return obs
 
     def step(self, a):
-        import torch
         env = self._backend()
         if self.num_envs == 1:
-            act = torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(1, -1), device=env.device)
-            obs, rew, done, info = env.step(act)
-            # one device-side gather + ONE host copy per step: obs | reward | done | info row | episode step
-            row = torch.cat([obs[0], rew[:1], done[:1].to(torch.float32), env.info[0], env.aux[0, :1].to(torch.float32)]).cpu().numpy()
-            od = obs.shape[1]
-            d = bool(row[od + 1] != 0)
-            out = {'food_rew': float(row[od + 2]), 'dead_rew': float(row[od + 3])} if self._gather_info else {}
-            if d and int(row[od + 6]) >= self.max_episode_steps > 0:
+            # numpy in / numpy out like the reference: one launch + one synchronisation, the kernel reads the action from and
+            # writes its outputs to pinned host memory (BatchedEnv.step_host)
+            obs, rew, done, info = env.step_host(np.asarray(a, dtype=np.float32).reshape(1, -1))
+            d = bool(done[0] != 0)
+            out = {'food_rew': float(info[0, 0]), 'dead_rew': float(info[0, 1])} if self._gather_info else {}
+            if d and int(info[0, 3]) >= self.max_episode_steps > 0:  # info[3] = length of the episode that just ended
                 out['TimeLimit.truncated'] = True
-            return row[:od].astype(np.float64), float(row[od]), d, out
+            return obs[0].astype(np.float64), float(rew[0]), d, out
         return env.step(a)
 
     def close(self):

@@ -34,6 +34,7 @@ class BatchedEnv:
         self.reward = torch.zeros(n, dtype=f32, device=dev)
         self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.info = torch.zeros(n, K.HRL_INFO_STRIDE, dtype=f32, device=dev)
+        self._host = None  # pinned host buffers of step_host(), made on first use
         self._bufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), None,
                                    self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
                                    self.info.data_ptr())
@@ -74,6 +75,31 @@ class BatchedEnv:
         info = {'food_rew': self.info[:, 0], 'dead_rew': self.info[:, 1], 'episode_return': self.info[:, 2],
                 'episode_length': self.info[:, 3]}
         return self.obs, self.reward, self.done, info
+
+    def step_host(self, actions):
+        """One step with HOST input and outputs -- what the reference's numpy-in / numpy-out `env.step(a)` hands over
+        (README.md:24-34), for the one-env classes: the action is written into pinned host memory that the kernel reads
+        directly, and observations / reward / done / info land in pinned host memory the kernel writes directly, so a step is
+        one launch and one stream synchronisation -- no staging copies, no packing kernel.  The simulation state stays in HBM.
+        Returns numpy views (obs [N, obs_dim], reward [N], done [N] uint8, info [N, 4]) that the next call overwrites; the
+        device tensors `obs` / `reward` / `done` / `info` are NOT updated by this path."""
+        if self._host is None:
+            f32 = torch.float32
+            t = {'act': torch.zeros(self.num_envs, self.act_dim, dtype=f32).pin_memory(),
+                 'obs': torch.zeros(self.num_envs, self.obs_dim, dtype=f32).pin_memory(),
+                 'rew': torch.zeros(self.num_envs, dtype=f32).pin_memory(),
+                 'done': torch.zeros(self.num_envs, dtype=torch.uint8).pin_memory(),
+                 'info': torch.zeros(self.num_envs, K.HRL_INFO_STRIDE, dtype=f32).pin_memory()}
+            self._host = t
+            self._host_np = {k: v.numpy() for k, v in t.items()}
+            self._hbufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), t['act'].data_ptr(),
+                                        t['obs'].data_ptr(), t['rew'].data_ptr(), t['done'].data_ptr(), t['info'].data_ptr())
+        h = self._host_np
+        h['act'][...] = actions
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hrl_step(self._h, C.byref(self._hbufs), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+        return h['obs'], h['rew'], h['done'], h['info']
 
     def set_goals(self, goals, mask=None):
         """AntFlagrun with flag_manual_goals: goals float32 [N, n_goals, 2] on this device (include/hrl_envs.h: hrl_set_goals)."""

@@ -14,7 +14,10 @@
  * Every entry point documents the reference call site it replaces.
  * All `float*`/`uint8_t*`/`int32_t*` buffer arguments of the hip library are DEVICE pointers;
  * `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on
- * that stream.  The library owns nothing but the immutable config copied at hrl_create() (host copy plus one
+ * that stream.  `actions`, `obs`, `reward`, `done` and `info` may instead be pinned, device-mapped HOST
+ * memory (hipHostMalloc): the kernels read / write them in place, which makes a numpy-in / numpy-out
+ * step of a few envs one launch and one stream synchronisation (the one-env classes do this,
+ * vec_env.py: step_host); `state`, `items` and `aux` belong in HBM.  The library owns nothing but the immutable config copied at hrl_create() (host copy plus one
  * ~0.6 KB device copy of the derived constants, freed by hrl_destroy()).
  */
 #ifndef HRL_ENVS_H

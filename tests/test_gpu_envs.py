@@ -322,3 +322,25 @@ def test_attributes_a_trainer_reads_between_steps():
     a.reset()
     assert a.robot.body_xyz.shape == (8, 3) and a.robot.body_real_xyz.shape == (8, 3)
     a.close()
+
+
+def test_step_host_equals_the_device_path():
+    """`BatchedEnv.step_host` (action read from / outputs written to pinned host memory by the kernel itself, one launch + one
+    synchronisation: the path of the one-env classes) gives what `step` gives through device tensors, bit for bit."""
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+    for kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER, K.HRL_ANT_MAZE):
+        n = 64
+        a_env = BatchedEnv(_lib.default_config(kind, num_envs=n, seed=9, auto_reset=1, max_episode_steps=20), 'cuda:0')
+        b_env = BatchedEnv(_lib.default_config(kind, num_envs=n, seed=9, auto_reset=1, max_episode_steps=20), 'cuda:0')
+        a_env.reset(); b_env.reset()
+        rng = np.random.RandomState(kind)
+        for t in range(45):
+            a = rng.uniform(-1, 1, (n, a_env.act_dim)).astype(np.float32)
+            o1, r1, d1, _ = a_env.step(torch.from_numpy(a).cuda())
+            o2, r2, d2, i2 = b_env.step_host(a)
+            assert isinstance(o2, np.ndarray) and o2.shape == (n, a_env.obs_dim)
+            assert np.array_equal(o1.cpu().numpy(), o2, equal_nan=True) and np.array_equal(r1.cpu().numpy(), r2), (kind, t)
+            assert np.array_equal(d1.cpu().numpy(), d2) and np.array_equal(a_env.info.cpu().numpy(), i2), (kind, t)
+        assert torch.equal(a_env.state, b_env.state) and torch.equal(a_env.aux, b_env.aux)
+        a_env.close(); b_env.close()
