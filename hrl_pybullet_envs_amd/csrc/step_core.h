@@ -944,10 +944,12 @@ HRL_DEV bool pgs_row_bounded(X &x, int nB) { /* limit or normal row R (compile-t
     return true;
 }
 template <int K, class X>
-HRL_DEV bool pgs_row_friction(X &x, int nB, int nF) { /* friction row nB + K */
+HRL_DEV bool pgs_row_friction(X &x, int nB, int nF) { /* friction rows nB + K, nB + K + 1 of one contact (K even): nF = 2 nC, so one test serves the pair */
     if (K >= nF) return false;
     x.each_row(nB + K, [&](int lane) { return pgs_candidate(x.reg(lane)); },
                [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.Af[K], dl, g.c); });
+    x.each_row(nB + K + 1, [&](int lane) { return pgs_candidate(x.reg(lane)); },
+               [&](int lane, float dl) { LaneRegs &g = x.reg(lane); g.c = fma_(g.Af[K + 1], dl, g.c); });
     return true;
 }
 template <class X, int... Rs, int... Ks>
@@ -961,7 +963,7 @@ HRL_DEV void pgs_sweep(X &x, int nB, int nF, std::integer_sequence<int, Rs...>, 
                        LaneRegs &g = x.reg(lane);
                        if (g.fn >= 0) { g.hi = g.mu * ln; g.lo = -g.hi; }
                    });
-    (void)(pgs_row_friction<Ks>(x, nB, nF) && ...);
+    (void)(pgs_row_friction<2 * Ks>(x, nB, nF) && ...);
 }
 template <int MB = MAXB, class X>
 HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool self) {
@@ -987,7 +989,7 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
         x.refresh();
         x.refresh_uniform(nb); /* keeps the 44 row-count tests inside the sweep as scalar compares (hoisted out of */
         x.refresh_uniform(nf); /* the loop they become 44 live lane-mask pairs, most of them spilled)             */
-        pgs_sweep(x, nb, nf, std::make_integer_sequence<int, MB>{}, std::make_integer_sequence<int, MAXF>{});
+        pgs_sweep(x, nb, nf, std::make_integer_sequence<int, MB>{}, std::make_integer_sequence<int, MAXF / 2>{});
     }
     x.stamp(9);
     x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });
