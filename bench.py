@@ -292,7 +292,7 @@ def main():
             out['roofline']['streams_ms_per_step'] = {k: ms / args.steps for (k, _, _, _), ms in zip(envs, dev_ms)}
         if gathered_ok is not None:
             out['config']['returns_gathered_ok'] = gathered_ok
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg belongs to the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args.kind)
         print(json.dumps(out), flush=True)
 
