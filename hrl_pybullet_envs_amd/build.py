@@ -10,17 +10,18 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libhrl_envs_hip.so')
 SOURCES = ['hrl_hip.hip', 'step_core.h', 'host_cfg.h']
-HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared']
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O2', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-shared']
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources (csrc/step_core.h + csrc/hrl_hip.hip): ties a committed counter summary
+    """sha256 over the kernel sources (csrc/step_core.h + csrc/hrl_hip.hip) and the compiler flags: ties a committed counter summary
     (profiles/pmc_summary.json, tools/summarize_profile.py) to the code it was collected from (bench.py: roofline.pmc_stale)."""
     import hashlib
     h = hashlib.sha256()
     for name in ('step_core.h', 'hrl_hip.hip'):
         with open(os.path.join(CSRC, name), 'rb') as f:
             h.update(f.read())
+    h.update(' '.join(HIPCC_FLAGS).encode())
     return h.hexdigest()
 
 
@@ -28,7 +29,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(PKG, '..', 'include', 'hrl_envs.h')]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(PKG, '..', 'include', 'hrl_envs.h'), os.path.abspath(__file__)]  # this file holds the flags
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -24,7 +24,7 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     lib = os.path.join(ROOT, 'gpurun_out', 'libhrl_envs_stamps.so')
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-DHRL_STAMPS',
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O2', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-DHRL_STAMPS',
                            '-fPIC', '-shared', '-o', lib, os.path.join(ROOT, 'hrl_pybullet_envs_amd', 'csrc', 'hrl_hip.hip')])
     _lib.LIB_PATH = lib
     _lib._lib = None
