@@ -93,7 +93,8 @@ def test_free_running_stays_bit_exact():
     assert np.array_equal(g.state.cpu().numpy(), o.state) and np.array_equal(g.items.cpu().numpy(), o.items)
 
 
-@pytest.mark.parametrize('kind,n,steps', [(K.HRL_ANT_GATHER, 512, 2000), (K.HRL_ANT_MAZE, 256, 1200), (K.HRL_POINT_GATHER, 512, 2000)])
+@pytest.mark.parametrize('kind,n,steps', [(K.HRL_ANT_GATHER, 512, 2000), (K.HRL_ANT_MAZE, 256, 1200), (K.HRL_POINT_GATHER, 512, 2000),
+                                          (K.HRL_ANT_FLAGRUN, 256, 1200), (K.HRL_ANT_MAZE_MJ, 256, 1200), (K.HRL_ANT_FLAT, 256, 1200)])
 def test_long_free_run_stays_bit_exact(kind, n, steps):
     """A whole episode's worth of steps (the 2000-step time limit of the registration for the gather kinds) with no state copying: device and
     oracle each run on their own from the same seed -- pickups, respawns, deaths, time-limit resets on the way -- and end bit-identical
@@ -112,7 +113,7 @@ def test_long_free_run_stays_bit_exact(kind, n, steps):
     assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(g.items.cpu().numpy(), o.items)
     assert np.array_equal(g.aux.cpu().numpy(), o.aux) and obs_bad_rows(g.obs.cpu().numpy(), o.obs).sum() == 0
     assert np.array_equal(g.info.cpu().numpy(), o.info)
-    if kind != K.HRL_ANT_MAZE:
+    if kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER):
         assert o.aux[:, 2].min() >= 2   # every env ran into the time limit at least once
 
 
