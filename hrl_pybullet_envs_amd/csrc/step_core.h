@@ -840,23 +840,61 @@ HRL_DEV float row_dot(const LaneRegs &g, const float *Brow, const J2pair &j2) {
     }
     return a;
 }
+/* four rows' dot products at once, term by term: the same chains as four row_dot calls, written interleaved so that the four
+ * independent fma chains issue back to back (column after column they ran as four dependent chains of 8 - 10 instructions) */
+template <bool SELF>
+HRL_DEV void row_dot4(const LaneRegs &g, const float *B0, const float *B1, const float *B2, const float *B3, const J2pair &j2, float *a) {
+    const float *Br[4] = {B0, B1, B2, B3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = g.Jb[0] * Br[i][0];
+#pragma unroll
+    for (int d = 1; d < 6; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = fma_(g.Jb[d], Br[i][d], a[i]);
+    const int s1 = g.jslot & 0xff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = fma_(g.Jh, Br[i][s1], a[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = fma_(g.Ja, Br[i][s1 + 1], a[i]);
+    if (SELF) {
+        const int s2 = g.jslot >> 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = fma_(j2.h, Br[i][s2], a[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = fma_(j2.a, Br[i][s2 + 1], a[i]);
+    }
+}
 /* columns 4G..4G+3 of a block behind one wave-uniform test (flat sequence of groups, no nesting).  Columns past the
  * block's end inside its last group are computed from whatever LDS holds and never read by the sweeps. */
-template <bool SELF, int G, class One>
+template <bool SELF, int G, bool WIDE, class One>
 HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, One one, const J2pair &j2) {
     if (4 * G < nB) {
+        if constexpr (WIDE) {
+            float a[4];
+            row_dot4<SELF>(g, L.Bt[4 * G], L.Bt[4 * G + 1], L.Bt[4 * G + 2], L.Bt[4 * G + 3], j2, a);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[4 * G + i], j2), one(4 * G + i));
+            for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, a[i], one(4 * G + i));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[4 * G + i], j2), one(4 * G + i));
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.An[4 * G + i] = 0.f;
     }
 }
-template <bool SELF, int G, class One>
+template <bool SELF, int G, bool WIDE, class One>
 HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, const J2pair &j2) {
     if (4 * G < nF) {
+        if constexpr (WIDE) {
+            float a[4];
+            row_dot4<SELF>(g, L.Bt[nB + 4 * G], L.Bt[nB + 4 * G + 1], L.Bt[nB + 4 * G + 2], L.Bt[nB + 4 * G + 3], j2, a);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[nB + 4 * G + i], j2), one(nB + 4 * G + i));
+            for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, a[i], one(nB + 4 * G + i));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[nB + 4 * G + i], j2), one(nB + 4 * G + i));
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = 0.f;
@@ -864,8 +902,9 @@ HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float
 }
 template <bool SELF, class One, int... Gn, int... Gf>
 HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, const J2pair &j2, std::integer_sequence<int, Gn...>, std::integer_sequence<int, Gf...>) {
-    (build_An_group<SELF, Gn>(L, g, nB, ninvd, one, j2), ...);
-    (build_Af_group<SELF, Gf>(L, g, nB, nF, ninvd, one, j2), ...);
+    constexpr bool WIDE = sizeof...(Gn) * 4 == MAXB; /* the ant kernels have the registers for four chains side by side; the point bot's (128, at its cap) has not */
+    (build_An_group<SELF, Gn, WIDE>(L, g, nB, ninvd, one, j2), ...);
+    (build_Af_group<SELF, Gf, WIDE>(L, g, nB, nF, ninvd, one, j2), ...);
 }
 template <bool SELF, int MB, class One> /* MB = most bounded rows the caller can have (a multiple of four): columns past it are not built */
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
