@@ -1032,9 +1032,26 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
     }
     x.stamp(9);
     x.each([&](int lane) { if (lane < nR) L.lamf[lane] = x.reg(lane).lam; });
-    x.each([&](int lane) { /* dof map: u = u* + sum_r B_r * lambda_r */
+    x.each([&](int lane) { /* dof map: u = u* + sum_r B_r * lambda_r, rows in order; blocks of 8, then 4, 2, 1 so that the loads of a block
+                              are in flight together (a one-row remainder loop paid the LDS latency up to seven times) */
         float v = L.ustar[lane & 15];
-        for (int r = 0; r < nR; ++r) v = fma_(L.Bt[r][lane & 15], L.lamf[r], v);
+        const int k = lane & 15;
+        int r = 0;
+        for (; r + 8 <= nR; r += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v = fma_(L.Bt[r + i][k], L.lamf[r + i], v);
+        }
+        if (nR & 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v = fma_(L.Bt[r + i][k], L.lamf[r + i], v);
+            r += 4;
+        }
+        if (nR & 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) v = fma_(L.Bt[r + i][k], L.lamf[r + i], v);
+            r += 2;
+        }
+        if (nR & 1) v = fma_(L.Bt[r][k], L.lamf[r], v);
         x.reg(lane).ud = v;
     });
 }
@@ -1822,8 +1839,13 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
         const int b = lane - nb, type = b / c.n_bins, bin = b - type * c.n_bins;
         const int k0 = type ? c.n_food : 0, k1 = type ? c.n_food + c.n_poison : c.n_food;
         float best = 0.f;
-        for (int k = k0; k < k1; ++k)
-            if (L.ibin[k] == (float)bin && L.iint[k] > best) best = L.iint[k];
+        /* all 16 slots, the type's range as a predicate: the 32 loads are in flight together (a loop over [k0, k1) paid the LDS latency
+           twice per item); same order, same comparisons */
+#pragma unroll
+        for (int k = 0; k < HRL_MAX_ITEMS; ++k) {
+            const bool take = (k >= k0) & (k < k1) & (L.ibin[k] == (float)bin) & (L.iint[k] > best);
+            best = take ? L.iint[k] : best;
+        }
         v = best;
     }
     if ((KIND == 1 || KIND == 3) && lane >= nb && !c.use_sensor) { /* ant_gather_env.py:179-196: xy of the nearest items, stable ascending by d2 */
