@@ -46,7 +46,7 @@ extern "C" {
 #define HRL_EPRET_OFF 29
 #define HRL_INITZ_OFF 30
 #define HRL_POTENTIAL_OFF 31
-#define HRL_ITEMS_STRIDE 32 /* 16 items x (x,y): food slots first, then poison slots */
+#define HRL_ITEMS_STRIDE 32 /* 16 items x (x,y): food slots first, then poison slots (n_food + n_poison <= HRL_MAX_ITEMS; the reference's defaults: 8 + 8) */
 #define HRL_MAX_ITEMS 16
 #define HRL_MAX_BINS 16
 #define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
