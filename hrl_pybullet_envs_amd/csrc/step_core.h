@@ -173,11 +173,12 @@ struct F2b { float ln, dl; }; /* a row's candidate impulse and its change; the c
 /* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
  * rounding of every operation is part of the algorithm's definition: DESIGN.md 3.7. */
 HRL_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-/* 1 / x for a finite, normal x whose reciprocal is normal too: the IEEE quotient.  Used ONLY where x is a function of the POSE (the pivots of
- * the base inertia, the joint-space inertias 1/D, the diagonal of A = J M^-1 J^T: positive, of moderate size whatever the velocities do -- an
- * env that blows up reaches the velocity-dependent divisions with infinities, where this form gives NaN and the division 0: those stay divisions).  On the device it is the compiler's own division sequence -- v_rcp_f32, one Newton step, quotient and two
- * residual corrections in fma -- without the operand scaling and the special-case fixup around it, which are the identity for such x
- * (three instructions and three links of the dependent chain less); on the host it is the division. */
+/* 1 / x for a finite, normal x whose reciprocal is normal too: the IEEE quotient.  Used ONLY where x is a function of the POSE (the pivots
+ * of the base inertia, the joint-space inertias 1/D, the diagonal of A = J M^-1 J^T: positive and of moderate size whatever the velocities
+ * do).  An env that blows up reaches the velocity-dependent divisions with infinities, where this form gives NaN and the division 0: those
+ * stay divisions.  On the device it is the compiler's own division sequence -- v_rcp_f32, one Newton step, quotient and two residual
+ * corrections in fma -- without the operand scaling and the special-case fixup around it, which are the identity for such x (three
+ * instructions and three links of the dependent chain less); on the host it is the division. */
 HRL_DEV float recip_normal(float x) {
 #ifdef HRL_EMU
     return 1.f / x;
@@ -926,7 +927,8 @@ HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int 
     J2pair j2{0.f, 0.f};
     if (SELF && lane < MAXR) { j2.h = L.J2[lane][0]; j2.a = L.J2[lane][1]; }
     const float aii = row_dot<SELF>(g, L.Bt[lane < nB + nF ? lane : 0], j2);
-    const float invd = MB == MAXB ? recip_normal(aii) : 1.f / aii; /* the point bot's kernel keeps the division: it measured 0.6 % slower with the short form */ /* 1 / A_ii; idle lanes carry row 0's registers */
+    /* 1 / A_ii; idle lanes carry row 0's registers.  The point bot's kernel keeps the division: it measured 0.6 % slower with the short form */
+    const float invd = MB == MAXB ? recip_normal(aii) : 1.f / aii;
     build_A_blocks<SELF>(L, g, nB, nF, -invd, one, j2, std::make_integer_sequence<int, MB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
     g.c = -(invd * (row_dot<SELF>(g, L.ustar, j2) + g.bias));
 }
