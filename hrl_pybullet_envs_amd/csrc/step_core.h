@@ -173,22 +173,6 @@ struct F2b { float ln, dl; }; /* a row's candidate impulse and its change; the c
 /* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
  * rounding of every operation is part of the algorithm's definition: DESIGN.md 3.7. */
 HRL_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-/* 1 / x for a finite, normal x whose reciprocal is normal too: the IEEE quotient.  Used ONLY where x is a function of the POSE (the pivots
- * of the base inertia, the joint-space inertias 1/D, the diagonal of A = J M^-1 J^T: positive and of moderate size whatever the velocities
- * do).  An env that blows up reaches the velocity-dependent divisions with infinities, where this form gives NaN and the division 0: those
- * stay divisions.  On the device it is the compiler's own division sequence -- v_rcp_f32, one Newton step, quotient and two residual
- * corrections in fma -- without the operand scaling and the special-case fixup around it, which are the identity for such x (three
- * instructions and three links of the dependent chain less); on the host it is the division. */
-HRL_DEV float recip_normal(float x) {
-#ifdef HRL_EMU
-    return 1.f / x;
-#else
-    float r = __builtin_amdgcn_rcpf(x);
-    r = fma_(fma_(-x, r, 1.f), r, r);
-    float q = fma_(fma_(-x, r, 1.f), r, r);
-    return fma_(fma_(-x, q, 1.f), r, q);
-#endif
-}
 HRL_DEV void cross3(float *o, const float *a, const float *b) {
     float x = fma_(a[1], b[2], -(a[2] * b[1])), y = fma_(a[2], b[0], -(a[0] * b[2])), z = fma_(a[0], b[1], -(a[1] * b[0]));
     o[0] = x; o[1] = y; o[2] = z;
@@ -341,7 +325,7 @@ HRL_DEV void ldl6_factor(float *Lm /* [15] */, float *id /* [6] */, const float 
         for (int k = 0; k < j; ++k) v[k] = Lm[tl(j, k)] * d[k];
 #pragma unroll
         for (int k = 0; k < j; ++k) s = fma_(-Lm[tl(j, k)], v[k], s);
-        d[j] = s; id[j] = recip_normal(s);
+        d[j] = s; id[j] = 1.f / s;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             float t = A[si(i, j)];
@@ -485,7 +469,7 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
     for (int k = 0; k < 6; ++k) L.cb[ja][k] = cba[k];
     float Ua[6], Iac[6];
     sym6_matvec(Ua, If, Sa);
-    const float invDa = recip_normal(dot6(Sa, Ua));
+    const float invDa = 1.f / dot6(Sa, Ua);
     const float uta = L.tau[ja] - dot6(Sa, pAf);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -516,7 +500,7 @@ HRL_DEV void phase_hip(WaveLds &L, const LaneRegs &g, int lane) {
     for (int k = 0; k < 21; ++k) Ix[k] = g.rI[k] + L.Iaf[l][k];
     float Uh[6], Iac[6];
     sym6_matvec(Uh, Ix, Sh);
-    const float invDh = recip_normal(dot6(Sh, Uh));
+    const float invDh = 1.f / dot6(Sh, Uh);
     const float uth = L.tau[jh] - dot6(Sh, pAx);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -926,9 +910,7 @@ template <bool SELF, int MB, class One> /* MB = most bounded rows the caller can
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
     J2pair j2{0.f, 0.f};
     if (SELF && lane < MAXR) { j2.h = L.J2[lane][0]; j2.a = L.J2[lane][1]; }
-    const float aii = row_dot<SELF>(g, L.Bt[lane < nB + nF ? lane : 0], j2);
-    /* 1 / A_ii; idle lanes carry row 0's registers.  The point bot's kernel keeps the division: it measured 0.6 % slower with the short form */
-    const float invd = MB == MAXB ? recip_normal(aii) : 1.f / aii;
+    const float invd = 1.f / row_dot<SELF>(g, L.Bt[lane < nB + nF ? lane : 0], j2); /* 1 / A_ii; idle lanes carry row 0's registers */
     build_A_blocks<SELF>(L, g, nB, nF, -invd, one, j2, std::make_integer_sequence<int, MB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
     g.c = -(invd * (row_dot<SELF>(g, L.ustar, j2) + g.bias));
 }
@@ -966,7 +948,7 @@ HRL_DEV void phase_integrate(const DevCfg &c, WaveLds &L, const float *q, float 
     /* renormalisation: the product of two unit quaternions is off unit length by rounding only, so one Newton step of
      * 1/sqrt at 1, (3 - n2) / 2, is exact to (n2 - 1)^2 ~ 1e-14; the closed-form branch keeps the exact 1/sqrt */
     const float n2 = fma_(nx, nx, ny * ny) + fma_(nz, nz, nw * nw);
-    const float inv = small ? fma_(-0.5f, n2, 1.5f) : 1.f / sqrtf(n2); /* a plain division: an env that blows up gets here with an infinite n2 (recip_normal) */
+    const float inv = small ? fma_(-0.5f, n2, 1.5f) : 1.f / sqrtf(n2);
     const int k = lane & 15;
     /* position k < 3 advances with the linear velocity u[3 + k], joint angle q[7 + j] with the joint rate u[6 + j] */
     const int ui = k < 3 ? k + 3 : (k >= 7 && k < 15 ? k - 1 : 0);
