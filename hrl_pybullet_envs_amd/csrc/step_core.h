@@ -1791,6 +1791,7 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
             dx = ix - rx; dy = iy - ry; d2 = dx * dx + dy * dy;
         }
         if (!c.use_sensor) inten = d2; /* get_abs_pos (ant_gather_env.py:179-196) sorts by squared distance */
+        else if (d2 != d2) bin = -2.f; /* a NaN distance (NaN robot or item coordinate): every reading of the item's type is NaN (phase_pack_obs) */
         else if (!(d2 > c.sensor_range)) {
             const float half_span = c.sensor_span * 0.5f, bin_res = c.sensor_span / (float)c.n_bins;
             const float angle = wrap_angle(atan2_spec(iy - ry, ix - rx) - yaw);
@@ -1841,22 +1842,28 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
         float best = 0.f;
         /* all 16 slots, the type's range as a predicate: the 32 loads are in flight together (a loop over [k0, k1) paid the LDS latency
            twice per item); same order, same comparisons */
+        bool bad = false;
 #pragma unroll
         for (int k = 0; k < HRL_MAX_ITEMS; ++k) {
-            const bool take = (k >= k0) & (k < k1) & (L.ibin[k] == (float)bin) & (L.iint[k] > best);
+            const bool mine = (k >= k0) & (k < k1);
+            const bool take = mine & (L.ibin[k] == (float)bin) & (L.iint[k] > best);
             best = take ? L.iint[k] : best;
+            bad = bad | (mine & (L.ibin[k] == -2.f));
         }
-        v = best;
+        v = bad ? __builtin_nanf("") : best; /* a numerical failure, not a reading: the episode ends (ant_gather_env.py:101-103) */
     }
     if ((KIND == 1 || KIND == 3) && lane >= nb && !c.use_sensor) { /* ant_gather_env.py:179-196: xy of the nearest items, stable ascending by d2 */
         const int mf = c.n_food < c.n_bins ? c.n_food : c.n_bins;
         const int b = lane - nb, type = b >= 2 * mf, bb = type ? b - 2 * mf : b, want = bb >> 1, comp = bb & 1;
         const int k0 = type ? c.n_food : 0, k1 = type ? c.n_food + c.n_poison : c.n_food;
+        bool bad = false;
         for (int i = k0; i < k1; ++i) {
             int rank = 0;
             for (int j = k0; j < k1; ++j) rank += (L.iint[j] < L.iint[i] || (L.iint[j] == L.iint[i] && j < i)) ? 1 : 0;
             if (rank == want) v = L.items[2 * i + comp];
+            bad = bad | (L.iint[i] != L.iint[i]);
         }
+        if (bad && want < (k1 - k0)) v = __builtin_nanf(""); /* a NaN distance has no place in the order: the type's outputs are NaN */
     }
     if (KIND == 2 && lane >= 26) {
         const float rx = L.st[0], ry = L.st[1], yaw = L.scal[4];

@@ -222,17 +222,22 @@ REAL FN(orc_sq_dist)(const REAL *item_xy, const REAL *robot_xy) {
  * implemented here literally (stable sort, reverse=True keeps input order among equal keys). */
 void FN(orc_food_sensor)(int n_bins, REAL span, REAL range, const REAL *robot_xy, REAL yaw, const REAL *items_xy,
                          int n_food, int n_poison, const REAL *d2, REAL *food_out, REAL *poison_out) {
-    int n = n_food + n_poison, order[HRL_MAX_ITEMS];
+    int n = n_food + n_poison, m = 0, order[HRL_MAX_ITEMS];
     for (int i = 0; i < n_bins; ++i) food_out[i] = poison_out[i] = 0;
-    for (int i = 0; i < n; ++i) order[i] = i;
-    for (int i = 1; i < n; ++i) { /* stable insertion sort, descending d2 (:141) */
+    /* An item whose squared distance is NaN (a NaN robot or item coordinate) is a numerical failure, not a reading: the reference raises at
+     * int(nan) (:161).  Here it takes no part in the ordering (a NaN key would stop the insertion sort from ordering the others) and makes
+     * every reading of its type NaN, which ends the episode (:101-103). */
+    for (int i = 0; i < n; ++i) if (d2[i] == d2[i]) order[m++] = i;
+    for (int i = 1; i < m; ++i) { /* stable insertion sort, descending d2 (:141) */
         int k = order[i], j = i - 1;
         while (j >= 0 && d2[order[j]] < d2[k]) { order[j + 1] = order[j]; --j; }
         order[j + 1] = k;
     }
     REAL bin_res = span / R_(n_bins); /* :142 */
     REAL half_span = span * R_(0.5);  /* :158 */
-    for (int s = 0; s < n; ++s) {
+    for (int i = 0; i < n; ++i)
+        if (d2[i] != d2[i]) { REAL *out = i < n_food ? food_out : poison_out; for (int b = 0; b < n_bins; ++b) out[b] = (REAL)NAN; }
+    for (int s = 0; s < m; ++s) {
         int k = order[s];
         if (d2[k] > range) continue;                                                               /* :145 */
         REAL angle = RATAN2(items_xy[2 * k + 1] - robot_xy[1], items_xy[2 * k] - robot_xy[0]) - yaw; /* :148 */
@@ -241,7 +246,8 @@ void FN(orc_food_sensor)(int n_bins, REAL span, REAL range, const REAL *robot_xy
         int bin = (int)((angle + half_span) / bin_res);                                            /* :161 */
         if (bin >= n_bins) bin = n_bins - 1; /* reference would raise IndexError at angle == +half_span (measure zero) */
         REAL intensity = R_(1.0) - d2[k] / range; /* :162 */
-        if (k < n_food) food_out[bin] = intensity; else poison_out[bin] = intensity;
+        REAL *out = k < n_food ? food_out : poison_out;
+        if (out[bin] == out[bin]) out[bin] = intensity; /* a type poisoned by a NaN distance stays NaN */
     }
 }
 
@@ -257,8 +263,9 @@ void FN(orc_abs_pos)(int n_bins, const REAL *items_xy, int n_food, int n_poison,
             while (j >= 0 && d2[order[j]] > d2[k]) { order[j + 1] = order[j]; --j; }
             order[j + 1] = k;
         }
-        int m = n < n_bins ? n : n_bins;
-        for (int i = 0; i < m; ++i) { out[2 * i] = items_xy[2 * order[i]]; out[2 * i + 1] = items_xy[2 * order[i] + 1]; }
+        int m = n < n_bins ? n : n_bins, bad = 0;
+        for (int i = 0; i < n; ++i) bad |= d2[base + i] != d2[base + i]; /* a NaN distance has no place in the order: the type's outputs are NaN */
+        for (int i = 0; i < m; ++i) { out[2 * i] = bad ? (REAL)NAN : items_xy[2 * order[i]]; out[2 * i + 1] = bad ? (REAL)NAN : items_xy[2 * order[i] + 1]; }
     }
 }
 

@@ -538,3 +538,40 @@ def test_specified_transcendentals_accuracy_and_agreement():
     s = rng.uniform(-0.99999, 0.99999, n).astype(np.float32)
     assert np.abs(run(3, s) - np.arcsin(s.astype(np.float64))).max() < 3e-7
     run(2, np.array([np.nan, 1, np.inf, -np.inf, np.inf], np.float32), np.array([1, np.nan, 1, np.inf, np.inf], np.float32))  # same bits, whatever they are
+
+
+@pytest.mark.parametrize('auto_reset', [1, 0])
+@pytest.mark.parametrize('kind', KINDS)
+def test_envs_that_blow_up_match_too(kind, auto_reset):
+    """Non-finite and absurd states -- velocities of 1e20 and inf, a NaN coordinate, a torso 1e19 m away, robots inside a wall, joint angles far
+    out of range -- go through the same arithmetic in the wave phases and in the oracle: NaN, inf, done, the dying cost and the auto-reset that
+    follows come out identical (NaNs compared as equal)."""
+    n = 64
+    cfg = orc.default_config(kind, num_envs=n, seed=31, auto_reset=auto_reset)
+    o, e = both(cfg)
+    o.reset(); e.reset()
+    rng = np.random.RandomState(9)
+    nq = 7 if kind == K.HRL_POINT_GATHER else 15
+    for t in range(15):
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        if t % 3 == 0:
+            rows = rng.permutation(n)[:48]
+            for env in (o, e):
+                r2 = np.random.RandomState(100 + t)
+                env.state[rows[0:8], 15 + r2.randint(0, 6, 8)] = 1e20
+                env.state[rows[8:16], 15 + r2.randint(0, 6, 8)] = np.inf
+                env.state[rows[16:24], 15 + r2.randint(0, 6, 8)] = -3e38
+                env.state[rows[24:28], 0] = 1e19
+                env.state[rows[28:32], 2] = -1e19
+                env.state[rows[32:36], r2.randint(0, nq, 4)] = np.nan
+                env.state[rows[36:40], 0:2] = [-2.0, 0.0] if kind in (K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ) else [7.6, 7.6]
+                if kind != K.HRL_POINT_GATHER:
+                    env.state[rows[40:48], 7 + r2.randint(0, 8, 8)] = r2.choice([40.0, -1e6, 3e30], 8)
+                if kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER):  # item coordinates too
+                    env.items[rows[0:4], r2.randint(0, 32, 4)] = np.nan
+                    env.items[rows[4:8], r2.randint(0, 32, 4)] = np.inf
+                    env.items[rows[24:26], r2.randint(0, 32, 2)] = 1e30
+                env.state[rows[20:24], 15 + r2.randint(0, 6, 4)] = np.nan
+                env.state[rows[26:28], 1] = -np.inf
+        o.step(a); e.step(a)
+        same(o, e, t)

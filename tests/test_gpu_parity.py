@@ -571,3 +571,47 @@ def test_flagrun_open_field_and_no_switch_on_device():
         assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
         paid += (o.rew > 1000).astype(int)
     assert np.all(paid >= 3) and np.all(paid <= 4)   # once per goal (the goal only moves with the timeout); out of goals -> done -> auto-reset -> a new list
+
+
+@pytest.mark.parametrize('auto_reset', [1, 0])
+@pytest.mark.parametrize('kind', KINDS)
+def test_envs_that_blow_up_match_too(kind, auto_reset):
+    """Non-finite and absurd states -- velocities of 1e20 and inf, NaN coordinates of the robot or of an item, a torso 1e19 m away, robots inside
+    a wall, joint angles far out of range -- go through the same arithmetic on both sides: what comes out (NaN, inf, done, the dying cost, the
+    auto-reset that follows) is identical, bit for bit with NaNs compared as equal.  (A NaN item distance used to read 0 on the device and NaN
+    in the oracle; a division replaced by a cheaper sequence that treats infinities differently shows up here too, not in a healthy run.)"""
+    n = 128
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+    g = BatchedEnv(_lib.default_config(kind, num_envs=n, seed=31, auto_reset=auto_reset), 'cuda:0')
+    o = orc.OracleEnv(orc.default_config(kind, num_envs=n, seed=31, auto_reset=auto_reset), np.float32)
+    g.reset(); o.reset()
+    rng = np.random.RandomState(9)
+    nq = 7 if kind == K.HRL_POINT_GATHER else 15
+    for t in range(15):
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        if t % 3 == 0:
+            rows = rng.permutation(n)[:48]
+            o.state[rows[0:8], 15 + rng.randint(0, 6, 8)] = 1e20
+            o.state[rows[8:16], 15 + rng.randint(0, 6, 8)] = np.inf
+            o.state[rows[16:24], 15 + rng.randint(0, 6, 8)] = -3e38
+            o.state[rows[20:24], 15 + rng.randint(0, 6, 4)] = np.nan
+            o.state[rows[24:28], 0] = 1e19
+            o.state[rows[26:28], 1] = -np.inf
+            o.state[rows[28:32], 2] = -1e19
+            o.state[rows[32:36], rng.randint(0, nq, 4)] = np.nan
+            o.state[rows[36:40], 0:2] = [-2.0, 0.0] if kind in (K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ) else [7.6, 7.6]  # inside the maze box / the walls
+            if kind != K.HRL_POINT_GATHER:
+                o.state[rows[40:48], 7 + rng.randint(0, 8, 8)] = rng.choice([40.0, -1e6, 3e30], 8)  # joint angles far out of range
+            if kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER):
+                o.items[rows[0:4], rng.randint(0, 32, 4)] = np.nan
+                o.items[rows[4:8], rng.randint(0, 32, 4)] = np.inf
+                o.items[rows[24:26], rng.randint(0, 32, 2)] = 1e30
+            push(g, o)
+        go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True), t
+        assert np.array_equal(g.aux.cpu().numpy(), o.aux) and np.array_equal(gd.cpu().numpy(), o.done), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew, equal_nan=True) and np.array_equal(g.info.cpu().numpy(), o.info, equal_nan=True), t
+        assert np.array_equal(go.cpu().numpy(), o.obs, equal_nan=True), t
+        assert np.array_equal(g.items.cpu().numpy(), o.items, equal_nan=True), t
+    assert int(o.done.sum()) >= 0
