@@ -998,6 +998,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
             } else {
                 const int k = f - 1 - W->n_planes - W->n_boxes;
                 REAL lo[3], hi[3];
+                if (items_xy[2 * k] != items_xy[2 * k] || items_xy[2 * k + 1] != items_xy[2 * k + 1]) continue; /* a cube at a NaN place is nowhere (a clamp between NaN bounds would put it everywhere) */
                 FN(item_box)(items_xy + 2 * k, lo, hi);
                 dist = FN(sphere_vs_box)(p, rad, lo, hi, n); surface = ORC_SURF_ITEM + k;
             }
@@ -1150,7 +1151,9 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
                 dist = FN(v3dot)(n, p) - W->plane_d[f - 1];
             } else {
                 REAL lo[3], hi[3];
-                FN(item_box)(items_xy + 2 * (f - 1 - W->n_planes), lo, hi);
+                const REAL *ixy0 = items_xy + 2 * (f - 1 - W->n_planes);
+                if (ixy0[0] != ixy0[0] || ixy0[1] != ixy0[1]) continue; /* a cube at a NaN place is nowhere */
+                FN(item_box)(ixy0, lo, hi);
                 dist = FN(sphere_vs_box)(p, 0, lo, hi, n); surface = ORC_SURF_ITEM + (f - 1 - W->n_planes);
             }
             if (dist < K->cdist) {
@@ -1166,6 +1169,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
     for (int f = 0; f < use_items; ++f)
         for (int s = 0; s < 8; ++s) {
             const REAL *ixy = items_xy + 2 * f;
+            if (ixy[0] != ixy[0] || ixy[1] != ixy[1]) continue; /* a cube at a NaN place is nowhere */
             REAL pc[3] = {(s & 1) ? ixy[0] + ORC_ITEM_HALF : ixy[0] - ORC_ITEM_HALF, (s & 2) ? ixy[1] + ORC_ITEM_HALF : ixy[1] - ORC_ITEM_HALF,
                           (s & 4) ? ORC_ITEM_Z + ORC_ITEM_HALF : ORC_ITEM_Z - ORC_ITEM_HALF};
             REAL d[3] = {pc[0] - q[0], pc[1] - q[1], pc[2] - q[2]};

@@ -615,3 +615,16 @@ def test_envs_that_blow_up_match_too(kind, auto_reset):
         assert np.array_equal(go.cpu().numpy(), o.obs, equal_nan=True), t
         assert np.array_equal(g.items.cpu().numpy(), o.items, equal_nan=True), t
     assert int(o.done.sum()) >= 0
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_fuzzed_absurd_values_stay_bit_exact(kind):
+    """tools/fuzz_parity.py on the device: NaN, +-inf, 1e20, 3e38, denormals and signed zeros in positions, velocities, item coordinates and
+    actions of running envs; every output equals the oracle's at every step."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_parity.py'))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    for seed in (0, 1, 2):
+        for ar in (0, 1):
+            assert fz.run(fz.GpuSide, kind, seed, ar) is None
