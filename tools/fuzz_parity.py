@@ -2,7 +2,7 @@
 """Parity under absurd inputs: the wave phases (the HIP kernels on a GPU box, `gpu`; the lock-step host executor of tests/emu, `emu`) against
 the fp32 oracle while NaN, +-inf, 1e20, 3e38, denormals and signed zeros are written into positions, velocities, item coordinates and actions of
 running envs -- the values a simulation that blows up can reach (quaternions are unit or NaN, joint angles moderate, joint rates within their clamp).
-Every output is compared bit for bit (NaNs as equal) at every step.    python tools/fuzz_parity.py [seeds] [gpu|emu]"""
+Every output is compared bit for bit (NaNs as equal) at every step.    python tools/fuzz_parity.py [seeds] [gpu|emu] [matrix]"""
 import os
 import sys
 
@@ -18,11 +18,11 @@ VALS = [np.nan, np.inf, -np.inf, 1e20, -1e20, 3e38, -3e38, 1e-40, -1e-40, -0.0, 
 
 
 class GpuSide:
-    def __init__(self, kind, n, seed, auto_reset):
+    def __init__(self, kind, n, seed, auto_reset, kw):
         import torch
         from hrl_pybullet_envs_amd import _lib
         from hrl_pybullet_envs_amd.vec_env import BatchedEnv
-        self.t, self.g = torch, BatchedEnv(_lib.default_config(kind, num_envs=n, seed=seed, auto_reset=auto_reset), 'cuda:0')
+        self.t, self.g = torch, BatchedEnv(_lib.default_config(kind, num_envs=n, seed=seed, auto_reset=auto_reset, **kw), 'cuda:0')
 
     def reset(self): self.g.reset()
 
@@ -37,9 +37,9 @@ class GpuSide:
 
 
 class EmuSide:
-    def __init__(self, kind, n, seed, auto_reset):
+    def __init__(self, kind, n, seed, auto_reset, kw):
         import emu_env
-        self.e = emu_env.EmuEnv(orc.default_config(kind, num_envs=n, seed=seed, auto_reset=auto_reset))
+        self.e = emu_env.EmuEnv(orc.default_config(kind, num_envs=n, seed=seed, auto_reset=auto_reset, **kw))
 
     def reset(self): self.e.reset()
 
@@ -53,9 +53,10 @@ class EmuSide:
         return dict(state=e.state, items=e.items, aux=e.aux, obs=e.obs, rew=e.rew, done=e.done, info=e.info)
 
 
-def run(Side, kind, seed, auto_reset, n=48, T=10):
-    o = orc.OracleEnv(orc.default_config(kind, num_envs=n, seed=seed, auto_reset=auto_reset), np.float32)
-    s = Side(kind, n, seed, auto_reset)
+def run(Side, kind, seed, auto_reset, n=48, T=10, kw=None):
+    kw = kw or {}
+    o = orc.OracleEnv(orc.default_config(kind, num_envs=n, seed=seed, auto_reset=auto_reset, **kw), np.float32)
+    s = Side(kind, n, seed, auto_reset, kw)
     o.reset(); s.reset()
     rng = np.random.RandomState(seed)
     nq, nv = (7, 6) if kind == K.HRL_POINT_GATHER else (15, 14)
@@ -83,22 +84,39 @@ def run(Side, kind, seed, auto_reset, n=48, T=10):
             ok = (A == B) | ((A != A) & (B != B))
             if not ok.all():
                 e = int(np.where(~ok.all(1))[0][0])
-                return f'kind {kind} seed {seed} auto_reset {auto_reset} step {t}: {name} differs for env {e} at {np.where(~ok[e])[0][:8]}; oracle {A[e][~ok[e]][:6]} other {B[e][~ok[e]][:6]}; pre-step state {pre[e, :29]}'
+                return f'kind {kind} {kw} seed {seed} auto_reset {auto_reset} step {t}: {name} differs for env {e} at {np.where(~ok[e])[0][:8]}; oracle {A[e][~ok[e]][:6]} other {B[e][~ok[e]][:6]}; pre-step state {pre[e, :29]}'
     return None
+
+
+MATRIX = [  # non-default branches (the CONFIG_MATRIX of the parity tests), fuzzed with `matrix` as third argument
+    (K.HRL_ANT_GATHER, dict(n_bins=7, n_food=5, n_poison=3, sensor_range=9.0, sensor_span=2.0, world_size=(9.0, 11.0))),
+    (K.HRL_ANT_GATHER, dict(respawn=0, robot_coll_dist=4.0, dying_cost=-3.0)),
+    (K.HRL_ANT_GATHER, dict(robot_coll_dist=0.0)),
+    (K.HRL_ANT_GATHER, dict(use_sensor=0)),
+    (K.HRL_POINT_GATHER, dict(robot_coll_dist=-1.0, respawn=0)),
+    (K.HRL_POINT_GATHER, dict(use_sensor=0)),
+    (K.HRL_ANT_MAZE, dict(sense_target=1, n_bins=8)),
+    (K.HRL_ANT_MAZE, dict(target_encoding=1, sense_walls=0, tol=3.0, targ_dist_rew=1, max_steps=20, done_at_target=0)),
+    (K.HRL_ANT_MAZE_MJ, dict(inner_rew_weight=0.5, n_bins=6)),
+    (K.HRL_ANT_FLAGRUN, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
+    (K.HRL_ANT_FLAGRUN, dict(flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0), flag_timeout=8, flag_max_targets=5)),
+    (K.HRL_ANT_FLAGRUN, dict(flag_switch_on_collision=0, flag_timeout=7, flag_max_targets=4)),
+]
 
 
 def main():
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     Side = GpuSide if (len(sys.argv) > 2 and sys.argv[2] == 'gpu') else EmuSide
+    cases = MATRIX if (len(sys.argv) > 3 and sys.argv[3] == 'matrix') else [(k, {}) for k in KINDS]
     fails = 0
-    for kind in KINDS:
+    for kind, kw in cases:
         for seed in range(seeds):
             for ar in (0, 1):
-                r = run(Side, kind, seed, ar)
+                r = run(Side, kind, seed, ar, kw=kw)
                 if r:
                     fails += 1
                     print('FAIL', r, flush=True)
-    print(f'{Side.__name__}: {len(KINDS) * seeds * 2} runs of 10 steps x 48 envs, {fails} with a difference')
+    print(f'{Side.__name__}: {len(cases) * seeds * 2} runs of 10 steps x 48 envs ({"non-default configs" if cases is MATRIX else "default configs"}), {fails} with a difference')
     return 1 if fails else 0
 
 
