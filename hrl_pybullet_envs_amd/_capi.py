@@ -1,17 +1,18 @@
 """ctypes mirror of include/hrl_envs.h (structs + constants only; no library loading here)."""
 import ctypes as C
 
-HRL_ABI_VERSION = 5
+HRL_ABI_VERSION = 6
 HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER, HRL_ANT_MAZE_MJ, HRL_ANT_FLAGRUN = 0, 1, 2, 3, 4, 5
 HRL_STATE_STRIDE = 32
 HRL_QPOS_OFF, HRL_QVEL_OFF, HRL_EPRET_OFF, HRL_INITZ_OFF, HRL_POTENTIAL_OFF = 0, 15, 29, 30, 31
-HRL_ITEMS_STRIDE = 32
-HRL_MAX_ITEMS = 16
-HRL_MAX_BINS = 16
+HRL_ITEMS_STRIDE = 32  # the default configs; in general hrl_items_stride(cfg)
+HRL_MAX_ITEMS = 64
+HRL_MAX_BINS = 64
+HRL_MAX_OBS = 256
 HRL_AUX_STRIDE = 4
 HRL_INFO_STRIDE = 4
-HRL_MAX_TARGETS = 8
-HRL_MAX_GOALS = 15
+HRL_MAX_TARGETS = 64
+HRL_MAX_GOALS = 63
 HRL_OK, HRL_ERR_BAD_ARG, HRL_ERR_HIP, HRL_ERR_NO_DEVICE = 0, 1, 2, 3
 
 
@@ -43,7 +44,7 @@ class hrl_config(C.Structure):
                 ('walk_target', C.c_float * 2),
                 ('flag_size', C.c_float), ('flag_max_targets', C.c_int32), ('flag_timeout', C.c_int32),
                 ('flag_switch_on_collision', C.c_int32), ('flag_enclosed', C.c_int32), ('flag_max_target_dist', C.c_float),
-                ('flag_manual_goals', C.c_int32),
+                ('flag_manual_goals', C.c_int32), ('flag_goal_capacity', C.c_int32),
                 ('model', hrl_model)]
 
     def copy(self):
@@ -54,4 +55,5 @@ class hrl_config(C.Structure):
 
 class hrl_buffers(C.Structure):
     _fields_ = [('state', C.c_void_p), ('items', C.c_void_p), ('aux', C.c_void_p), ('actions', C.c_void_p),
-                ('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('info', C.c_void_p)]
+                ('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('info', C.c_void_p),
+                ('final_obs', C.c_void_p), ('truncated', C.c_void_p)]

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, 'libhrl_envs_hip.so')
 _lib = None
 
 # every symbol include/hrl_envs.h declares
-SYMBOLS = ['hrl_default_config', 'hrl_obs_dim', 'hrl_act_dim', 'hrl_create', 'hrl_destroy', 'hrl_reset', 'hrl_step',
+SYMBOLS = ['hrl_default_config', 'hrl_obs_dim', 'hrl_act_dim', 'hrl_items_stride', 'hrl_create', 'hrl_destroy', 'hrl_reset', 'hrl_step',
            'hrl_get_state', 'hrl_set_state', 'hrl_set_goals', 'hrl_next_target', 'hrl_last_error', 'hrl_backend']
 
 
@@ -40,6 +40,7 @@ def lib():
         L.hrl_default_config.argtypes = [C.c_int32, C.POINTER(K.hrl_config)]
         L.hrl_obs_dim.argtypes = [C.POINTER(K.hrl_config)]
         L.hrl_act_dim.argtypes = [C.POINTER(K.hrl_config)]
+        L.hrl_items_stride.argtypes = [C.POINTER(K.hrl_config)]
         _lib = L
     return _lib
 
@@ -64,6 +65,8 @@ def default_config(kind, **over):
             for i, x in enumerate(v):
                 arr[i] = x
         elif k == 'targets':
+            if len(v) > K.HRL_MAX_TARGETS:
+                raise ValueError(f'at most {K.HRL_MAX_TARGETS} targets')
             cfg.n_targets = len(v)
             for i, t in enumerate(v):
                 cfg.targets[i][0], cfg.targets[i][1] = float(t[0]), float(t[1])

@@ -33,7 +33,7 @@ def u01(x):
 def flag_goal(seed, flag_size, ep, k):
     """Goal k of episode ep of the shared list (ant_flagrun_env.py:71-78 with counter-based draws; step_core.h flag_goal):
     uniform in the square, redrawn while within 0.5 of the origin, at most 64 attempts.  ep, k broadcast; returns [..., 2] fp32."""
-    ep, k = np.broadcast_arrays(np.asarray(ep, np.uint64), np.asarray(k, np.uint64))
+    ep, k = np.broadcast_arrays(np.asarray(ep, np.int64).astype(np.uint64), np.asarray(k, np.int64).astype(np.uint64))
     size = np.float32(flag_size)
     gx = np.zeros(ep.shape, np.float32); gy = np.zeros(ep.shape, np.float32)
     todo = np.ones(ep.shape, bool)

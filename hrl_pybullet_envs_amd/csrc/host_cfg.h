@@ -60,6 +60,7 @@ inline int default_config(int32_t kind, hrl_config *c) {
         c->centroid_n_static = 3; c->centroid_static_sum[0] = -7.f;
     }
     c->flag_size = 10.f; c->flag_max_targets = 100; c->flag_timeout = 200; c->flag_switch_on_collision = 1; c->flag_enclosed = 1;
+    c->flag_goal_capacity = 15;
     if (kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:14-16; arena (size+2)^2 :59-61; start (0,0,0.25) :144 */
         c->use_sensor = 0; c->n_bins = 8; c->sensor_span = 3.14159265358979323846f; c->sensor_range = 4.f; c->tol = 0.5f;
         c->world_size[0] = 12.f; c->world_size[1] = 12.f; c->start_pos[2] = 0.25f;
@@ -85,6 +86,14 @@ inline int obs_dim(const hrl_config *c) {
     return -1;
 }
 inline int act_dim(const hrl_config *c) { return c->env_kind == HRL_POINT_GATHER ? 2 : 8; }
+/* floats per env of the items buffer: 32 (HRL_ITEMS_STRIDE) unless the config holds more than 16 items or 15 manual goals */
+inline int items_stride(const hrl_config *c) {
+    int words = 0;
+    if (c->env_kind == HRL_ANT_GATHER || c->env_kind == HRL_POINT_GATHER) words = 2 * (c->n_food + c->n_poison);
+    if (c->env_kind == HRL_ANT_FLAGRUN && c->flag_manual_goals) words = 2 * (1 + c->flag_goal_capacity);
+    const int s = (words + 31) / 32 * 32;
+    return s < HRL_ITEMS_STRIDE ? HRL_ITEMS_STRIDE : s;
+}
 
 /* returns "" when the config is usable, else the reason */
 inline std::string validate(const hrl_config *c) {
@@ -95,15 +104,15 @@ inline std::string validate(const hrl_config *c) {
     if (c->num_envs <= 0) return "num_envs must be positive";
     const bool gather = c->env_kind == HRL_ANT_GATHER || c->env_kind == HRL_POINT_GATHER;
     if (gather) {
-        if (c->n_food < 0 || c->n_poison < 0 || c->n_food + c->n_poison > HRL_MAX_ITEMS) return "n_food + n_poison must be within 0..16";
-        if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
+        if (c->n_food < 0 || c->n_poison < 0 || c->n_food + c->n_poison > HRL_MAX_ITEMS) return "n_food + n_poison must be within 0..64 (an item is a lane of the env's wave)";
+        if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..64";
         if (!(c->robot_coll_dist > 0) && !c->model.item_collision) return "robot_coll_dist <= 0 (contact based pickup, ant_gather_env.py:113-116) needs model.item_collision";
         if (!(c->world_size[0] > 1 && c->world_size[1] > 1 && c->world_size[0] < 50 && c->world_size[1] < 50)) return "world_size must be within (1, 50)";
         if (!(c->sensor_range > 0) || !(c->sensor_span > 0)) return "sensor_range and sensor_span must be positive";
     }
     if (c->env_kind == HRL_ANT_MAZE || c->env_kind == HRL_ANT_MAZE_MJ) {
-        if (c->n_targets < 1 || c->n_targets > HRL_MAX_TARGETS) return "n_targets must be within 1..8";
-        if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..16";
+        if (c->n_targets < 1 || c->n_targets > HRL_MAX_TARGETS) return "n_targets must be within 1..64";
+        if (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS) return "n_bins must be within 1..64";
         if (c->target_encoding != 0 && c->target_encoding != 1) return "target_encoding must be 0 (normed_vec) or 1 (angle)"; /* utils.py:66-68 */
         const bool walls = c->env_kind == HRL_ANT_MAZE_MJ || c->sense_walls; /* the Mj variant always senses walls (ant_maze_mj_env.py:58) */
         if ((walls || c->sense_target) && !(c->sensor_span > 0)) return "sensor_span must be positive";
@@ -119,10 +128,11 @@ inline std::string validate(const hrl_config *c) {
         if (close_mode && !(c->flag_max_target_dist / 2 > c->tol)) return "flag_max_target_dist / 2 must exceed tol (the per-axis offset is drawn from U(tol, max_target_dist / 2))";
         if (c->flag_timeout > 32767) return "flag_timeout must be <= 32767";
         if (!(c->flag_size > 1.0f)) return "flag_size must exceed 1 (targets are rejected within 0.5 of the origin)";
-        if (c->use_sensor && (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS)) return "sensor_bins must be within 1..16";
+        if (c->use_sensor && (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS)) return "sensor_bins must be within 1..64";
+        if (c->flag_manual_goals && (c->flag_goal_capacity < 1 || c->flag_goal_capacity > HRL_MAX_GOALS)) return "flag_goal_capacity must be within 1..63";
         if (c->use_sensor && c->n_bins < 2 && c->sensor_span != 6.28318530717958647692f) return "sensor_bins must be >= 2 unless sensor_span == 2 pi (the wall sensor divides by n_bins - 1)";
     }
-    if (obs_dim(c) > 64) { snprintf(buf, sizeof buf, "observation width %d exceeds 64", obs_dim(c)); return buf; }
+    if (obs_dim(c) > HRL_MAX_OBS) { snprintf(buf, sizeof buf, "observation width %d exceeds %d", obs_dim(c), HRL_MAX_OBS); return buf; }
     const hrl_model &m = c->model;
     if (!(m.timestep > 0) || m.frame_skip < 1 || m.frame_skip > 64 || m.solver_iters < 1 || m.solver_iters > 64) return "bad timestep / frame_skip / solver_iters";
     if (!(m.density > 0)) return "density must be positive";
@@ -193,6 +203,8 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.flag_switch = c.flag_switch_on_collision; d.flag_mtd = c.flag_max_target_dist; d.flag_manual = c.flag_manual_goals;
     d.self_collision = m.self_collision; d.item_collision = m.item_collision; d.mu_self = m.friction_robot * m.friction_robot;
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
+    d.items_stride = items_stride(&c);
+    d.item_shift = c.n_food + c.n_poison > 16 ? 6 : 4;
 }
 
 }  // namespace hrl

@@ -260,6 +260,7 @@ DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
     DevBufs d;
     d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
     d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask;
+    d.final_obs = b->final_obs; d.truncated = b->truncated;
     d.stamps = g_stamps;
     return d;
 }
@@ -282,6 +283,7 @@ int hrl_default_config(int32_t env_kind, hrl_config *cfg) {
 }
 int hrl_obs_dim(const hrl_config *cfg) { return cfg ? obs_dim(cfg) : -1; }
 int hrl_act_dim(const hrl_config *cfg) { return cfg ? act_dim(cfg) : -1; }
+int hrl_items_stride(const hrl_config *cfg) { return cfg ? items_stride(cfg) : -1; }
 
 int hrl_create(const hrl_config *cfg, hrl_handle **out) {
     if (!out) return fail(HRL_ERR_BAD_ARG, "hrl_create: null out");
@@ -355,15 +357,16 @@ int hrl_set_goals(hrl_handle *h, const hrl_buffers *b, const float *goals_xy, in
     if (!h || !b || !b->state || !b->aux || !b->obs || !b->items || !goals_xy) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: null handle or buffer");
     if (h->dc.kind != HRL_ANT_FLAGRUN || !h->dc.flag_manual) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: only for AntFlagrun with flag_manual_goals (manual_goal_creation, ant_flagrun_env.py:27)");
     if (h->dc.flag_mtd > 0.f) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: with flag_max_targets < 1 next_target() draws a goal near the robot and ignores the list (ant_flagrun_env.py:113-114): use hrl_next_target");
-    if (n_goals < 1 || n_goals > HRL_MAX_GOALS) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: n_goals must be within 1..15");
+    if (n_goals < 1 || n_goals > h->cfg.flag_goal_capacity) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: n_goals must be within 1..flag_goal_capacity (" + std::to_string(h->cfg.flag_goal_capacity) + ")");
     hipLaunchKernelGGL(k_set_goals, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc, goals_xy, (int)n_goals, (uint8_t *)nullptr);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_set_goals launch");
 }
 
 int hrl_next_target(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, uint8_t *ok, void *stream) {
-    if (!h || !b || !b->state || !b->aux || !b->obs || !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: null handle or buffer");
-    if (h->dc.kind != HRL_ANT_FLAGRUN || !h->dc.flag_manual) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: only for AntFlagrun with flag_manual_goals (manual_goal_creation, ant_flagrun_env.py:27)");
+    if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: null handle or buffer");
+    if (h->dc.kind != HRL_ANT_FLAGRUN) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: only for AntFlagrun (ant_flagrun_env.py:112-120)");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: this env keeps its goals in the items buffer (max_target_dist or manual goals)");
     hipLaunchKernelGGL(k_set_goals, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc, (const float *)nullptr, 0, ok);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_next_target launch");

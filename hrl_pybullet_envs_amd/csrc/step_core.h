@@ -66,7 +66,7 @@ struct DevCfg {
     float world_sx, world_sy, sensor_range, sensor_span, coll_dist, spacing, dying_cost;
     int target_encoding, sense_target, sense_walls, done_at_target, max_steps, targ_dist_rew, n_targets;
     float tol, inner_rew_weight;
-    float targets[8][2];
+    float targets[HRL_MAX_TARGETS][2];
     float start_pos[3];
     int centroid_n_static;
     float centroid_sx, centroid_sy, walk_tx, walk_ty;
@@ -84,6 +84,8 @@ struct DevCfg {
     int self_collision, item_collision;
     float mu_self; /* friction between two ant links */
     int obs_dim, act_dim;
+    int items_stride; /* floats per env of the items buffer (hrl_items_stride): 32 for the default configs */
+    int item_shift;   /* respawn key of a contact pickup: item | move << item_shift; 4 for up to 16 items (the streams of ABI <= 5), else 6 */
 };
 
 struct DevBufs {
@@ -93,6 +95,8 @@ struct DevBufs {
     float *obs, *reward;
     uint8_t *done;
     float *info;
+    float *final_obs;   /* optional: the observation of the step that ended an episode (include/hrl_envs.h) */
+    uint8_t *truncated; /* optional: ended by the step limit alone */
     const uint8_t *mask;
     unsigned long long *stamps; /* diagnostic builds only (tools/stamp_profile.py): per-phase cycle sums */
 };
@@ -110,12 +114,12 @@ struct alignas(16) WaveLds {
         };
         struct {
             float s28[32];       /* upstream 28-vector (WalkerBase.calc_state) */
-            float obs[64];
-            float ibin[16];      /* per item: sensor bin (as float, -1 = none) */
-            float iint[16];      /* per item: intensity */
-            float irew[16];      /* per item: pickup reward */
+            float obs[HRL_MAX_OBS];
+            float ibin[HRL_MAX_ITEMS]; /* per item: sensor bin (as float, -1 = none) */
+            float iint[HRL_MAX_ITEMS]; /* per item: intensity */
+            float irew[HRL_MAX_ITEMS]; /* per item: pickup reward */
             float red[16];
-            int flags[8];        /* 0: non-finite obs seen, 1: done, 3: flagrun retarget, 4: flagrun packed goal state */
+            int flags[8];        /* 0: non-finite obs seen, 1: done, 2: ended by the step limit alone, 3: flagrun retarget, 4: flagrun packed goal state */
             float scal[8];       /* 0: reward, 1: food_rew, 2: dead_rew, 3: walk_target_dist, 4: yaw, 5: joints_at_limit, 6-7: parts centroid xy */
         };
     };
@@ -125,7 +129,7 @@ struct alignas(16) WaveLds {
     float ustar[16];     /* unconstrained velocity (dof order) */
     float st[32];        /* packed state record as stored in HBM */
     float jlim[2][NJ];   /* joint ranges, copied from the constants when the env is loaded (phase L reads them per lane) */
-    float items[32];
+    float items[2 * HRL_MAX_ITEMS]; /* the env's items record (the default configs use the first 32 floats) */
     float act[8];
     int aux[4];
     float q[2][16];      /* ping-pong: substep s reads q[s&1], writes q[(s+1)&1] */
@@ -152,6 +156,9 @@ struct alignas(16) WaveLds {
     float planes[4][4];  /* lateral half-spaces (n, d), copied from the constants when the env is loaded: the collision passes index them per lane */
 #ifdef HRL_WGTIME
     int dbg_rows; /* diagnostic build (tools/wg_times.py): solver rows | cube passes << 16 | self-contact substeps << 24, summed over the step */
+#endif
+#ifdef HRL_LDS_PAD
+    float pad_[HRL_LDS_PAD]; /* A/B builds (tools/variants.py): the stride between the four records of a group decides which LDS banks the leader's lanes of different envs hit */
 #endif
 };
 
@@ -618,6 +625,8 @@ HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, fl
 
 /* what a contact is with (WaveLds::csurf; the oracle's ORC_SURF_* codes) */
 constexpr int SURF_BOX = 8, SURF_ITEM = 16, SURF_SELF = 64;
+/* code of item cube i: SURF_ITEM + i for the first 48 items (every config of ABI <= 5), the items beyond sit behind the 48 capsule-pair codes */
+HRL_DEV int surf_item(int i) { return i + (i < 48 ? SURF_ITEM : SURF_SELF); }
 constexpr float ITEM_HALF = 0.125f, ITEM_Z = 0.1f; /* assets/food.xml:12,19 (box size 0.25), gather_scene.py:62 */
 
 /* r = contact point relative to O, n = normal towards the body `link`; link2 >= 0: against that ant body (self contact) */
@@ -668,7 +677,7 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
     if (item >= 0) {
         const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
         const float lo[3] = {ix - ITEM_HALF, iy - ITEM_HALF, ITEM_Z - ITEM_HALF}, hi[3] = {ix + ITEM_HALF, iy + ITEM_HALF, ITEM_Z + ITEM_HALF};
-        h.dist = sphere_vs_box(p, rad, lo, hi, h.n); h.surf = SURF_ITEM + item;
+        h.dist = sphere_vs_box(p, rad, lo, hi, h.n); h.surf = surf_item(item);
     } else if (f == 0) h.dist = (p[2] - c.ground_z) - rad;
     else if (f <= c.n_planes) {
         h.n[0] = L.planes[f - 1][0]; h.n[1] = L.planes[f - 1][1]; h.n[2] = L.planes[f - 1][2];
@@ -825,11 +834,14 @@ HRL_DEV void phase_self_rows(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
  * they stay in registers: a runtime index would push them out into scratch memory.
  * `one(r)` is 1 on lane r and 0 elsewhere (the unit diagonal), supplied by the executor. */
 struct J2pair { float h, a; }; /* self-contact rows: the second leg's entries of the lane's row (from WaveLds::J2) */
-template <bool SELF>
+template <bool SELF, bool FREE = false> /* FREE: the row of a single free body (the point bot): no joint entries */
 HRL_DEV float row_dot(const LaneRegs &g, const float *Brow, const J2pair &j2) {
     float a = g.Jb[0] * Brow[0];
 #pragma unroll
     for (int d = 1; d < 6; ++d) a = fma_(g.Jb[d], Brow[d], a);
+    /* the joint slots of a free body hold exact zeros on both sides: fma(+0, +0, a) is a + (+0) -- which turns a -0 into +0 and changes nothing
+       else -- and a second one is the identity; written as that addition, the row needs neither the two loads nor Jh / Ja / jslot in registers */
+    if (FREE) return a + 0.f;
     const int s1 = g.jslot & 0xff;
     a = fma_(g.Jh, Brow[s1], a);
     a = fma_(g.Ja, Brow[s1 + 1], a);
@@ -868,6 +880,7 @@ HRL_DEV void row_dot4(const LaneRegs &g, const float *B0, const float *B1, const
  * block's end inside its last group are computed from whatever LDS holds and never read by the sweeps. */
 template <bool SELF, int G, bool WIDE, class One>
 HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, One one, const J2pair &j2) {
+    constexpr bool FREE = !WIDE; /* the narrow build is the point bot's */
     if (4 * G < nB) {
         if constexpr (WIDE) {
             float a[4];
@@ -876,7 +889,7 @@ HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, 
             for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, a[i], one(4 * G + i));
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[4 * G + i], j2), one(4 * G + i));
+            for (int i = 0; i < 4; ++i) g.An[4 * G + i] = fma_(ninvd, row_dot<SELF, FREE>(g, L.Bt[4 * G + i], j2), one(4 * G + i));
         }
     } else {
 #pragma unroll
@@ -885,6 +898,7 @@ HRL_DEV void build_An_group(const WaveLds &L, LaneRegs &g, int nB, float ninvd, 
 }
 template <bool SELF, int G, bool WIDE, class One>
 HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float ninvd, One one, const J2pair &j2) {
+    constexpr bool FREE = !WIDE;
     if (4 * G < nF) {
         if constexpr (WIDE) {
             float a[4];
@@ -893,7 +907,7 @@ HRL_DEV void build_Af_group(const WaveLds &L, LaneRegs &g, int nB, int nF, float
             for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, a[i], one(nB + 4 * G + i));
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot<SELF>(g, L.Bt[nB + 4 * G + i], j2), one(nB + 4 * G + i));
+            for (int i = 0; i < 4; ++i) g.Af[4 * G + i] = fma_(ninvd, row_dot<SELF, FREE>(g, L.Bt[nB + 4 * G + i], j2), one(nB + 4 * G + i));
         }
     } else {
 #pragma unroll
@@ -910,9 +924,10 @@ template <bool SELF, int MB, class One> /* MB = most bounded rows the caller can
 HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
     J2pair j2{0.f, 0.f};
     if (SELF && lane < MAXR) { j2.h = L.J2[lane][0]; j2.a = L.J2[lane][1]; }
-    const float invd = 1.f / row_dot<SELF>(g, L.Bt[lane < nB + nF ? lane : 0], j2); /* 1 / A_ii; idle lanes carry row 0's registers */
+    constexpr bool FREE = MB != MAXB; /* the point bot's solver (no limit rows: at most MAXC bounded rows) */
+    const float invd = 1.f / row_dot<SELF, FREE>(g, L.Bt[lane < nB + nF ? lane : 0], j2); /* 1 / A_ii; idle lanes carry row 0's registers */
     build_A_blocks<SELF>(L, g, nB, nF, -invd, one, j2, std::make_integer_sequence<int, MB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
-    g.c = -(invd * (row_dot<SELF>(g, L.ustar, j2) + g.bias));
+    g.c = -(invd * (row_dot<SELF, FREE>(g, L.ustar, j2) + g.bias));
 }
 
 /* Phase I (dof map): integrate positions; the joint rates were clamped by the caller.  Lane k < 16 produces element k
@@ -1145,8 +1160,8 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
     if (items_on) { /* food / poison cubes: lane = item decides whether its cube is within reach of any sphere (the cube's
                        half extent more than the planes' bound, per axis), then the near cubes are tested four at a time */
         const float R = reach + ITEM_HALF;
-        unsigned long long near = x.each_ballot([&](int lane) {
-            return (lane < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * (lane & 15)]) < R) & (fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R);
+        unsigned long long near = x.each_ballot([&](int lane) { /* lane = item (at most 64 of them) */
+            return (lane < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * lane]) < R) & (fabsf(q[1] - L.items[2 * lane + 1]) < R);
         });
         while (near) {
 #ifdef HRL_WGTIME
@@ -1292,13 +1307,17 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
             x.each([&](int lane) { if (lane == 0) L.nC = nC; });
         }
     }
-    if (items_on) { /* lane = (env, item): cubes within reach of any sphere of their env's ant; then one near cube per env and pass */
+    if (items_on) { /* lane = (env, item): cubes within reach of any sphere of their env's ant; then one near cube per env and pass.
+                       More than 16 items: slice after slice of 16 (one trip for the default configs), which keeps the slot order */
         const float R = reach + ITEM_HALF;
+        const int n_items = c.n_food + c.n_poison;
+#pragma unroll 1
+        for (int ib = 0; ib < n_items; ib += 16) {
         unsigned long long near = x.each_ballot([&](int lane) {
             const WaveLds &L = x.lds(lane >> 4);
             const float *q = L.q[qi];
-            const int it = lane & 15;
-            return (it < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * it]) < R) & (fabsf(q[1] - L.items[2 * it + 1]) < R);
+            const int it = ib + (lane & 15);
+            return (it < n_items) & (fabsf(q[0] - L.items[2 * it]) < R) & (fabsf(q[1] - L.items[2 * it + 1]) < R);
         });
         while (near) {
             const unsigned long long cur = near;
@@ -1306,7 +1325,7 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
                 [&](int lane) {
                     WaveLds &L = x.lds(lane >> 4);
                     const unsigned sub = (unsigned)(cur >> (lane & 48)) & 0xffffu;
-                    const int s = lane & 15, item = sub ? __builtin_ctz(sub) : -1;
+                    const int s = lane & 15, item = sub ? ib + __builtin_ctz(sub) : -1;
                     return sphere_vs_surface(c, L, L.q[qi], (item >= 0 && s < 13) ? s : -1, 0, item);
                 },
                 [&](int lane, int rank, const Hit &h) { WaveLds &L = x.lds(lane >> 4); store_contact(L, L.nC + rank, h, false); },
@@ -1318,6 +1337,7 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const unsigned sub = (unsigned)(near >> (16 * e)) & 0xffffu; low |= (unsigned long long)(sub & (0u - sub)) << (16 * e); }
             near &= ~low;
+        }
         }
     }
     if (c.self_collision) { /* the envs with a joint outside the range in which no two legs can meet (see ant_contacts), one after the other */
@@ -1449,7 +1469,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
             if (item >= 0) {
                 const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
                 const float lo[3] = {ix - ITEM_HALF, iy - ITEM_HALF, ITEM_Z - ITEM_HALF}, hi[3] = {ix + ITEM_HALF, iy + ITEM_HALF, ITEM_Z + ITEM_HALF};
-                h.dist = sphere_vs_box(p, 0.f, lo, hi, h.n); h.surf = SURF_ITEM + item;
+                h.dist = sphere_vs_box(p, 0.f, lo, hi, h.n); h.surf = surf_item(item);
             } else if (f == 0) h.dist = p[2] - c.ground_z;
             else {
                 h.n[0] = L.planes[f - 1][0]; h.n[1] = L.planes[f - 1][1]; h.n[2] = L.planes[f - 1][2];
@@ -1477,8 +1497,8 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
     }
     if (items_on) { /* cubes whose box comes within reach of a corner (half diagonal 0.35 sqrt 3 = 0.607), four per pass */
         const float R = 0.35f * 1.7320508f + ITEM_HALF + c.cdist + 0.02f;
-        unsigned long long near = x.each_ballot([&](int lane) {
-            return (lane < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * (lane & 15)]) < R) & (fabsf(q[1] - L.items[2 * (lane & 15) + 1]) < R);
+        unsigned long long near = x.each_ballot([&](int lane) { /* lane = item (at most 64 of them) */
+            return (lane < c.n_food + c.n_poison) & (fabsf(q[0] - L.items[2 * lane]) < R) & (fabsf(q[1] - L.items[2 * lane + 1]) < R);
         });
         const unsigned long long near0 = near;
         while (near) {
@@ -1501,19 +1521,21 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
         /* then the near cubes' own 8 corners against the player's oriented box -- what catches a cube under the middle of a face --,
            eight cubes per pass: the corner in the box frame, its closest surface point, the normal turned back to the world and
            towards the player */
-        near = near0;
         x.refresh();
-        while (near) {
-            const unsigned group = (unsigned)near; /* at most 16 items: slot `lane >> 3` takes the group's slot-th near cube */
+#pragma unroll 1
+        for (int ib = 0; ib < 64; ib += 32) { /* items 0..31, then (configs with more than 32 items) 32..63: ascending item order either way */
+        unsigned near32 = (unsigned)(near0 >> ib);
+        while (near32) {
+            const unsigned group = near32; /* slot `lane >> 3` takes the group's slot-th near cube */
 #pragma unroll
-            for (int k = 0; k < 8; ++k) near &= near - 1;
+            for (int k = 0; k < 8; ++k) near32 &= near32 - 1;
             int cnt = x.each_compact(
                 [&](int lane) {
                     const int slot = lane >> 3;
                     unsigned m = group;
 #pragma unroll
                     for (int k = 0; k < 7; ++k) m = k < slot ? (m & (m - 1)) : m;
-                    const int item = m ? (int)__builtin_ctz(m) : -1;
+                    const int item = m ? ib + (int)__builtin_ctz(m) : -1;
                     CornerHit h; h.ok = false; h.dist = 0.f; h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.c[0] = h.c[1] = h.c[2] = 0.f; h.surf = 0;
                     if (item >= 0) {
                         const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
@@ -1522,7 +1544,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
                         const float d[3] = {pc[0] - q[0], pc[1] - q[1], pc[2] - q[2]};
                         const float l[3] = {dot3(d, &L.XYZ[0]), dot3(d, &L.XYZ[3]), dot3(d, &L.XYZ[6])}, blo[3] = {-he, -he, -he}, bhi[3] = {he, he, he};
                         float nl[3];
-                        h.dist = sphere_vs_box(l, 0.f, blo, bhi, nl); h.surf = SURF_ITEM + item;
+                        h.dist = sphere_vs_box(l, 0.f, blo, bhi, nl); h.surf = surf_item(item);
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             const float nw = fma_(nl[2], L.XYZ[6 + k], fma_(nl[1], L.XYZ[3 + k], nl[0] * L.XYZ[k]));
@@ -1535,6 +1557,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
                 keep(nC), [&](int, const CornerHit &) {});
             nC += cnt;
             if (nC > MAXC) nC = MAXC;
+        }
         }
     }
     x.each([&](int lane) { /* contact map: tangents of the kept contacts */
@@ -1694,10 +1717,19 @@ HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, in
     return best;
 }
 
+/* maze kinds: the episode's target, entry aux[3] of the constructor's `targets` (ant_maze_bullet_env.py:114-115): a wave-uniform index,
+ * so the pair is a scalar load from the constants; an index outside the table (the caller owns `aux`) reads entry 0 */
+template <class X>
+HRL_DEV void maze_target(X &x, const DevCfg &c, WaveLds &L, float *tx, float *ty) {
+    const unsigned ti = (unsigned)x.uniform(L.aux[3]);
+    const int k = ti < (unsigned)HRL_MAX_TARGETS ? (int)ti : 0;
+    *tx = c.targets[k][0]; *ty = c.targets[k][1];
+}
+
 /* Phase O1: upstream WalkerBase.calc_state (28-vector clipped to +-5) into L.s28, plus walk_target_dist, yaw and
  * joints_at_limit into L.scal.  `with_centroid` needs L.ph/pa/tip of the CURRENT qpos (phase_kin_ankle on L.st). */
 template <int KIND>
-HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_feet, bool with_centroid) {
+HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_feet, bool with_centroid, float mtx, float mty) {
     const float *qp = L.st, *qv = L.st + 15;
     float rpy[3];
     quat_to_rpy(qp + 3, rpy);
@@ -1706,12 +1738,7 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
         if (c.flag_mtd > 0.f || c.flag_manual) { tx = L.items[0]; ty = L.items[1]; }
         else flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &tx, &ty);
     }
-    if (KIND == 2 || KIND == 4) { /* maze kinds: the episode's target */
-        const int ti = L.aux[3];
-        tx = c.targets[0][0]; ty = c.targets[0][1];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) { tx = (ti == i) ? c.targets[i][0] : tx; ty = (ti == i) ? c.targets[i][1] : ty; }
-    }
+    if (KIND == 2 || KIND == 4) { tx = mtx; ty = mty; } /* maze kinds: the episode's target (maze_target) */
     float cx = qp[0], cy = qp[1];
     if (with_centroid) {
         float sx = 0.f, sy = 0.f;
@@ -1776,8 +1803,7 @@ HRL_DEV void respawn_item(const DevCfg &c, long long env, uint32_t index, uint32
  * the item's cube among the `n_contacts` contacts of the step's last collision pass (L.csurf), the observation is taken
  * BEFORE such an item is moved (:95-96 precede :113). */
 HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, bool pickups, int n_contacts) {
-    const int n = c.n_food + c.n_poison;
-    if (lane >= 16) return;
+    const int n = c.n_food + c.n_poison; /* <= HRL_MAX_ITEMS = the lanes of the wave */
     float rew = 0.f, bin = -1.f, inten = 0.f;
     if (lane < n) {
         const float rx = L.st[0], ry = L.st[1], yaw = L.scal[4];
@@ -1803,12 +1829,12 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
         }
         if (pickups && !(c.coll_dist > 0.f)) {
             int hits = 0;
-            for (int i = 0; i < n_contacts; ++i) hits += L.csurf[i] == SURF_ITEM + lane ? 1 : 0;
+            for (int i = 0; i < n_contacts; ++i) hits += L.csurf[i] == surf_item(lane) ? 1 : 0;
             if (hits > 0) {
                 rew = (lane < c.n_food ? 1.f : -1.f) * (float)hits;
                 /* the reference moves the item once per contact point (gather_scene.py:95-114); the moves are independent
-                 * draws, keyed item | move << 4, so the last one is where it ends up */
-                if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane | ((hits - 1) << 4), rx, ry, &ix, &iy);
+                 * draws, keyed item | move << 4 (<< 6 with more than 16 items), so the last one is where it ends up */
+                if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane | ((hits - 1) << c.item_shift), rx, ry, &ix, &iy);
                 else { ix = 100.f; iy = 0.f; }
                 L.items[2 * lane] = ix; L.items[2 * lane + 1] = iy;
             }
@@ -1819,7 +1845,7 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
 
 /* Phase O3: final observation vector into L.obs, non-finite flag into L.flags[0] */
 template <int KIND>
-HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
+HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane /* = observation element: lane + 64 * pass */, float mtx, float mty) {
     if (lane >= c.obs_dim) return;
     float v = 0.f;
     if (KIND == 0) v = L.st[lane];                       /* MjAnt.py:17-25: qpos | qvel */
@@ -1844,8 +1870,15 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
            twice per item); same order, same comparisons */
         bool bad = false;
 #pragma unroll
-        for (int k = 0; k < HRL_MAX_ITEMS; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const bool mine = (k >= k0) & (k < k1);
+            const bool take = mine & (L.ibin[k] == (float)bin) & (L.iint[k] > best);
+            best = take ? L.iint[k] : best;
+            bad = bad | (mine & (L.ibin[k] == -2.f));
+        }
+#pragma unroll 1
+        for (int k = 16; k < k1; ++k) { /* configs with more than 16 items: the rest of the slots, same order, same comparisons */
+            const bool mine = k >= k0;
             const bool take = mine & (L.ibin[k] == (float)bin) & (L.iint[k] > best);
             best = take ? L.iint[k] : best;
             bad = bad | (mine & (L.ibin[k] == -2.f));
@@ -1867,10 +1900,7 @@ HRL_DEV void phase_pack_obs(const DevCfg &c, WaveLds &L, int lane) {
     }
     if (KIND == 2 && lane >= 26) {
         const float rx = L.st[0], ry = L.st[1], yaw = L.scal[4];
-        const int ti = L.aux[3];
-        float tx = c.targets[0][0], ty = c.targets[0][1];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) { tx = (ti == i) ? c.targets[i][0] : tx; ty = (ti == i) ? c.targets[i][1] : ty; }
+        const float tx = mtx, ty = mty;
         const int ntar = c.sense_target ? c.n_bins : 2;
         if (lane < 26 + ntar) {
             const int i = lane - 26;
@@ -1928,16 +1958,21 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode, i
         x.each([&](int lane) { if (lane < 16) L.q[0][lane] = lane < 15 ? L.st[lane] : 0.f; });
         x.each([&](int lane) { phase_kin_ankle<true>(c, L, x.reg(lane), L.q[0], lane); });
     }
+    float mtx = 0.f, mty = 0.f;
+    if (KIND == 2 || KIND == 4) maze_target(x, c, L, &mtx, &mty);
     x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
     if (KIND == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
     else {
         const bool feet = step_mode && (KIND == 2 || KIND == 5); /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
-        x.each([&](int lane) { phase_calc_state<KIND>(c, L, lane, feet, centroid); });
+        x.each([&](int lane) { phase_calc_state<KIND>(c, L, lane, feet, centroid, mtx, mty); });
     }
     x.stamp(21);
     if (KIND == 1 || KIND == 3) x.each([&](int lane) { phase_items(c, L, lane, env, step_mode, n_contacts); });
     x.stamp(22);
-    x.each([&](int lane) { phase_pack_obs<KIND>(c, L, lane); });
+    /* lane = observation element; observations wider than the wave (more than 19 bins, say) take ceil(obs_dim / 64) passes (one copy of the
+       packing code: a wave-uniform loop that the default configs run once) */
+#pragma unroll 1
+    for (int o = 0; o < c.obs_dim; o += 64) x.each([&](int lane) { phase_pack_obs<KIND>(c, L, lane + o, mtx, mty); });
 }
 
 /* ================================================================================================= RESET / STEP */
@@ -1957,12 +1992,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
             if (KIND == 5) {
                 if (c.flag_mtd > 0.f || c.flag_manual) { ptx = L.items[0]; pty = L.items[1]; }
                 else flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &ptx, &pty);
-            } else {
-                const int ti = L.aux[3];
-                ptx = c.targets[0][0]; pty = c.targets[0][1];
-#pragma unroll
-                for (int i = 1; i < 8; ++i) { ptx = (ti == i) ? c.targets[i][0] : ptx; pty = (ti == i) ? c.targets[i][1] : pty; }
-            }
+            } else maze_target(x, c, L, &ptx, &pty);
         }
         x.each([](int) {}); /* the reads above precede the writes below */
     }
@@ -2010,6 +2040,16 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
             L.aux[3] = (int)(r[0] % (uint32_t)c.n_targets);
         }
     });
+    if ((KIND == 1 || KIND == 3 || KIND == 5) && c.items_stride > 32) /* a longer items record: items 16.. of a gather env (gather_scene.py:38-50), zeros elsewhere */
+        x.each([&](int lane) {
+            const uint32_t ep = (uint32_t)L.aux[2];
+            const int i = 16 + lane;
+            if (i < HRL_MAX_ITEMS) {
+                float px = 0.f, py = 0.f;
+                if ((KIND == 1 || KIND == 3) && i < c.n_food + c.n_poison) respawn_item(c, env, ep, 1u, i, 0.f, 0.f, &px, &py);
+                L.items[2 * i] = px; L.items[2 * i + 1] = py;
+            }
+        });
     x.each([&](int lane) { if (lane == 0) L.aux[0] = 0; if (lane == 2) L.aux[2] = L.aux[2] + 1; });
     compute_obs<KIND>(x, c, env, false);
     x.each([&](int lane) {
@@ -2031,7 +2071,10 @@ HRL_DEV void load_env(X &x, const DevBufs &b, const DevCfg &c, int e, bool with_
     WaveLds &L = x.lds();
     x.each([&](int lane) {
         if (lane < 32) L.st[lane] = b.state[(size_t)e * 32 + lane];
-        else L.items[lane - 32] = b.items ? b.items[(size_t)e * 32 + (lane - 32)] : 0.f;
+        else L.items[lane - 32] = b.items ? b.items[(size_t)e * c.items_stride + (lane - 32)] : 0.f;
+#pragma unroll 1
+        for (int o = 32; o < c.items_stride; o += 64) /* a longer items record (more than 16 items / 15 manual goals): the rest of it */
+            if (o + lane < c.items_stride) L.items[o + lane] = b.items ? b.items[(size_t)e * c.items_stride + (o + lane)] : 0.f;
         if (lane < 4) L.aux[lane] = b.aux[(size_t)e * 4 + lane];
         if (lane < 8) L.act[lane] = (with_actions && lane < c.act_dim) ? b.actions[(size_t)e * c.act_dim + lane] : 0.f;
         if (lane >= 8 && lane < 16) { L.jlim[0][lane - 8] = c.jlo[lane - 8]; L.jlim[1][lane - 8] = c.jhi[lane - 8]; }
@@ -2043,9 +2086,15 @@ HRL_DEV void store_env(X &x, const DevBufs &b, const DevCfg &c, int e) {
     WaveLds &L = x.lds();
     x.each([&](int lane) {
         if (lane < 32) b.state[(size_t)e * 32 + lane] = L.st[lane];
-        else if (b.items) b.items[(size_t)e * 32 + (lane - 32)] = L.items[lane - 32];
+        else if (b.items) b.items[(size_t)e * c.items_stride + (lane - 32)] = L.items[lane - 32];
+#pragma unroll 1
+        for (int o = 32; o < c.items_stride; o += 64)
+            if (b.items && o + lane < c.items_stride) b.items[(size_t)e * c.items_stride + (o + lane)] = L.items[o + lane];
         if (lane < 4) b.aux[(size_t)e * 4 + lane] = L.aux[lane];
         if (lane < c.obs_dim) b.obs[(size_t)e * c.obs_dim + lane] = L.obs[lane];
+#pragma unroll 1
+        for (int o = 64; o < c.obs_dim; o += 64) /* observations wider than the wave */
+            if (o + lane < c.obs_dim) b.obs[(size_t)e * c.obs_dim + (o + lane)] = L.obs[o + lane];
     });
 }
 
@@ -2072,10 +2121,12 @@ HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, con
     load_env(x, b, c, e, false);
     if (n_goals > 0) {
         x.each([&](int lane) {
-            if (lane >= 2 && lane < 32) { /* items word `lane`: pending slot (lane - 2) >> 1 */
-                const int k = (lane - 2) >> 1, comp = lane & 1;
-                L.items[lane] = k < n_goals ? goals_xy[((size_t)e * n_goals + k) * 2 + comp] : 0.f;
-            }
+#pragma unroll 1
+            for (int w = lane; w < c.items_stride; w += 64)
+                if (w >= 2) { /* items word w: pending slot (w - 2) >> 1 */
+                    const int k = (w - 2) >> 1, comp = w & 1;
+                    L.items[w] = k < n_goals ? goals_xy[((size_t)e * n_goals + k) * 2 + comp] : 0.f;
+                }
             if (lane == 63) L.aux[3] = (int)(((uint32_t)n_goals & 0xffffu) | ((uint32_t)L.aux[3] & 0xffff0000u));
         });
     }
@@ -2088,6 +2139,9 @@ HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, con
         if (c.flag_mtd > 0.f) {
             cur = (cur + 1u) & 0xffffu;
             flag_close_goal(c, env, (uint32_t)L.aux[2], cur, L.st[0], L.st[1], &gx, &gy);
+        } else if (!c.flag_manual) { /* the shared list of a non-manual env (:91-96): goal k of the episode is a function of (seed, episode, k),
+                                        `cur` of its flag_max_targets goals are used up; popping one more is cur + 1 */
+            if (cur >= (uint32_t)c.flag_max_targets) good = 0; else cur += 1u;
         } else if (cur == 0u) good = 0;
         else { cur -= 1u; gx = L.items[2 + 2 * cur]; gy = L.items[3 + 2 * cur]; }
         if (good) { L.items[0] = gx; L.items[1] = gy; L.aux[3] = (int)(cur | (a3 & 0x7fff0000u)); }
@@ -2102,7 +2156,6 @@ HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, con
 template <int KIND, class X>
 HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     WaveLds &L = x.lds();
-    const long long env = c.env_id_offset + e;
     const bool on = e < c.n_envs;
     if (on) {
         load_env(x, b, c, e, true);
@@ -2137,6 +2190,19 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         }
     } else {
         x.each([&](int lane) { if (lane == 0) L.on = on ? 1 : 0; });
+        if (!on) /* a record of a ragged last group that holds no env: the packed phases of the leader and of the contact waves compute it along
+                    (results never used), so it is PARKED -- at rest high above the ground, far from every wall, box and cube, joints in the range
+                    in which no legs can meet and away from their limits: no pass beyond the ones every record gets is ever run for it, and what
+                    the group costs does not depend on what LDS held before */
+            x.each([&](int lane) {
+                if (lane < 16) {
+                    const float v = lane == 2 ? 1e3f : (lane == 6 ? 1.f : 0.f);
+                    L.q[0][lane] = v; L.q[1][lane] = v; L.u[lane] = 0.f;
+                }
+                if (lane < 8) { L.tau[lane] = 0.f; L.jlim[0][lane] = -1e3f; L.jlim[1][lane] = 1e3f; }
+                L.items[lane] = 1e6f; L.items[64 + lane] = 1e6f;
+                if (lane >= 16 && lane < 32) L.planes[(lane - 16) >> 2][lane & 3] = (lane & 3) == 2 ? 1.f : ((lane & 3) == 3 ? -1e6f : 0.f);
+            });
         x.group_sync(); /* every record of the group is loaded before another wave reads it */
 #pragma unroll 1
         for (int s = 0; s < c.nsub; ++s) { /* substep s: dynamics (leader) next to contacts (the other waves) | rows, solve, integrate */
@@ -2162,8 +2228,10 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         if (on) n_contacts = x.uniform(L.nC);
     }
     if (!on) return;
-    int eo = e; /* the env index again, opaque: the output addresses are formed here, not kept in registers since the loads */
+    int eo = e; /* the env index again, opaque: the output addresses and the 64-bit global id (the key of the epilogue's random draws) are
+                   formed here, not kept in registers since the loads (the point kernel, at its register cap, spilled the id around the loop) */
     HRL_PIN_VGPR(eo);
+    const long long env = c.env_id_offset + eo;
     x.each([&](int lane) { /* back to the packed record */
         if (lane < 15) L.st[lane] = L.q[qi][lane];
         if (lane >= 16 && lane < 30) {
@@ -2246,12 +2314,16 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             L.red[0] = pot;
         }
         const int t_ep = L.aux[0] + 1;
-        if (c.max_episode_steps > 0 && t_ep >= c.max_episode_steps) done = 1; /* gym TimeLimit (__init__.py:15) */
-        L.scal[0] = rew; L.scal[1] = food; L.scal[2] = dead; L.flags[1] = done;
+        int trunc = 0; /* gym TimeLimit (__init__.py:15): done, and info['TimeLimit.truncated'] = not done */
+        if (c.max_episode_steps > 0 && t_ep >= c.max_episode_steps) { trunc = !done; done = 1; }
+        L.scal[0] = rew; L.scal[1] = food; L.scal[2] = dead; L.flags[1] = done; L.flags[2] = trunc;
         L.red[1] = L.st[29] + rew; L.red[2] = (float)t_ep;
     });
     x.each([&](int lane) { /* each LDS word below is read and written by one lane only */
-        if (lane == 0) { L.aux[0] = L.aux[0] + 1; b.reward[eo] = L.scal[0]; b.done[eo] = (uint8_t)L.flags[1]; }
+        if (lane == 0) {
+            L.aux[0] = L.aux[0] + 1; b.reward[eo] = L.scal[0]; b.done[eo] = (uint8_t)L.flags[1];
+            if (b.truncated) b.truncated[eo] = (uint8_t)L.flags[2];
+        }
         if (lane == 1) L.aux[1] = L.aux[1] + 1;
         if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
@@ -2275,6 +2347,12 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     if constexpr (KIND == 5) { /* ant_flagrun_env.py:110-118: the returned state is calc_state() w.r.t. the NEW goal */
         if (x.uniform(L.flags[3])) compute_obs<KIND>(x, c, env, true);
     }
+    if (done_u && b.final_obs) /* the terminal observation (ant_gather_env.py:96,118-119): a reset below replaces L.obs by the next episode's first */
+        x.each([&](int lane) {
+#pragma unroll 1
+            for (int o = 0; o < c.obs_dim; o += 64)
+                if (o + lane < c.obs_dim) b.final_obs[(size_t)eo * c.obs_dim + (o + lane)] = L.obs[o + lane];
+        });
     if (done_u && c.auto_reset) reset_env<KIND>(x, c, env);
     store_env(x, b, c, eo);
     x.stamp(15);

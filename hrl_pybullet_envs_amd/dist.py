@@ -51,8 +51,12 @@ def all_gather_returns(local, world, out=None, counts=None):
     `shard_range`) makes uneven shards legal: every rank pads to max(counts), the padding is trimmed after the
     collective.  Without `counts` the shards must be equal, which is checked by the shape of `out` only -- so callers
     with uneven shards MUST pass counts (an unequal all_gather_into_tensor hangs on RCCL)."""
-    if world == 1 and not dist.is_initialized():
+    if not dist.is_initialized():
+        if world != 1:
+            raise ValueError(f'all_gather_returns(world={world}) without a process group: call init_distributed() first')
         return local.clone() if out is None else out.copy_(local)
+    if dist.get_world_size() != world:  # a collective sized for another world errors out -- or, on RCCL, hangs when only some ranks call it
+        raise ValueError(f'all_gather_returns(world={world}) but the process group has {dist.get_world_size()} ranks')
     if counts is not None and len(set(counts)) > 1:
         if len(counts) != world or local.numel() != counts[dist.get_rank()]:
             raise ValueError(f'counts {counts} do not describe this rank\'s shard of {local.numel()} values')
@@ -92,9 +96,13 @@ class ReturnGatherer:
         if not isinstance(envs, (list, tuple)):
             envs = [(envs, None)]
         self.parts, self.world = list(envs), world
+        if dist.is_initialized() and dist.get_world_size() != world:
+            raise ValueError(f'ReturnGatherer(world={world}) but the process group has {dist.get_world_size()} ranks')
+        if not dist.is_initialized() and world != 1:
+            raise ValueError(f'ReturnGatherer(world={world}) without a process group: call init_distributed() first')
         dev = self.parts[0][0].device
         n = sum(e.num_envs for e, _ in self.parts)
-        if counts is None and dist.is_initialized() and dist.get_world_size() == world:
+        if counts is None and dist.is_initialized():
             sizes = [None] * world
             dist.all_gather_object(sizes, n)
             counts = [int(c) for c in sizes]

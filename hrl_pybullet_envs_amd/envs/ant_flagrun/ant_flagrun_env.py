@@ -16,11 +16,12 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
     def __init__(self, size=10, tolerance=0.5, max_targets=100, max_target_dist=0, timeout=200, enclosed=True,
                  use_sensor=False, sensor_bins=8, sensor_span=np.pi, sensor_range=4,
                  switch_flag_on_collision=True, manual_goal_creation=False, seed=123, debug=False,
-                 num_envs=1, device='cuda:0'):
+                 num_envs=1, device='cuda:0', goal_capacity=15):
         assert (max_target_dist == 0 and max_targets > 0) or (max_targets <= 0 and max_target_dist > 0), \
             'cannot have both max_targets and max_target_dist set at the same time'  # ant_flagrun_env.py:17-18
         cfg = _lib.default_config(K.HRL_ANT_FLAGRUN, flag_size=float(size), tol=float(tolerance), flag_max_targets=int(max_targets),
                                   flag_manual_goals=int(bool(manual_goal_creation)),
+                                  flag_goal_capacity=int(goal_capacity),  # longest `env.goals` list of a manual env (1..63; 15 fits the default record)
                                   flag_max_target_dist=float(max_target_dist),
                                   flag_timeout=int(timeout), flag_enclosed=int(bool(enclosed)), use_sensor=int(bool(use_sensor)),
                                   n_bins=int(sensor_bins), sensor_span=float(sensor_span), sensor_range=float(sensor_range),
@@ -34,6 +35,7 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
             cfg.centroid_static_sum[0] = 0.0
         self.size, self.tol, self.max_targets, self.timeout, self.enclosed = size, tolerance, max_targets, timeout, enclosed
         self.max_target_dist, self.manual_goal_creation = max_target_dist, manual_goal_creation
+        self.goal_capacity, self._create_calls = int(goal_capacity), 0
         self.switch_flag_on_collision = switch_flag_on_collision
         self.use_sensor, self.n_bins, self.sensor_span, self.sensor_range, self.debug = use_sensor, sensor_bins, sensor_span, sensor_range, debug
         self._finish_init(cfg, num_envs, device, seed)
@@ -53,7 +55,7 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
             return [] if self.num_envs == 1 else (torch.zeros(self.num_envs, 0, 2, device=env.device), torch.zeros(self.num_envs, dtype=torch.int32, device=env.device))
         cur = (env.aux[:, 3] & 0xffff)
         if self._listed():
-            pend = env.items[:, 2:].reshape(self.num_envs, K.HRL_MAX_GOALS, 2)
+            pend = env.items[:, 2:2 + 2 * self.goal_capacity].reshape(self.num_envs, self.goal_capacity, 2)
             if self.num_envs == 1:
                 return [tuple(g) for g in pend[0, :int(cur[0])].tolist()]
             return pend, cur
@@ -72,7 +74,8 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
     @goals.setter
     def goals(self, goals):
         """`env.goals = [...]` of a manual_goal_creation env: stores the list (one for every env: [n, 2]; or [N, n, 2]), at
-        most 15 goals; nothing else changes until next_target() / a goal is reached."""
+        most `goal_capacity` goals (constructor argument of this package, default 15, up to 63); nothing else changes until
+        next_target() / a goal is reached."""
         import torch
         if not self._listed():
             raise AttributeError('env.goals can only be assigned with manual_goal_creation=True and max_targets > 0 '
@@ -82,16 +85,17 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         if g.dim() == 2:
             g = g.unsqueeze(0).expand(self.num_envs, -1, -1)
         n = int(g.shape[1])
-        if g.shape[0] != self.num_envs or g.shape[2] != 2 or n > K.HRL_MAX_GOALS:
-            raise ValueError(f'goals must be [n <= {K.HRL_MAX_GOALS}, 2] or [num_envs, n, 2]')
+        if g.shape[0] != self.num_envs or g.shape[2] != 2 or n > self.goal_capacity:
+            raise ValueError(f'goals must be [n <= goal_capacity = {self.goal_capacity}, 2] or [num_envs, n, 2] (build the env with a larger '
+                             f'goal_capacity, up to {K.HRL_MAX_GOALS})')
         env.items[:, 2:] = 0
         env.items[:, 2:2 + 2 * n] = g.reshape(self.num_envs, 2 * n)
         env.aux[:, 3] = (env.aux[:, 3] & ~0xffff) | n
 
     def next_target(self, mask=None):
-        """`env.next_target()` (ant_flagrun_env.py:112-120): the last goal of the list (or, with max_targets < 1, a goal near
-        the robot) becomes the target; returns calc_state towards it.  One env: IndexError when the list is empty, as in
-        the reference; batched: returns (obs, ok) with ok[i] = 0 for such envs (left unchanged)."""
+        """`env.next_target()` (ant_flagrun_env.py:112-120): the last goal of the list -- the manual one, or the shared list reset() made --
+        (or, with max_targets < 1, a goal near the robot) becomes the target; returns calc_state towards it.  One env: IndexError when the
+        list is empty, as in the reference; batched: returns (obs, ok) with ok[i] = 0 for such envs (left unchanged)."""
         obs, ok = self._backend().next_target(mask)
         if self.num_envs == 1:
             if not bool(ok[0]):
@@ -101,7 +105,7 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
 
     def set_goals(self, goals, mask=None):
         """`env.goals = [...]; env.next_target()` in one call (one kernel launch): goals [n_goals, 2] (one list for every env)
-        or [num_envs, n_goals, 2], at most 15.  As in the reference the list is consumed from its BACK: goals[-1] becomes the
+        or [num_envs, n_goals, 2], at most `goal_capacity`.  As in the reference the list is consumed from its BACK: goals[-1] becomes the
         target now, goals[-2] next, ... (`self.goals.pop()`, :116).  Returns the observation towards the new target."""
         import torch
         if not self._listed():
@@ -115,11 +119,27 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         return obs[0].double().cpu().numpy() if self.num_envs == 1 else obs
 
     def create_targets(self, n):
-        """ant_flagrun_env.py:91-96 refills the list from the shared RandomState; here the shared list is a function of
-        (seed, episode, k) that reset() arms, so only the length the env was built with can be asked for."""
-        if self.manual_goal_creation or n != self.max_targets:
-            raise NotImplementedError('the shared goal list has max_targets goals per episode, armed by reset(); with '
-                                      'manual_goal_creation assign env.goals instead')
+        """ant_flagrun_env.py:91-96: `self.goals = [self.create_target() for _ in range(n)]` from the RandomState all parallel envs share.
+        manual_goal_creation (the documented workflow reset(); create_targets(n); next_target()): n <= goal_capacity goals of the same
+        counter-based stream the kernel draws its shared list from, keyed by (seed, how many times create_targets was called, k) -- every env
+        and every process with the same seed gets the same list, and a later call a fresh one -- stored like `env.goals = [...]`.
+        Otherwise the shared list is a function of (seed, episode, k) that reset() arms with max_targets goals: asking for exactly that is a
+        no-op, any other n cannot be served."""
+        n = int(n)
+        if self._listed():
+            if not 0 <= n <= self.goal_capacity:
+                raise ValueError(f'create_targets({n}): a manual_goal_creation env holds at most goal_capacity = {self.goal_capacity} goals '
+                                 f'(constructor argument of this package, up to {K.HRL_MAX_GOALS})')
+            from ..._philox import flag_goal
+            self._create_calls += 1
+            ks = np.arange(n, 0, -1)  # list index i holds goal number n - i: pop() hands them out in draw order
+            self.goals = flag_goal(self._cfg.seed, self._cfg.flag_size, (1 << 30) | self._create_calls, ks).astype(np.float32).reshape(n, 2)
+            return
+        if self.max_target_dist > 0:
+            return  # max_targets < 1: next_target() never reads the list (:113-114)
+        if n != self.max_targets:
+            raise ValueError(f'create_targets({n}): the shared goal list has max_targets = {self.max_targets} goals per episode, armed by reset(); '
+                             'build the env with another max_targets, or with manual_goal_creation=True to make lists of any length')
 
     @property
     def steps_since_goal_change(self):  # :43,171,192,200

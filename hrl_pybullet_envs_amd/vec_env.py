@@ -6,6 +6,7 @@ All tensors stay resident in HBM.  Layout: include/hrl_envs.h.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _capi as K
@@ -22,22 +23,57 @@ class BatchedEnv:
         L = _lib.lib()
         self.num_envs = cfg.num_envs
         self.obs_dim, self.act_dim = L.hrl_obs_dim(C.byref(cfg)), L.hrl_act_dim(C.byref(cfg))
+        self.items_stride = L.hrl_items_stride(C.byref(cfg))  # 32 unless the config holds more than 16 items / 15 manual goals
         with torch.cuda.device(self.device):
             h = C.c_void_p()
             _lib.check(L.hrl_create(C.byref(cfg), C.byref(h)))
         self._h = h
         n, dev, f32 = self.num_envs, self.device, torch.float32
         self.state = torch.zeros(n, K.HRL_STATE_STRIDE, dtype=f32, device=dev)
-        self.items = torch.zeros(n, K.HRL_ITEMS_STRIDE, dtype=f32, device=dev)
+        self.items = torch.zeros(n, self.items_stride, dtype=f32, device=dev)
         self.aux = torch.zeros(n, K.HRL_AUX_STRIDE, dtype=torch.int32, device=dev)
-        self.obs = torch.zeros(n, self.obs_dim, dtype=f32, device=dev)
-        self.reward = torch.zeros(n, dtype=f32, device=dev)
-        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.info = torch.zeros(n, K.HRL_INFO_STRIDE, dtype=f32, device=dev)
-        self._host = None  # pinned host buffers of step_host(), made on first use
+        # the step's outputs; `final_obs` = the observation of the step that ended an episode (rows of envs that did not finish keep their
+        # last terminal observation) and `truncated` = the step limit alone ended it: what a trainer bootstraps a truncated episode from
+        # (include/hrl_envs.h).  Read them through the properties below: after step_host() they are refreshed from the host buffers first.
+        self._out = {'obs': torch.zeros(n, self.obs_dim, dtype=f32, device=dev), 'reward': torch.zeros(n, dtype=f32, device=dev),
+                     'done': torch.zeros(n, dtype=torch.uint8, device=dev), 'info': torch.zeros(n, K.HRL_INFO_STRIDE, dtype=f32, device=dev),
+                     'final_obs': torch.zeros(n, self.obs_dim, dtype=f32, device=dev), 'truncated': torch.zeros(n, dtype=torch.uint8, device=dev)}
+        self._host = None         # pinned host buffers of step_host(), made on first use
+        self._host_fresh = False  # the last step wrote its outputs to the host buffers: the device tensors are stale until read
+        o = self._out
         self._bufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), None,
-                                   self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
-                                   self.info.data_ptr())
+                                   o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
+                                   o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr())
+
+    def _device_out(self, name):
+        """Output tensor `name` on the device.  step_host() leaves the step's outputs in pinned host memory only (that is its point: one
+        launch, one synchronisation); whoever then reads a device tensor -- ReturnGatherer's snapshot of info[:, 2], code that mixes step()
+        and step_host() -- gets the host values copied over first, once, instead of silently stale ones."""
+        if self._host_fresh:
+            self._host_fresh = False
+            h = self._host
+            for k, hk in (('obs', 'obs'), ('reward', 'rew'), ('done', 'done'), ('info', 'info')):
+                self._out[k].copy_(h[hk], non_blocking=True)
+            # final_obs: the kernel writes rows only where an episode ended; the rows that ended in any host step since the last refresh
+            if self._host_ended.any():
+                d = torch.from_numpy(self._host_ended)
+                self._out['final_obs'][d.to(self.device)] = h['final_obs'][d].to(self.device)
+                self._host_ended[:] = False
+            self._out['truncated'].copy_(h['trunc'], non_blocking=True)
+        return self._out[name]
+
+    def _before_device_launch(self):
+        """A launch that writes the device output tensors comes after a step_host(): bring the host outputs over first (they would
+        otherwise be copied over the NEW device values at the next read)."""
+        if self._host_fresh:
+            self._device_out('obs')
+
+    obs = property(lambda self: self._device_out('obs'))
+    reward = property(lambda self: self._device_out('reward'))
+    done = property(lambda self: self._device_out('done'))
+    info = property(lambda self: self._device_out('info'))
+    final_obs = property(lambda self: self._device_out('final_obs'))
+    truncated = property(lambda self: self._device_out('truncated'))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -57,6 +93,7 @@ class BatchedEnv:
         m = None
         if mask is not None:
             m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._before_device_launch()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hrl_reset(self._h, C.byref(self._bufs), None if m is None else m.data_ptr(),
                                             self._stream()))
@@ -69,11 +106,15 @@ class BatchedEnv:
                 or tuple(actions.shape) != (self.num_envs, self.act_dim):
             actions = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, self.act_dim).contiguous()
         self._bufs.actions = actions.data_ptr()
+        self._before_device_launch()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hrl_step(self._h, C.byref(self._bufs), self._stream()))
         self._last_actions = actions  # keep alive until the stream has consumed it
         info = {'food_rew': self.info[:, 0], 'dead_rew': self.info[:, 1], 'episode_return': self.info[:, 2],
-                'episode_length': self.info[:, 3]}
+                'episode_length': self.info[:, 3],
+                # valid where done: the terminal observation (the returned obs of such an env is already the next episode's first
+                # when auto_reset is on) and gym's TimeLimit flag
+                'final_observation': self.final_obs, 'TimeLimit.truncated': self.truncated}
         return self.obs, self.reward, self.done, info
 
     def step_host(self, actions):
@@ -81,25 +122,36 @@ class BatchedEnv:
         (README.md:24-34), for the one-env classes: the action is written into pinned host memory that the kernel reads
         directly, and observations / reward / done / info land in pinned host memory the kernel writes directly, so a step is
         one launch and one stream synchronisation -- no staging copies, no packing kernel.  The simulation state stays in HBM.
-        Returns numpy views (obs [N, obs_dim], reward [N], done [N] uint8, info [N, 4]) that the next call overwrites; the
-        device tensors `obs` / `reward` / `done` / `info` are NOT updated by this path."""
+        Returns numpy views (obs [N, obs_dim], reward [N], done [N] uint8, info [N, 4]) that the next call overwrites (the terminal
+        observation / truncation flag of this path: `host_final_obs()`); the device tensors `obs` / `reward` / `done` / `info` are
+        refreshed from these host buffers when they are next read (`_device_out`), not by this call."""
         if self._host is None:
             f32 = torch.float32
             t = {'act': torch.zeros(self.num_envs, self.act_dim, dtype=f32).pin_memory(),
                  'obs': torch.zeros(self.num_envs, self.obs_dim, dtype=f32).pin_memory(),
                  'rew': torch.zeros(self.num_envs, dtype=f32).pin_memory(),
                  'done': torch.zeros(self.num_envs, dtype=torch.uint8).pin_memory(),
-                 'info': torch.zeros(self.num_envs, K.HRL_INFO_STRIDE, dtype=f32).pin_memory()}
+                 'info': torch.zeros(self.num_envs, K.HRL_INFO_STRIDE, dtype=f32).pin_memory(),
+                 'final_obs': torch.zeros(self.num_envs, self.obs_dim, dtype=f32).pin_memory(),
+                 'trunc': torch.zeros(self.num_envs, dtype=torch.uint8).pin_memory()}
             self._host = t
             self._host_np = {k: v.numpy() for k, v in t.items()}
+            self._host_ended = np.zeros(self.num_envs, bool)  # envs whose episode ended in a host step since the device tensors were refreshed
             self._hbufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), t['act'].data_ptr(),
-                                        t['obs'].data_ptr(), t['rew'].data_ptr(), t['done'].data_ptr(), t['info'].data_ptr())
+                                        t['obs'].data_ptr(), t['rew'].data_ptr(), t['done'].data_ptr(), t['info'].data_ptr(),
+                                        t['final_obs'].data_ptr(), t['trunc'].data_ptr())
         h = self._host_np
         h['act'][...] = actions
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hrl_step(self._h, C.byref(self._hbufs), self._stream()))
             torch.cuda.current_stream(self.device).synchronize()
+        self._host_fresh = True
+        self._host_ended |= h['done'] != 0
         return h['obs'], h['rew'], h['done'], h['info']
+
+    def host_final_obs(self):
+        """(final_obs [N, obs_dim], truncated [N] uint8) numpy views of the last step_host(): valid where its `done` was set."""
+        return self._host_np['final_obs'], self._host_np['trunc']
 
     def set_goals(self, goals, mask=None):
         """AntFlagrun with flag_manual_goals: goals float32 [N, n_goals, 2] on this device (include/hrl_envs.h: hrl_set_goals)."""
@@ -107,6 +159,7 @@ class BatchedEnv:
         if goals.dim() != 3 or goals.shape[0] != self.num_envs or goals.shape[2] != 2:
             raise ValueError(f'goals must be [num_envs={self.num_envs}, n_goals, 2], got {tuple(goals.shape)}')
         m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._before_device_launch()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hrl_set_goals(self._h, C.byref(self._bufs), goals.data_ptr(), int(goals.shape[1]),
                                                 None if m is None else m.data_ptr(), self._stream()))
@@ -118,6 +171,7 @@ class BatchedEnv:
         Returns (obs, ok): ok[i] == 0 where the reference raises IndexError (empty list; that env is unchanged)."""
         m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
         ok = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
+        self._before_device_launch()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hrl_next_target(self._h, C.byref(self._bufs), None if m is None else m.data_ptr(), ok.data_ptr(), self._stream()))
         return self.obs, ok

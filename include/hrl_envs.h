@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HRL_ABI_VERSION 5
+#define HRL_ABI_VERSION 6
 
 /* env kinds */
 #define HRL_ANT_FLAT 0     /* AntMjEnv: flat ground, obs 29 (envs/MjAnt.py:31-97)                        */
@@ -46,13 +46,15 @@ extern "C" {
 #define HRL_EPRET_OFF 29
 #define HRL_INITZ_OFF 30
 #define HRL_POTENTIAL_OFF 31
-#define HRL_ITEMS_STRIDE 32 /* 16 items x (x,y): food slots first, then poison slots (n_food + n_poison <= HRL_MAX_ITEMS; the reference's defaults: 8 + 8) */
-#define HRL_MAX_ITEMS 16
-#define HRL_MAX_BINS 16
+#define HRL_ITEMS_STRIDE 32 /* items record of the default configs: 16 items x (x,y), food slots first, then poison slots (the reference's
+                               defaults: 8 + 8).  A config with more items (or a longer manual goal list) has a longer record: hrl_items_stride() */
+#define HRL_MAX_ITEMS 64    /* n_food + n_poison (ant_gather_env.py:16-17 takes any counts; an item is a lane of the wave here) */
+#define HRL_MAX_BINS 64     /* n_bins / sensor_bins */
+#define HRL_MAX_OBS 256     /* widest observation: AntMazeMj with 64 bins = 29 + 3 * 64 + 1 = 222 */
 #define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
 #define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
-#define HRL_MAX_TARGETS 8
-#define HRL_MAX_GOALS 15    /* flagrun manual goals per hrl_set_goals call: items[0..1] current, items[2..31] the pending list in list order */
+#define HRL_MAX_TARGETS 64  /* maze kinds: `targets` of the constructor (ant_maze_bullet_env.py:23) */
+#define HRL_MAX_GOALS 63    /* flagrun manual goals (flag_goal_capacity): items[0..1] current, items[2..] the pending list in list order */
 
 /* status codes */
 #define HRL_OK 0
@@ -137,19 +139,30 @@ typedef struct hrl_config {
      * pops the list when flag_max_targets > 0 and draws a goal near the robot (ignoring the list) when flag_max_targets < 1
      * (flag_max_target_dist > 0), :113-116; the constructor's either-or rule (:17-18) holds for manual envs too. */
     int32_t flag_manual_goals;
+    /* manual_goal_creation: the longest list `env.goals = [...]` / hrl_set_goals() may hold, 1..HRL_MAX_GOALS (default 15: the
+     * pending list then fits the default 32-float items record; a larger capacity lengthens the record, hrl_items_stride()). */
+    int32_t flag_goal_capacity;
     hrl_model model;
 } hrl_config;
 
 /* Caller-owned buffers of one shard.  Unused pointers may be NULL (items for non-gather kinds). */
 typedef struct hrl_buffers {
     float *state;         /* [N][HRL_STATE_STRIDE]  in/out */
-    float *items;         /* [N][HRL_ITEMS_STRIDE]  in/out (gather kinds) */
+    float *items;         /* [N][hrl_items_stride()] in/out (gather kinds; flagrun with max_target_dist or manual goals) */
     int32_t *aux;         /* [N][HRL_AUX_STRIDE]    in/out */
     const float *actions; /* [N][act_dim]           in  (step only) */
     float *obs;           /* [N][obs_dim]           out */
     float *reward;        /* [N]                    out (step only) */
     uint8_t *done;        /* [N]                    out (step only) */
     float *info;          /* [N][HRL_INFO_STRIDE]   out (step only) */
+    /* The observation of the step that ENDED an episode (ant_gather_env.py:96,118-119, ant_maze_bullet_env.py:82,97: step() returns the
+     * state of the terminal step).  With auto_reset the env is reset inside hrl_step and `obs` then holds the first observation of the NEXT
+     * episode; the terminal one -- what a trainer bootstraps the value of a truncated episode from -- is written here.  Rows of envs that
+     * did not finish in this step are left untouched.  Written whenever done[i] != 0, with or without auto_reset.  May be NULL. */
+    float *final_obs;     /* [N][obs_dim]           out (step only, optional) */
+    /* gym TimeLimit (`max_episode_steps=2000`, hrl_pybullet_envs/__init__.py:15): 1 when the episode was ended by the step limit ALONE
+     * (gym.wrappers.TimeLimit: info['TimeLimit.truncated'] = not done), else 0; written for every env in every step.  May be NULL. */
+    uint8_t *truncated;   /* [N]                    out (step only, optional) */
 } hrl_buffers;
 
 typedef struct hrl_handle hrl_handle;
@@ -162,6 +175,9 @@ int hrl_default_config(int32_t env_kind, hrl_config *cfg);
  * ant_maze_bullet_env.py:54-57, MjAnt.py:15, point_bot.py:15-16). */
 int hrl_obs_dim(const hrl_config *cfg);
 int hrl_act_dim(const hrl_config *cfg);
+/* floats per env of the `items` buffer: HRL_ITEMS_STRIDE (32) for up to 16 items / 15 manual goals -- every default config --, else the
+ * next multiple of 32 that holds 2 * (n_food + n_poison) (gather_scene.py:33) or 2 * (1 + flag_goal_capacity) floats; at most 128. */
+int hrl_items_stride(const hrl_config *cfg);
 
 /* Replaces env construction (gym.make / Env.__init__ + first BulletClient): validates and copies cfg. */
 int hrl_create(const hrl_config *cfg, hrl_handle **out);
@@ -186,16 +202,17 @@ int hrl_set_state(hrl_handle *h, const hrl_buffers *bufs, const float *qpos, con
  * (ant_flagrun_env.py:45,112-120): goals_xy[N][n_goals][2] (device) is every env's list.  As in the reference next_target()
  * is `self.goals.pop()`: the LAST goal of the list becomes the current target at once (set_target + calc_state: bufs->obs is
  * refreshed, the potential is left as it is, :119), the others follow from the back of the list to its front as goals are
- * reached or time out; the episode ends when they run out (IndexError, :193-194).  1 <= n_goals <= HRL_MAX_GOALS.
+ * reached or time out; the episode ends when they run out (IndexError, :193-194).  1 <= n_goals <= flag_goal_capacity.
  * Envs with mask[i] == 0 are left alone (mask == NULL: all).  Rejected when flag_max_targets < 1: next_target() then draws
  * goals near the robot and never reads the list (:113-114). */
 int hrl_set_goals(hrl_handle *h, const hrl_buffers *bufs, const float *goals_xy, int32_t n_goals, const uint8_t *mask, void *stream);
 
-/* `env.next_target()` alone (ant_flagrun_env.py:112-120) of a manual_goal_creation env: pops the last pending goal, or with
- * flag_max_targets < 1 draws a goal near the robot (create_close_target, :80-89); clears _rewarded, refreshes bufs->obs.
+/* `env.next_target()` alone (ant_flagrun_env.py:112-120): pops the last pending goal of a manual_goal_creation env, or the next goal of the
+ * shared list reset() made (:150-153), or with flag_max_targets < 1 draws a goal near the robot (create_close_target, :80-89); clears
+ * _rewarded, refreshes bufs->obs.
  * ok (device, [N], may be NULL): 1, or 0 for an env whose list is empty -- the reference raises IndexError there; such an
  * env is left unchanged.  (The pending list itself is plain data in the caller's `items` / `aux` tensors: `env.goals = [...]`
- * without next_target() is items[2 + 2k..] = goals[k], aux[3] low 16 bits = len(goals).) */
+ * without next_target() is items[2 + 2k..] = goals[k], aux[3] low 16 bits = len(goals) <= flag_goal_capacity.) */
 int hrl_next_target(hrl_handle *h, const hrl_buffers *bufs, const uint8_t *mask, uint8_t *ok, void *stream);
 
 /* Last error text of the calling thread ("" if none). */

@@ -407,7 +407,7 @@ int FN(orc_gather_task_src)(const hrl_config *cfg, int ant, const REAL *base_sta
     if (!(cfg->robot_coll_dist > 0)) { /* :113-116: one reward_collision() per contact point, in contact order: an item touched
                                          * by k contact points pays k times and is moved k times (gather_scene.py:95-114 does
                                          * not look at where the item is).  Move m of item i draws from the source under the
-                                         * key i | m << 4; every move is independent of the previous one, so where the item ends
+                                         * key i | m << 4 (m << 6 with more than 16 items); every move is independent of the previous one, so where the item ends
                                          * up is its LAST move (what the device computes directly). */
         int hits[HRL_MAX_ITEMS] = {0};
         for (int c = 0; c < n_contacts; ++c) {
@@ -415,7 +415,7 @@ int FN(orc_gather_task_src)(const hrl_config *cfg, int ant, const REAL *base_sta
             if (i < 0 || i >= n) continue; /* not an item: reward_collision returns 0 */
             food_reward += (i < nf) ? 1 : -1;
             if (cfg->respawn) {
-                int k = FN(random_on_plane_src)(ws, torso_xyz, R_(cfg->robot_object_spacing), draw, ctx, i | (hits[i] << 4), max_attempts, items_xy + 2 * i);
+                int k = FN(random_on_plane_src)(ws, torso_xyz, R_(cfg->robot_object_spacing), draw, ctx, i | (hits[i] << (n > 16 ? 6 : 4)), max_attempts, items_xy + 2 * i);
                 if (k < 0) return -1;
                 used += k;
             } else { items_xy[2 * i] = 100; items_xy[2 * i + 1] = 0; }
@@ -922,6 +922,9 @@ typedef struct FN(orc_contact) { int level, leg, level2, leg2, sphere, surface; 
 
 #define ORC_SURF_BOX 8
 #define ORC_SURF_ITEM 16
+/* code of item cube i: ORC_SURF_ITEM + i for the first 48 items, the items beyond (configs with more than 48 items) behind the 48 capsule-pair codes */
+#define ORC_SURF_OF_ITEM(i) ((i) + ((i) < 48 ? ORC_SURF_ITEM : ORC_SURF_SELF))
+#define ORC_ITEM_OF_SURF(s) ((s) >= ORC_SURF_ITEM && (s) < ORC_SURF_SELF ? (s) - ORC_SURF_ITEM : ((s) >= ORC_SURF_SELF + 48 && (s) < ORC_SURF_SELF + HRL_MAX_ITEMS ? (s) - ORC_SURF_SELF : -1))
 #define ORC_SURF_SELF 64
 #define ORC_ITEM_HALF R_(0.125) /* assets/food.xml:12,19: box size 0.25 */
 #define ORC_ITEM_Z R_(0.1)      /* gather_scene.py:62 */
@@ -1000,7 +1003,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                 REAL lo[3], hi[3];
                 if (items_xy[2 * k] != items_xy[2 * k] || items_xy[2 * k + 1] != items_xy[2 * k + 1]) continue; /* a cube at a NaN place is nowhere (a clamp between NaN bounds would put it everywhere) */
                 FN(item_box)(items_xy + 2 * k, lo, hi);
-                dist = FN(sphere_vs_box)(p, rad, lo, hi, n); surface = ORC_SURF_ITEM + k;
+                dist = FN(sphere_vs_box)(p, rad, lo, hi, n); surface = ORC_SURF_OF_ITEM(k);
             }
             if (dist < K->cdist) {
                 if (f == 0) ground_touch[s] = 1;
@@ -1154,7 +1157,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
                 const REAL *ixy0 = items_xy + 2 * (f - 1 - W->n_planes);
                 if (ixy0[0] != ixy0[0] || ixy0[1] != ixy0[1]) continue; /* a cube at a NaN place is nowhere */
                 FN(item_box)(ixy0, lo, hi);
-                dist = FN(sphere_vs_box)(p, 0, lo, hi, n); surface = ORC_SURF_ITEM + (f - 1 - W->n_planes);
+                dist = FN(sphere_vs_box)(p, 0, lo, hi, n); surface = ORC_SURF_OF_ITEM(f - 1 - W->n_planes);
             }
             if (dist < K->cdist) {
                 ++ncand;
@@ -1184,7 +1187,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
                 ++ncand;
                 if (nc < MAXC) {
                     for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
-                    cd[nc] = dist; csurf[nc] = ORC_SURF_ITEM + f; ++nc;
+                    cd[nc] = dist; csurf[nc] = ORC_SURF_OF_ITEM(f); ++nc;
                 }
             }
         }
@@ -1455,16 +1458,16 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     }
     if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) { /* gather_scene.py:38-50 */
         REAL origin[2] = {0, 0};
-        for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+        for (int i = 0; i < orc_items_stride(cfg); ++i) items[i] = 0;
         for (int i = 0; i < cfg->n_food + cfg->n_poison; ++i) FN(respawn_item)(cfg, env, ep, 1, i, origin, items + 2 * i);
     }
     aux[0] = 0; aux[2] = (int32_t)(ep + 1); /* NB: the flagrun goal stream is keyed by the NEW episode index */
     if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_manual_goals) { /* the walk target survives the reset (:149-152), pending goals do not */
-        for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+        for (int i = 0; i < orc_items_stride(cfg); ++i) items[i] = 0;
         items[0] = prev_target[0]; items[1] = prev_target[1];
     } else if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_max_target_dist > 0) { /* reset -> next_target -> create_close_target (:153, :111-112) */
         REAL g2[2];
-        for (int i = 0; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+        for (int i = 0; i < orc_items_stride(cfg); ++i) items[i] = 0;
         FN(flag_close_goal)(cfg, env, ep + 1, 1, st, g2);
         items[0] = g2[0]; items[1] = g2[1];
     }
@@ -1481,9 +1484,9 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
 
 /* `env.goals = [...]` of a manual_goal_creation flagrun env (ant_flagrun_env.py:45,96,150): the pending list, in list order,
  * behind the current goal in the items record (items[2 + 2k..] = goals[k]); its length in the low 16 bits of aux[3]. */
-void FN(orc_flag_goals_assign)(REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals) {
+void FN(orc_flag_goals_assign)(const hrl_config *cfg, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals) {
     for (int k = 0; k < n_goals; ++k) { items[2 + 2 * k] = goals_xy[2 * k]; items[3 + 2 * k] = goals_xy[2 * k + 1]; }
-    for (int i = 2 + 2 * n_goals; i < HRL_ITEMS_STRIDE; ++i) items[i] = 0;
+    for (int i = 2 + 2 * n_goals; i < orc_items_stride(cfg); ++i) items[i] = 0;
     aux[3] = (int32_t)(((uint32_t)n_goals & 0xffffu) | ((uint32_t)aux[3] & 0xffff0000u));
 }
 
@@ -1499,6 +1502,9 @@ int FN(orc_flag_next_target)(const hrl_config *cfg, int64_t env, const REAL *st,
         cur = (cur + 1) & 0xffffu;
         FN(flag_close_goal)(cfg, env, (uint32_t)aux[2], cur, st, g2);
         items[0] = g2[0]; items[1] = g2[1];
+    } else if (!cfg->flag_manual_goals) { /* the shared list reset() made (:91-96,150-153): `cur` of its max_targets goals are used up */
+        if (cur >= (uint32_t)cfg->flag_max_targets) return 0; /* goals.pop() on an empty list */
+        cur += 1;
     } else {
         if (cur == 0) return 0;
         cur -= 1;
@@ -1511,7 +1517,7 @@ int FN(orc_flag_next_target)(const hrl_config *cfg, int64_t env, const REAL *st,
 /* hrl_set_goals() of include/hrl_envs.h: `env.goals = [...]; env.next_target()`; the returned state is calc_state() towards
  * the new goal (:120). */
 void FN(orc_env_set_goals_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals, REAL *obs) {
-    FN(orc_flag_goals_assign)(items, aux, goals_xy, n_goals);
+    FN(orc_flag_goals_assign)(&E->cfg, items, aux, goals_xy, n_goals);
     FN(orc_flag_next_target)(&E->cfg, env, st, items, aux);
     REAL feet[4] = {0, 0, 0, 0};
     FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0);
@@ -1526,7 +1532,7 @@ void FN(orc_env_next_target_one)(const FN(orc_env) * E, int64_t env, REAL *st, R
 
 /* One env step on the packed record.  Mirrors hrl_step() of include/hrl_envs.h. */
 void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, const REAL *act,
-                          REAL *obs, REAL *rew_out, uint8_t *done_out, REAL *info) {
+                          REAL *obs, REAL *rew_out, uint8_t *done_out, REAL *info, REAL *final_obs, uint8_t *truncated) {
     const hrl_config *cfg = &E->cfg;
     const FN(orc_consts) *K = &E->K;
     REAL q[15], u[14], feet[4] = {0, 0, 0, 0};
@@ -1562,7 +1568,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
                    FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, base, &nlim, &wtd, rpy, 0); }
         else { FN(orc_quat_to_rpy)(st + 3, rpy); FN(orc_pointbot_state)(st, rpy, st + HRL_QVEL_OFF, tgt, 1, base); }
         /* getContactPoints after stepSimulation = the contacts of the step's last collision pass (:114) */
-        for (int c = 0; c < dbg.n_contacts; ++c) contact_items[c] = dbg.surface[c] >= ORC_SURF_ITEM && dbg.surface[c] < ORC_SURF_ITEM + HRL_MAX_ITEMS ? dbg.surface[c] - ORC_SURF_ITEM : -1;
+        for (int c = 0; c < dbg.n_contacts; ++c) contact_items[c] = ORC_ITEM_OF_SURF(dbg.surface[c]);
         FN(orc_philox_src) src = {cfg, env, t_life, 0};
         FN(orc_gather_task_src)(cfg, ant, base, ant ? 28 : 8, st, rpy[2], st[HRL_INITZ_OFF], ant ? R_(0.26) : R_(-1), items, FN(orc_draw_philox), &src, 64,
                                 contact_items, dbg.n_contacts, obs, &rew, &done, &food_rew, &dead_rew);
@@ -1618,10 +1624,15 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         FN(orc_maze_task)(cfg, s28, inner, idone, st, rpy[2], tgt, wtd, aux[0] + 1, &FN(maze_lines)[0][0], 7, 3, obs, &rew, &done);
     }
     aux[0] += 1; aux[1] += 1;
-    if (cfg->max_episode_steps > 0 && aux[0] >= cfg->max_episode_steps) done = 1; /* gym TimeLimit, __init__.py:15 */
+    int trunc = 0; /* gym TimeLimit, __init__.py:15 (gym.wrappers.TimeLimit: info['TimeLimit.truncated'] = not done; done = True) */
+    if (cfg->max_episode_steps > 0 && aux[0] >= cfg->max_episode_steps) { trunc = !done; done = 1; }
     st[HRL_EPRET_OFF] += rew;
     *rew_out = rew; *done_out = (uint8_t)done;
+    if (truncated) *truncated = (uint8_t)trunc;
     info[0] = food_rew; info[1] = dead_rew; info[2] = st[HRL_EPRET_OFF]; info[3] = R_(aux[0]);
+    /* what step() returns in the reference is the state of THIS step (ant_gather_env.py:96,118-119, ant_maze_bullet_env.py:82,97): kept in
+     * final_obs when the episode ends, because the in-place reset below overwrites obs with the next episode's first observation */
+    if (done && final_obs) { const int od = orc_obs_dim(cfg); for (int i = 0; i < od; ++i) final_obs[i] = obs[i]; }
     if (done && cfg->auto_reset) FN(orc_env_reset_one)(E, env, st, items, aux, obs);
 }
 
@@ -1634,19 +1645,24 @@ void FN(orc_reset_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_
     for (int i = 0; i < cfg->num_envs; ++i) {
         if (mask && !mask[i]) continue;
         FN(orc_env_reset_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE,
-                              items ? items + (size_t)i * HRL_ITEMS_STRIDE : 0, aux + (size_t)i * HRL_AUX_STRIDE, obs + (size_t)i * od);
+                              items ? items + (size_t)i * orc_items_stride(cfg) : 0, aux + (size_t)i * HRL_AUX_STRIDE, obs + (size_t)i * od);
     }
 }
-void FN(orc_step_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
-                        REAL *reward, uint8_t *done, REAL *info) {
+void FN(orc_step_batch_v6)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
+                           REAL *reward, uint8_t *done, REAL *info, REAL *final_obs, uint8_t *truncated) {
     FN(orc_env) E;
     FN(orc_env_init)(cfg, &E);
     int od = orc_obs_dim(cfg), ad = orc_act_dim(cfg);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < cfg->num_envs; ++i)
         FN(orc_env_step_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE,
-                             items ? items + (size_t)i * HRL_ITEMS_STRIDE : 0, aux + (size_t)i * HRL_AUX_STRIDE,
-                             actions + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, info + (size_t)i * HRL_INFO_STRIDE);
+                             items ? items + (size_t)i * orc_items_stride(cfg) : 0, aux + (size_t)i * HRL_AUX_STRIDE,
+                             actions + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, info + (size_t)i * HRL_INFO_STRIDE,
+                             final_obs ? final_obs + (size_t)i * od : 0, truncated ? truncated + i : 0);
+}
+void FN(orc_step_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
+                        REAL *reward, uint8_t *done, REAL *info) {
+    FN(orc_step_batch_v6)(cfg, state, items, aux, actions, obs, reward, done, info, 0, 0);
 }
 
 void FN(orc_set_goals_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals, const uint8_t *mask, REAL *obs) {
@@ -1655,7 +1671,7 @@ void FN(orc_set_goals_batch)(const hrl_config *cfg, REAL *state, REAL *items, in
     int od = orc_obs_dim(cfg);
     for (int i = 0; i < cfg->num_envs; ++i) {
         if (mask && !mask[i]) continue;
-        FN(orc_env_set_goals_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * HRL_ITEMS_STRIDE, aux + (size_t)i * HRL_AUX_STRIDE,
+        FN(orc_env_set_goals_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * orc_items_stride(cfg), aux + (size_t)i * HRL_AUX_STRIDE,
                                   goals_xy + (size_t)i * n_goals * 2, n_goals, obs + (size_t)i * od);
     }
 }
@@ -1665,7 +1681,7 @@ void FN(orc_next_target_batch)(const hrl_config *cfg, REAL *state, REAL *items, 
     int od = orc_obs_dim(cfg);
     for (int i = 0; i < cfg->num_envs; ++i) {
         if (mask && !mask[i]) continue;
-        FN(orc_env_next_target_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * HRL_ITEMS_STRIDE, aux + (size_t)i * HRL_AUX_STRIDE,
+        FN(orc_env_next_target_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE, items + (size_t)i * orc_items_stride(cfg), aux + (size_t)i * HRL_AUX_STRIDE,
                                     obs + (size_t)i * od, ok ? ok + i : 0);
     }
 }
@@ -1674,7 +1690,7 @@ void FN(orc_next_target_batch)(const hrl_config *cfg, REAL *state, REAL *items, 
  * 64-bit LCG, on `threads` OpenMP threads.  Returns wall seconds of the stepping loop; *checksum guards against DCE. */
 double FN(orc_bench)(const hrl_config *cfg, int steps, int threads, double *checksum) {
     int n = cfg->num_envs, od = orc_obs_dim(cfg), ad = orc_act_dim(cfg);
-    REAL *state = calloc((size_t)n * HRL_STATE_STRIDE, sizeof(REAL)), *items = calloc((size_t)n * HRL_ITEMS_STRIDE, sizeof(REAL));
+    REAL *state = calloc((size_t)n * HRL_STATE_STRIDE, sizeof(REAL)), *items = calloc((size_t)n * orc_items_stride(cfg), sizeof(REAL));
     REAL *obs = calloc((size_t)n * od, sizeof(REAL)), *rew = calloc(n, sizeof(REAL)), *info = calloc((size_t)n * HRL_INFO_STRIDE, sizeof(REAL));
     REAL *act = calloc((size_t)n * ad, sizeof(REAL));
     int32_t *aux = calloc((size_t)n * HRL_AUX_STRIDE, sizeof(int32_t));
@@ -1775,7 +1791,7 @@ void FN(orc_point_substeps_items)(const hrl_config *cfg, REAL *q, REAL *u, const
     for (int s = 0; s < n; ++s) FN(orc_point_substep)(&E.K, &E.W, q, u, force, items_xy, n_items, &dbg);
     if (info3) {
         info3[0] = dbg.n_rows; info3[1] = 0; info3[2] = dbg.n_contacts;
-        for (int c = 0; c < dbg.n_contacts; ++c) info3[1] += dbg.surface[c] >= ORC_SURF_ITEM;
+        for (int c = 0; c < dbg.n_contacts; ++c) info3[1] += ORC_ITEM_OF_SURF(dbg.surface[c]) >= 0;
     }
 }
 

@@ -99,6 +99,7 @@ static DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
     DevBufs d;
     d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
     d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask; d.stamps = nullptr;
+    d.final_obs = b->final_obs; d.truncated = b->truncated;
     return d;
 }
 
@@ -106,6 +107,7 @@ extern "C" {
 int emu_default_config(int32_t kind, hrl_config *c) { return default_config(kind, c); }
 int emu_obs_dim(const hrl_config *c) { return obs_dim(c); }
 int emu_act_dim(const hrl_config *c) { return act_dim(c); }
+int emu_items_stride(const hrl_config *c) { return items_stride(c); }
 const char *emu_validate(const hrl_config *c) { static std::string s; s = validate(c); return s.c_str(); }
 int emu_reset(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, int reverse) {
     if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
@@ -137,7 +139,7 @@ int emu_step_group(const hrl_config *cfg, const hrl_buffers *b, int reverse, int
 }
 int emu_step(const hrl_config *cfg, const hrl_buffers *b, int reverse) { return emu_step_group(cfg, b, reverse, 4); }
 int emu_set_goals(const hrl_config *cfg, const hrl_buffers *b, const float *goals_xy, int n_goals, const uint8_t *mask, int reverse) {
-    if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN || !cfg->flag_manual_goals || n_goals < 1 || n_goals > HRL_MAX_GOALS) return HRL_ERR_BAD_ARG;
+    if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN || !cfg->flag_manual_goals || n_goals < 1 || n_goals > cfg->flag_goal_capacity) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, mask);
     if (cfg->flag_max_target_dist > 0.f) return HRL_ERR_BAD_ARG;
@@ -145,7 +147,7 @@ int emu_set_goals(const hrl_config *cfg, const hrl_buffers *b, const float *goal
     return HRL_OK;
 }
 int emu_next_target(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, uint8_t *ok, int reverse) {
-    if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN || !cfg->flag_manual_goals) return HRL_ERR_BAD_ARG;
+    if (!validate(cfg).empty() || cfg->env_kind != HRL_ANT_FLAGRUN) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, mask);
     for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; set_goals_entry(x, d, c, e, nullptr, 0, ok); }

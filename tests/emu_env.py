@@ -34,17 +34,19 @@ class EmuEnv:
         self.N, self.od, self.ad = n, L.emu_obs_dim(C.byref(cfg)), L.emu_act_dim(C.byref(cfg))
         f = np.float32
         self.state = np.zeros((n, K.HRL_STATE_STRIDE), f)
-        self.items = np.zeros((n, K.HRL_ITEMS_STRIDE), f)
+        self.items = np.zeros((n, L.emu_items_stride(C.byref(cfg))), f)
         self.aux = np.zeros((n, K.HRL_AUX_STRIDE), np.int32)
         self.obs = np.zeros((n, self.od), f)
         self.rew = np.zeros(n, f)
         self.done = np.zeros(n, np.uint8)
         self.info = np.zeros((n, K.HRL_INFO_STRIDE), f)
         self.act = np.zeros((n, self.ad), f)
+        self.final_obs = np.zeros((n, self.od), f)
+        self.truncated = np.zeros(n, np.uint8)
 
     def _bufs(self):
         return K.hrl_buffers(ptr(self.state), ptr(self.items), ptr(self.aux), ptr(self.act), ptr(self.obs),
-                             ptr(self.rew), ptr(self.done), ptr(self.info))
+                             ptr(self.rew), ptr(self.done), ptr(self.info), ptr(self.final_obs), ptr(self.truncated))
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

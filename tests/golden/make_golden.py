@@ -328,10 +328,11 @@ def main():
                          scene_run(5, (9, 11), 4, 6, 3.0, True, [(0, (0, 0, .5)), (4, (2, 2, .5)), (9, (-3, 1, .5))])]
 
     # ---------------------------------------------------------------- AntGather / Gather(Point) full step (task half)
-    def gather_step_case(cls, k, force=None):
+    def gather_step_case(cls, k, force=None, n_food=8, n_poison=8, n_bins=None):
         lrs = np.random.RandomState(5000 + k)
-        n_bins = 10 if cls is AntGatherBulletEnv else 5
-        sc = GatherScene(None, 9.8, 0.0165 / 4, 4, (15, 15), 8, 8, 2.0, True)
+        if n_bins is None:
+            n_bins = 10 if cls is AntGatherBulletEnv else 5
+        sc = GatherScene(None, 9.8, 0.0165 / 4, 4, (15, 15), n_food, n_poison, 2.0, True)
         sc.rs = LoggingRS(6000 + k)
         sc.loaded = True
         cl = FakeClient()
@@ -344,7 +345,7 @@ def main():
         if force == 'far':
             xy = np.array([0.0, 0.0])
         else:
-            tgt = sc.all_items[ids[lrs.randint(0, 16)]]
+            tgt = sc.all_items[ids[lrs.randint(0, n_food + n_poison)]]
             xy = np.array(tgt[:2]) + lrs.uniform(-0.9, 0.9, 2)
         z = 0.2 if force == 'dead' else lrs.uniform(0.3, 0.9)
         rpy = [lrs.uniform(-.3, .3), lrs.uniform(-.3, .3), lrs.uniform(-np.pi, np.pi)]
@@ -391,13 +392,14 @@ def main():
     G['gather_step'] = gs
 
     # ---------------------------------------------------------------- maze: target obs + full step (task half)
-    def maze_case(k, encoding, sense_target=False, force_target=None, near=False):
+    def maze_case(k, encoding, sense_target=False, force_target=None, near=False, n_bins=10, targets=None):
         lrs = np.random.RandomState(7000 + k)
         xy = np.array([lrs.uniform(-4.5, 4.5), lrs.uniform(-8.5, 8.5)])
         rpy = [lrs.uniform(-.2, .2), lrs.uniform(-.2, .2), lrs.uniform(-np.pi, np.pi)]
         body = Body([xy[0], xy[1], 0.45], rpy)
-        targets = ([2, -3], [2, 0], [2, 3], [-2, 4])
-        target = np.array(targets[lrs.randint(0, 4)] if force_target is None else force_target)
+        if targets is None:
+            targets = ([2, -3], [2, 0], [2, 3], [-2, 4])
+        target = np.array(targets[lrs.randint(0, len(targets))] if force_target is None else force_target)
         if near:  # put the robot next to its target -> sparse-reward / done branch
             xy = target + lrs.uniform(-1.0, 1.0, 2)
             body = Body([xy[0], xy[1], 0.45], rpy)
@@ -407,7 +409,7 @@ def main():
         wtd = float(np.linalg.norm(target - centroid))
         self = AntMazeBulletEnv.__new__(AntMazeBulletEnv)
         self.__dict__.update(dict(
-            n_bins=10, sensor_range=5.0, sensor_span=2 * np.pi, targets=targets, sense_walls=True,
+            n_bins=n_bins, sensor_range=5.0, sensor_span=2 * np.pi, targets=targets, sense_walls=True,
             sense_target=sense_target, done_at_target=True, max_steps=-1, t=int(lrs.randint(0, 50)), tol=1.5,
             inner_rew_weight=0, targ_dist_rew=False, target_encoding=PositionEncoding(encoding), target=target,
             debug=0, scene=maze, robot=NS(body_real_xyz=[xy[0], xy[1], 0.45], walk_target_dist=wtd),
@@ -475,8 +477,7 @@ def main():
 
     # ---------------------------------------------------------------- AntMazeMjEnv.step / _get_obs (ant_maze_mj_env.py:57-78)
     from hrl_pybullet_envs.envs.ant_maze.ant_maze_mj_env import AntMazeMjEnv
-    mm = []
-    for k in range(50):
+    def maze_mj_case(k, n_bins=10):
         lrs = np.random.RandomState(11000 + k)
         targets = ([2, -4], [2, 0], [2, 4], [0, 4], [-2, 4])
         target = np.array(targets[lrs.randint(0, 5)])
@@ -496,16 +497,17 @@ def main():
         robot.alive_bonus = lambda z, pitch: MjAnt.alive_bonus(robot, z, pitch)
         self = AntMazeMjEnv.__new__(AntMazeMjEnv)
         self.__dict__.update(dict(robot=robot, scene=maze, potential=pot_old, joints_at_limit_cost=-0.1, ground_ids=set(),
-                                  reward=0.0, n_bins=10, sensor_span=2 * np.pi, sensor_range=5.0, targets=targets,
+                                  reward=0.0, n_bins=n_bins, sensor_span=2 * np.pi, sensor_range=5.0, targets=targets,
                                   tol=1.5, inner_rew_weight=float(k % 3 == 0) * 0.5, t=t0, target=target, debug=0,
                                   robot_body=Body([xy[0], xy[1], state[2]], rpy)))
         maze.global_step = lambda: None
         obs, rew, d, _ = AntMazeMjEnv.step(self, np.zeros(8))
-        mm.append({'state': state.tolist(), 'rpy': list(map(float, rpy)), 'target': target.tolist(), 't_before': t0,
-                   'potential_old': pot_old, 'potential_new': pot_new, 'joints_at_limit': n_lim,
-                   'walk_target_dist': wtd, 'inner_rew_weight': float(self.inner_rew_weight), 'obs': tolist(obs),
-                   'rew': float(rew), 'done': bool(d), 't_after': int(self.t)})
-    G['maze_mj_step'] = mm
+        return {'state': state.tolist(), 'rpy': list(map(float, rpy)), 'target': target.tolist(), 't_before': t0,
+                'potential_old': pot_old, 'potential_new': pot_new, 'joints_at_limit': n_lim,
+                'walk_target_dist': wtd, 'inner_rew_weight': float(self.inner_rew_weight), 'obs': tolist(obs),
+                'rew': float(rew), 'done': bool(d), 't_after': int(self.t)}
+
+    G['maze_mj_step'] = [maze_mj_case(k) for k in range(50)]
 
     # ---------------------------------------------------------------- AntFlagrunBulletEnv.step bookkeeping (ant_flagrun_env.py:162-204)
     from hrl_pybullet_envs.envs.ant_flagrun.ant_flagrun_env import AntFlagrunBulletEnv
@@ -827,6 +829,31 @@ def main():
                 snapc('step', nu, nb, rew=float(r), done=bool(d), retargeted='target' in info)
         man['close'].append({'timeout': 3, 'max_target_dist': 3.0, 'size': 10, 'tol': 0.5, 'events': events})
     G['flagrun_manual_seq'] = man
+
+    # ---------------------------------------------------------------- constructor arguments beyond the defaults' sizes
+    # ant_gather_env.py:16-29 / point_gather_env.py:8-21 take any n_food, n_poison, n_bins; ant_maze_bullet_env.py:23-25 any `targets`
+    # and n_bins; ant_maze_mj_env.py:50 any n_bins.  The same reference functions as above, on 20 food + 12 poison items with 24 bins,
+    # 12 maze targets with 33 bins, AntMazeMj with 16 and 64 bins (its own RandomStates: the fixtures above stay byte-identical).
+    big = {'food_sensor': [], 'gather_step': [], 'maze_step': [], 'maze_mj_step': []}
+    brs = np.random.RandomState(424242)
+    for k in range(30):
+        big['food_sensor'].append(sensor_case(AntGatherBulletEnv if k % 3 else GatherBulletEnv, 24, np.pi, 20., 20, 12, brs.uniform(-7, 7, 2),
+                                              brs.uniform(-np.pi, np.pi), np.random.RandomState(31000 + k)))
+    for k in range(6):
+        big['food_sensor'].append(sensor_case(AntGatherBulletEnv, 64, 2.5, 30., 40, 24, brs.uniform(-7, 7, 2),
+                                              brs.uniform(-np.pi, np.pi), np.random.RandomState(32000 + k)))
+    for k in range(30):
+        big['gather_step'].append(gather_step_case(AntGatherBulletEnv if k % 3 else GatherBulletEnv, 400 + k, None, 20, 12, 24))
+    big['gather_scene'] = [scene_run(31, (15, 15), 20, 12, 2.0, True, [(0, (1, 1, .5)), (19, (1, 1, .5)), (20, (0, 0, .5)), (31, (6.5, 6.5, .5)), (32, (0, 0, .5))])]
+    many_targets = tuple([float(-2.0 + 0.5 * i), float(-4.0 + 0.7 * i)] for i in range(12))
+    for k in range(20):
+        big['maze_step'].append(maze_case(500 + k, k % 2, sense_target=k % 4 < 2, near=k >= 14, n_bins=33, targets=many_targets))
+    big['maze_targets'] = [list(t) for t in many_targets]
+    for k in range(10):
+        big['maze_mj_step'].append(dict(maze_mj_case(600 + k, n_bins=16), n_bins=16))
+    for k in range(4):
+        big['maze_mj_step'].append(dict(maze_mj_case(700 + k, n_bins=64), n_bins=64))
+    G['big_config'] = big
 
     only = set(sys.argv[1:])  # optional: names of the fixtures to (re)write; default all
     for name, val in G.items():

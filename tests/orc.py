@@ -47,6 +47,10 @@ def default_config(kind, **over):
             setattr(cfg.model, k[6:], v)
         elif k == 'world_size':
             cfg.world_size[0], cfg.world_size[1] = v
+        elif k == 'targets':
+            cfg.n_targets = len(v)
+            for i, t in enumerate(v):
+                cfg.targets[i][0], cfg.targets[i][1] = float(t[0]), float(t[1])
         else:
             setattr(cfg, k, v)
     return cfg
@@ -60,6 +64,10 @@ def act_dim(cfg):
     return lib().orc_act_dim(C.byref(cfg))
 
 
+def items_stride(cfg):
+    return lib().orc_items_stride(C.byref(cfg))
+
+
 class OracleEnv:
     """Batched env on host numpy buffers with the device buffer layout (include/hrl_envs.h)."""
 
@@ -68,12 +76,14 @@ class OracleEnv:
         n = cfg.num_envs
         self.N, self.od, self.ad = n, obs_dim(cfg), act_dim(cfg)
         self.state = np.zeros((n, K.HRL_STATE_STRIDE), self.dtype)
-        self.items = np.zeros((n, K.HRL_ITEMS_STRIDE), self.dtype)
+        self.items = np.zeros((n, items_stride(cfg)), self.dtype)
         self.aux = np.zeros((n, K.HRL_AUX_STRIDE), np.int32)
         self.obs = np.zeros((n, self.od), self.dtype)
         self.rew = np.zeros(n, self.dtype)
         self.done = np.zeros(n, np.uint8)
         self.info = np.zeros((n, K.HRL_INFO_STRIDE), self.dtype)
+        self.final_obs = np.zeros((n, self.od), self.dtype)
+        self.truncated = np.zeros(n, np.uint8)
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
@@ -83,8 +93,9 @@ class OracleEnv:
 
     def step(self, actions):
         a = np.ascontiguousarray(actions, self.dtype).reshape(self.N, self.ad)
-        fn('orc_step_batch', self.dtype)(C.byref(self.cfg), ptr(self.state), ptr(self.items), ptr(self.aux), ptr(a),
-                                         ptr(self.obs), ptr(self.rew), ptr(self.done), ptr(self.info))
+        fn('orc_step_batch_v6', self.dtype)(C.byref(self.cfg), ptr(self.state), ptr(self.items), ptr(self.aux), ptr(a),
+                                            ptr(self.obs), ptr(self.rew), ptr(self.done), ptr(self.info), ptr(self.final_obs),
+                                            ptr(self.truncated))
         return self.obs, self.rew, self.done, self.info
 
     @property

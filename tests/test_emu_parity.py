@@ -173,8 +173,11 @@ def test_flagrun_close_goal_mode():
 def test_validation_errors():
     import ctypes as C
     L = emu_env.lib()
-    bad = orc.default_config(K.HRL_ANT_GATHER, n_food=12, n_poison=12)
+    bad = orc.default_config(K.HRL_ANT_GATHER, n_food=40, n_poison=25)
     assert b'n_food' in L.emu_validate(C.byref(bad))
+    assert L.emu_validate(C.byref(orc.default_config(K.HRL_ANT_GATHER, n_food=40, n_poison=24, n_bins=64))) == b''   # 64 items, obs 154
+    assert b'n_bins' in L.emu_validate(C.byref(orc.default_config(K.HRL_ANT_GATHER, n_bins=65)))
+    assert b'flag_goal_capacity' in L.emu_validate(C.byref(orc.default_config(K.HRL_ANT_FLAGRUN, flag_manual_goals=1, flag_goal_capacity=64)))
     bad = orc.default_config(K.HRL_ANT_GATHER, robot_coll_dist=0, model_item_collision=0)
     assert b'robot_coll_dist' in L.emu_validate(C.byref(bad))  # contact pickup needs the cubes as colliders
     assert L.emu_validate(C.byref(orc.default_config(K.HRL_ANT_GATHER, robot_coll_dist=0))) == b''
@@ -210,6 +213,18 @@ def test_product_defaults_equal_oracle_defaults():
     (K.HRL_ANT_FLAGRUN, 7, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
     (K.HRL_ANT_FLAGRUN, 6, dict(flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0), flag_timeout=8, flag_max_targets=5)),
     (K.HRL_ANT_FLAGRUN, 6, dict(flag_switch_on_collision=0, flag_timeout=7, flag_max_targets=4)),
+    # constructor arguments beyond the caps of ABI <= 5 (ant_gather_env.py:16-29 takes any n_food / n_poison / n_bins, ant_maze_bullet_env.py:23
+    # any targets): more than 16 items (longer items record, 16-item slices in the packed contact phase, 6-bit item field of the respawn key),
+    # observations wider than the wave (several packing / store passes), more than 8 targets
+    (K.HRL_ANT_GATHER, 6, dict(n_food=20, n_poison=12, n_bins=24, world_size=(9.0, 9.0))),
+    (K.HRL_POINT_GATHER, 6, dict(n_food=20, n_poison=12, n_bins=24, world_size=(9.0, 9.0))),
+    (K.HRL_ANT_GATHER, 5, dict(n_food=40, n_poison=24, n_bins=64, robot_coll_dist=0.0, world_size=(8.0, 8.0))),
+    (K.HRL_POINT_GATHER, 5, dict(n_food=33, n_poison=31, n_bins=40, robot_coll_dist=-1.0, world_size=(8.0, 8.0))),
+    (K.HRL_ANT_GATHER, 5, dict(n_food=20, n_poison=12, n_bins=24, use_sensor=0, world_size=(9.0, 9.0))),
+    (K.HRL_ANT_MAZE_MJ, 4, dict(n_bins=16)),
+    (K.HRL_ANT_MAZE_MJ, 4, dict(n_bins=64)),
+    (K.HRL_ANT_MAZE, 6, dict(sense_target=1, n_bins=33, targets=[(-2.0 + 0.5 * i, -4.0 + 0.1 * i) for i in range(12)], tol=0.7)),
+    (K.HRL_ANT_FLAGRUN, 4, dict(use_sensor=1, n_bins=40, flag_timeout=9)),
 ])
 def test_non_default_configs_bit_exact(kind, n, kw):
     cfg = orc.default_config(kind, num_envs=n, seed=17, auto_reset=1, max_episode_steps=25, **kw)
@@ -219,7 +234,7 @@ def test_non_default_configs_bit_exact(kind, n, kw):
     for t in range(60):
         a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
         o.step(a); e.step(a)
-        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
+        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info', 'final_obs', 'truncated'):
             assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, name)
 
 
@@ -228,7 +243,7 @@ def both(cfg, reverse=False):
 
 
 def same(o, e, tag=''):
-    for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
+    for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info', 'final_obs', 'truncated'):
         assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (tag, name)
 
 
@@ -589,3 +604,148 @@ def test_fuzzed_absurd_values_stay_bit_exact(kind):
     for seed in (0, 1):
         for ar in (0, 1):
             assert fz.run(fz.EmuSide, kind, seed, ar) is None
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_terminal_observation_and_truncation_flag(kind):
+    """ABI v6: `final_obs` = the observation of the step that ended an episode (what the reference's step() returns there,
+    ant_gather_env.py:96,118-119, ant_maze_bullet_env.py:82,97) and `truncated` = ended by the step limit alone (gym TimeLimit:
+    info['TimeLimit.truncated'] = not done).  Property, on the oracle: an auto-resetting env with a step limit against a twin without reset
+    and without limit stepped from the same pre-step records -- the twin's observation IS the terminal one, its done the env's own.
+    Then the wave phases (both lane orders) equal the oracle bit for bit, final_obs / truncated included (same())."""
+    n, limit = 24, 9
+    kw = dict(flag_timeout=4, flag_max_targets=3) if kind == K.HRL_ANT_FLAGRUN else {}
+    cfg = orc.default_config(kind, num_envs=n, seed=5, auto_reset=1, max_episode_steps=limit, **kw)
+    twin = orc.OracleEnv(orc.default_config(kind, num_envs=n, seed=5, auto_reset=0, max_episode_steps=0, **kw), np.float32)
+    (o, e), er = both(cfg), emu_env.EmuEnv(cfg, reverse=True)
+    o.reset(); e.reset(); er.reset()
+    rng = np.random.RandomState(8)
+    n_trunc = n_term = n_both = 0
+    for t in range(40):
+        if t % 4 == 3 or t % 9 == 8:   # some episodes end on their own -- a numerical failure ends any kind's (ant_gather_env.py:101-103,
+            rows = rng.permutation(n)[:4]   # gather_base.py:91-93), an ant held under 0.26 m dies --, some of them exactly at the step limit
+            for env in (o, e, er):
+                env.state[rows[:2], 15] = np.nan
+                if kind != K.HRL_POINT_GATHER:
+                    env.state[rows[2:], 2] = 0.05; env.state[rows[2:], 17] = -3.0
+        twin.state[...] = o.state; twin.items[...] = o.items; twin.aux[...] = o.aux
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        keep = o.final_obs.copy()
+        o.step(a); e.step(a); er.step(a); twin.step(a)
+        same(o, e, t); same(e, er, (t, 'lane order'))
+        d = o.done.astype(bool)
+        hit_limit = twin.aux[:, 0] >= limit
+        assert np.array_equal(d, twin.done.astype(bool) | hit_limit)
+        assert np.array_equal(o.truncated.astype(bool), hit_limit & ~twin.done.astype(bool))
+        assert np.array_equal(o.final_obs[d], twin.obs[d], equal_nan=True)         # the terminal observation
+        assert np.array_equal(o.final_obs[~d], keep[~d], equal_nan=True)            # rows of live envs are left alone
+        assert np.array_equal(o.rew, twin.rew, equal_nan=True)
+        assert not np.array_equal(o.final_obs[d], o.obs[d], equal_nan=True) or not d.any()   # obs itself is already the next episode's first
+        n_trunc += int(o.truncated.sum()); n_term += int((d & ~o.truncated.astype(bool)).sum()); n_both += int((hit_limit & twin.done.astype(bool)).sum())
+    assert n_trunc >= 20 and n_term >= 5 and n_both >= 1, (n_trunc, n_term, n_both)   # n_both: ended on its own AT the limit -> not truncated
+
+
+@pytest.mark.parametrize('kind,kw', [
+    (K.HRL_ANT_GATHER, dict(n_food=20, n_poison=12, n_bins=24)),
+    (K.HRL_POINT_GATHER, dict(n_food=20, n_poison=12, n_bins=24)),
+    (K.HRL_ANT_GATHER, dict(n_food=40, n_poison=24, n_bins=64, robot_coll_dist=0.0)),
+    (K.HRL_POINT_GATHER, dict(n_food=40, n_poison=24, n_bins=30, robot_coll_dist=-1.0)),
+])
+def test_more_than_16_items(kind, kw):
+    """n_food + n_poison > 16 (ant_gather_env.py:16-17 takes any counts): the longer items record, the 16-item slices of the packed
+    contact phase, the wider item field of the respawn key and the item codes beyond the capsule pairs.  Robots are parked at every slot in
+    turn so that the items past the 16th (and past the 48th) are picked up, touched and sensed; both lane orders equal the oracle."""
+    n = 32
+    n_items = kw['n_food'] + kw['n_poison']
+    cfg = orc.default_config(kind, num_envs=n, seed=19, auto_reset=1, **kw)
+    assert orc.items_stride(cfg) == (64 if n_items == 32 else 128)
+    (o, e), er = both(cfg), emu_env.EmuEnv(cfg, reverse=True)
+    o.reset(); e.reset(); er.reset()
+    same(o, e, 'reset')
+    assert np.all(o.items[:, 2 * n_items:] == 0) and np.all(np.abs(o.items[:, :2 * n_items]) <= 7.0) and np.all(o.items[:, 2 * n_items - 2:2 * n_items] != 0)
+    contact = 'robot_coll_dist' in kw
+    rng = np.random.RandomState(3)
+    paid_hi = moved_hi = 0
+    for t in range(36):
+        k = (np.arange(n) * 2 + t * 5) % n_items        # every slot gets its turn
+        it = o.items[:, :2 * n_items].reshape(n, n_items, 2)[np.arange(n), k]
+        if contact and kind == K.HRL_POINT_GATHER:
+            side = rng.randint(0, 4, n); d = np.array([[1, 0], [-1, 0], [0, 1], [0, -1]], np.float32)[side]
+            lat = rng.uniform(-0.3, 0.3, n).astype(np.float32); gap = rng.uniform(-0.004, 0.01, n).astype(np.float32)
+            xy = it - d * (np.float32(0.475) + gap)[:, None] + d[:, ::-1] * lat[:, None]
+            for env in (o, e, er):
+                env.state[:, 0:2] = xy; env.state[:, 2] = 0.35; env.state[:, 3:7] = [0, 0, 0, 1]; env.state[:, 7:13] = 0
+        else:
+            off = rng.uniform(-1.0, 1.0, (n, 2)).astype(np.float32) * np.float32(0.5 if not contact else 1.2)
+            for env in (o, e, er):
+                env.state[:, 0:2] = it + off
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        it0 = o.items.copy()
+        o.step(a); e.step(a); er.step(a)
+        same(o, e, t); same(e, er, (t, 'lane order'))
+        moved = np.any((o.items != it0).reshape(n, -1, 2), axis=2) & ~o.done.astype(bool)[:, None]
+        moved_hi += int(moved[:, 16:n_items].sum()) if n_items <= 48 else int(moved[:, 48:n_items].sum())
+        paid_hi += int((o.info[:, 0] != 0).sum())
+    assert moved_hi >= 10 and paid_hi >= 20, (moved_hi, paid_hi)
+    # the sensor sees the items past the 16th: with only those in range, readings are non-zero
+    if not contact:
+        o2 = orc.OracleEnv(orc.default_config(kind, num_envs=4, seed=1, **kw), np.float32)
+        e2 = emu_env.EmuEnv(o2.cfg)
+        o2.reset(); e2.reset()
+        for env in (o2, e2):
+            env.items[:, :32] = 90.0       # the first 16 far out of range
+            env.items[:, 32:2 * n_items:2] = env.state[:, 0:1] + 3.0; env.items[:, 33:2 * n_items:2] = env.state[:, 1:2] + np.linspace(-2, 2, n_items - 16, dtype=np.float32)
+        a = np.zeros((4, o2.ad), np.float32) + np.float32(0.1)
+        o2.step(a); e2.step(a)
+        same(o2, e2, 'sensor')
+        nb = 26 if kind == K.HRL_ANT_GATHER else 8
+        assert (o2.obs[:, nb:] > 0).any(axis=1).all()
+
+
+def test_manual_goal_lists_longer_than_15():
+    """manual_goal_creation with flag_goal_capacity = 40 (`env.goals = [...]` takes any list, ant_flagrun_env.py:45): the pending list lives in a
+    longer items record; 40 goals are consumed back to front, one per 3-step timeout."""
+    import ctypes as C
+    n, G = 6, 40
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=2, auto_reset=0, flag_manual_goals=1, flag_goal_capacity=G, flag_timeout=3, max_episode_steps=0)
+    assert orc.items_stride(cfg) == 96
+    (o, e), er = both(cfg), emu_env.EmuEnv(cfg, reverse=True)
+    o.reset(); e.reset(); er.reset()
+    goals = np.random.RandomState(0).uniform(-4, 4, (n, G, 2)).astype(np.float32)
+    orc.lib().orc_set_goals_batch_f32(C.byref(cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(goals), G, None, orc.ptr(o.obs))
+    for env in (e, er):
+        b = env._bufs()
+        assert emu_env.lib().emu_set_goals(C.byref(cfg), C.byref(b), orc.ptr(goals), G, None, env.reverse) == 0
+    same(o, e, 'set_goals'); same(e, er, 'set_goals lane order')
+    assert np.array_equal(o.items[:, 0:2], goals[:, G - 1]) and np.all((o.aux[:, 3] & 0xffff) == G - 1)
+    assert emu_env.lib().emu_set_goals(C.byref(cfg), C.byref(e._bufs()), orc.ptr(goals), G + 1, None, 0) != 0   # beyond the capacity
+    rng = np.random.RandomState(1)
+    for t in range(3 * G + 2):
+        a = rng.uniform(-0.3, 0.3, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a); er.step(a)
+        same(o, e, t); same(e, er, (t, 'lane order'))
+        left, cur = G - 1 - (t + 1) // 3, o.aux[:, 3] & 0xffff   # one goal per timeout, sooner where a goal happens to be reached
+        live = ~o.done.astype(bool)
+        assert np.all(cur[live] <= max(left, 0)) and np.array_equal(o.items[live, 0:2], goals[np.arange(n)[live], cur[live]]), t
+    assert o.done.all()    # the list ran out (IndexError in the reference, :193-194)
+
+
+def test_next_target_pops_the_shared_list_of_a_non_manual_env():
+    """`env.next_target()` called from outside on a NON-manual env (ant_flagrun_env.py:112-116): `self.goals.pop()` of the list reset() made --
+    here: the goal counter of the episode advances --, ok = 0 (IndexError in the reference) once max_targets goals are used up."""
+    import ctypes as C
+    n = 9
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=4, auto_reset=0, flag_max_targets=3)
+    o, e = both(cfg)
+    o.reset(); e.reset()
+    mask = np.ones(n, np.uint8); mask[::4] = 0
+    for k in range(4):
+        ok_o, ok_e = np.full(n, 7, np.uint8), np.full(n, 7, np.uint8)
+        orc.lib().orc_next_target_batch_f32(C.byref(cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(mask), orc.ptr(o.obs), orc.ptr(ok_o))
+        assert emu_env.lib().emu_next_target(C.byref(cfg), C.byref(e._bufs()), orc.ptr(mask), orc.ptr(ok_e), 0) == 0
+        same(o, e, k)
+        assert np.array_equal(ok_o, ok_e) and np.all(ok_o[mask == 0] == 7) and np.all(ok_o[mask == 1] == (1 if k < 2 else 0))
+        assert np.all((o.aux[mask == 1, 3] & 0xffff) == min(2 + k, 3)) and np.all((o.aux[mask == 0, 3] & 0xffff) == 1)
+    a = np.zeros((n, 8), np.float32)
+    o.step(a); e.step(a)
+    same(o, e, 'step')

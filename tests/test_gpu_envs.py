@@ -311,7 +311,41 @@ def test_attributes_a_trainer_reads_between_steps():
     assert ob.shape == (28,) and e.goal == (3.0, 3.0) and e.goals == [(1.0, 2.0), (-2.0, 0.5)]
     ob2 = e.set_goals([(0.5, 0.5), (4.0, -4.0)])
     assert e.goal == (4.0, -4.0) and e.goals == [(0.5, 0.5)] and ob2.shape == (28,)
-    e.close()
+    # the reference's documented manual workflow (ant_flagrun_env.py:91-96): reset(); create_targets(n); next_target()
+    e.reset()
+    e.create_targets(7)
+    g7 = e.goals
+    assert len(g7) == 7 and all(abs(x) <= 5 and abs(y) <= 5 and (x * x + y * y) ** 0.5 >= 0.5 for x, y in g7)
+    e.next_target()
+    assert e.goal == pytest.approx(g7[-1]) and e.goals == g7[:-1]
+    e.create_targets(7)
+    assert e.goals != g7 and len(e.goals) == 7                    # a later call draws a fresh list
+    e2 = H.AntFlagrunBulletEnv(manual_goal_creation=True, seed=3)
+    e2.reset(); e2.create_targets(7)
+    assert e2.goals == g7                                          # same seed, same call number: the same list in every process
+    with pytest.raises(ValueError, match='goal_capacity'):
+        e2.create_targets(16)
+    e2.close(); e.close()
+    big = H.AntFlagrunBulletEnv(manual_goal_creation=True, seed=3, goal_capacity=40)
+    big.reset(); big.create_targets(40)
+    assert len(big.goals) == 40 and big._backend().items.shape[1] == 96
+    big.next_target()
+    assert len(big.goals) == 39
+    big.close()
+    # next_target() of a NON-manual env pops the shared list (:112-116), IndexError when it is used up
+    f = H.AntFlagrunBulletEnv(max_targets=3, seed=9)
+    f.reset()
+    g0 = f.goals
+    assert len(g0) == 2
+    ob = f.next_target()
+    assert ob.shape == (28,) and f.goal == pytest.approx(g0[-1]) and f.goals == g0[:-1] and not f._rewarded
+    f.next_target()
+    with pytest.raises(IndexError):
+        f.next_target()
+    f.create_targets(3)                                            # the length reset() armed: fine; any other cannot be served
+    with pytest.raises(ValueError, match='max_targets'):
+        f.create_targets(5)
+    f.close()
     # gather kinds: the robot object of the constructor with live pose attributes
     p = H.PointGatherBulletEnv(seed=1)
     p.reset()
@@ -342,5 +376,19 @@ def test_step_host_equals_the_device_path():
             assert isinstance(o2, np.ndarray) and o2.shape == (n, a_env.obs_dim)
             assert np.array_equal(o1.cpu().numpy(), o2, equal_nan=True) and np.array_equal(r1.cpu().numpy(), r2), (kind, t)
             assert np.array_equal(d1.cpu().numpy(), d2) and np.array_equal(a_env.info.cpu().numpy(), i2), (kind, t)
+            # the terminal observation / truncation flag of the host path, and the device tensors of an env stepped through the host:
+            # reading them brings the host values over (they used to stay silently stale)
+            fo, tr = b_env.host_final_obs()
+            dd = d2.astype(bool)
+            assert np.array_equal(a_env.final_obs.cpu().numpy()[dd], fo[dd], equal_nan=True) and np.array_equal(a_env.truncated.cpu().numpy(), tr), (kind, t)
+            if t % 7 == 0:
+                assert np.array_equal(b_env.obs.cpu().numpy(), o2, equal_nan=True) and np.array_equal(b_env.info.cpu().numpy(), i2)
+                assert np.array_equal(b_env.final_obs.cpu().numpy()[dd], fo[dd], equal_nan=True)
         assert torch.equal(a_env.state, b_env.state) and torch.equal(a_env.aux, b_env.aux)
+        # mixing the two paths: a device step after host steps, then a reset, never resurrects stale host outputs
+        a = rng.uniform(-1, 1, (n, a_env.act_dim)).astype(np.float32)
+        o1, r1, d1, _ = a_env.step(torch.from_numpy(a).cuda()); o2, r2, d2, _ = b_env.step(torch.from_numpy(a).cuda())
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(a_env.final_obs, b_env.final_obs)
+        b_env.step_host(a); a_env.step(torch.from_numpy(a).cuda())
+        assert torch.equal(a_env.reset(), b_env.reset())
         a_env.close(); b_env.close()

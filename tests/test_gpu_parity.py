@@ -308,13 +308,16 @@ def test_env_counts_that_do_not_fill_the_last_group(n):
     g, o = make(K.HRL_ANT_GATHER, n, seed=11)
     # the caller's buffers become views into larger allocations: a write past row n - 1 lands in the guard rows behind them
     big = {}
-    for k in ('state', 'items', 'aux', 'obs', 'reward', 'done', 'info'):
+    for k in ('state', 'items', 'aux', 'obs', 'reward', 'done', 'info', 'final_obs', 'truncated'):
         t = getattr(g, k)
         big[k] = torch.full((n + 8,) + tuple(t.shape[1:]), 7, dtype=t.dtype, device=t.device)
         big[k][:n] = t
-        setattr(g, k, big[k][:n])
+        if k in g._out:
+            g._out[k] = big[k][:n]   # the step's outputs are read through properties over this dict
+        else:
+            setattr(g, k, big[k][:n])
     g._bufs = K.hrl_buffers(g.state.data_ptr(), g.items.data_ptr(), g.aux.data_ptr(), None, g.obs.data_ptr(), g.reward.data_ptr(),
-                            g.done.data_ptr(), g.info.data_ptr())
+                            g.done.data_ptr(), g.info.data_ptr(), g.final_obs.data_ptr(), g.truncated.data_ptr())
     g.reset(); o.reset()
     rng = np.random.RandomState(3)
     for t in range(25):
@@ -403,6 +406,17 @@ CONFIG_MATRIX = [
     (K.HRL_ANT_FLAGRUN, 35, dict(flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0), flag_timeout=8, flag_max_targets=5)),  # ant_flagrun_env.py:59-64: open field
     (K.HRL_ANT_FLAGRUN, 29, dict(flag_switch_on_collision=0, flag_timeout=7, flag_max_targets=4)),                                           # :183-194
     (K.HRL_ANT_FLAGRUN, 19, dict(flag_manual_goals=1, flag_max_targets=0, flag_max_target_dist=3.0, flag_timeout=5)),                        # manual + close targets (:113-114)
+    # constructor arguments beyond the caps of ABI <= 5 (ant_gather_env.py:16-29, ant_maze_bullet_env.py:23-25, ant_maze_mj_env.py:50):
+    # more than 16 items, observations wider than the wave, more than 8 targets
+    (K.HRL_ANT_GATHER, 70, dict(n_food=20, n_poison=12, n_bins=24)),
+    (K.HRL_POINT_GATHER, 41, dict(n_food=20, n_poison=12, n_bins=24)),
+    (K.HRL_ANT_GATHER, 37, dict(n_food=40, n_poison=24, n_bins=64, robot_coll_dist=0.0, world_size=(8.0, 8.0), centroid_static_sum=(-4.0, 0.0))),
+    (K.HRL_POINT_GATHER, 33, dict(n_food=33, n_poison=31, n_bins=40, robot_coll_dist=-1.0, world_size=(8.0, 8.0))),
+    (K.HRL_ANT_GATHER, 21, dict(n_food=20, n_poison=12, n_bins=24, use_sensor=0)),
+    (K.HRL_ANT_MAZE_MJ, 35, dict(n_bins=16)),
+    (K.HRL_ANT_MAZE_MJ, 18, dict(n_bins=64)),
+    (K.HRL_ANT_MAZE, 45, dict(sense_target=1, n_bins=33, targets=[(-2.0 + 0.5 * i, -4.0 + 0.1 * i) for i in range(12)], tol=0.7)),
+    (K.HRL_ANT_FLAGRUN, 22, dict(use_sensor=1, n_bins=40, flag_timeout=9)),
 ]
 
 
@@ -419,6 +433,7 @@ def test_non_default_configs_match_oracle(kind, n, kw):
         go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
         assert np.array_equal(g.state.cpu().numpy(), o.state), t
         assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), t
+        assert np.array_equal(g.truncated.cpu().numpy(), o.truncated) and obs_bad_rows(g.final_obs.cpu().numpy(), o.final_obs).sum() == 0, t
         flips += int(obs_bad_rows(go.cpu().numpy(), o.obs).sum())
     assert flips == 0
     assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux)
@@ -628,3 +643,112 @@ def test_fuzzed_absurd_values_stay_bit_exact(kind):
     for seed in (0, 1, 2):
         for ar in (0, 1):
             assert fz.run(fz.GpuSide, kind, seed, ar) is None
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_terminal_observation_and_truncation_flag(kind):
+    """ABI v6: hrl_buffers.final_obs = the observation of the step that ended an episode (ant_gather_env.py:96,118-119,
+    ant_maze_bullet_env.py:82,97) -- which the in-kernel reset replaces in `obs` by the next episode's first --, hrl_buffers.truncated = ended by
+    the step limit alone.  Device == oracle bit for bit (the oracle's semantics are pinned against a never-resetting twin in
+    tests/test_emu_parity.py); rows of live envs keep what they held; a launch with NULL pointers writes neither."""
+    import ctypes as C
+    from hrl_pybullet_envs_amd import _lib
+    n, limit = 192, 9
+    kw = dict(flag_timeout=4, flag_max_targets=3) if kind == K.HRL_ANT_FLAGRUN else {}
+    g, o = make(kind, n, seed=5, max_episode_steps=limit, **kw)
+    g.reset(); o.reset()
+    g.final_obs.fill_(-7.0); o.final_obs[...] = -7.0
+    rng = np.random.RandomState(8)
+    n_trunc = n_term = 0
+    for t in range(40):
+        if t % 4 == 3 or t % 9 == 8:
+            rows = rng.permutation(n)[:24]
+            o.state[rows[:12], 15] = np.nan
+            if kind != K.HRL_POINT_GATHER:
+                o.state[rows[12:], 2] = 0.05; o.state[rows[12:], 17] = -3.0
+            push(g, o)
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(gd.cpu().numpy(), o.done), t
+        assert np.array_equal(gi['TimeLimit.truncated'].cpu().numpy(), o.truncated), t
+        assert np.array_equal(gi['final_observation'].cpu().numpy(), o.final_obs, equal_nan=True), t
+        assert np.array_equal(go.cpu().numpy(), o.obs, equal_nan=True), t
+        d = o.done.astype(bool)
+        n_trunc += int(o.truncated.sum()); n_term += int((d & ~o.truncated.astype(bool)).sum())
+    assert n_trunc >= 100 and n_term >= 40, (n_trunc, n_term)
+    assert (o.final_obs != -7.0).any(axis=1).all()   # every env has ended at least once
+    # NULL pointers: nothing is written (and nothing crashes)
+    keep_f, keep_t = g.final_obs.clone(), g.truncated.clone()
+    g._bufs.final_obs = None; g._bufs.truncated = None
+    for t in range(12):
+        g.step(torch.from_numpy(rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(g.final_obs.view(torch.int32), keep_f.view(torch.int32)) and torch.equal(g.truncated, keep_t)   # bit patterns: rows hold NaNs
+    assert int(g.done.sum()) >= 0 and C.sizeof(K.hrl_buffers) == 80
+
+
+@pytest.mark.parametrize('kind,kw', [
+    (K.HRL_ANT_GATHER, dict(n_food=20, n_poison=12, n_bins=24)),
+    (K.HRL_POINT_GATHER, dict(n_food=20, n_poison=12, n_bins=24)),
+    (K.HRL_ANT_GATHER, dict(n_food=40, n_poison=24, n_bins=64, robot_coll_dist=0.0)),
+    (K.HRL_POINT_GATHER, dict(n_food=40, n_poison=24, n_bins=30, robot_coll_dist=-1.0)),
+])
+def test_more_than_16_items(kind, kw):
+    """n_food + n_poison > 16 on the device (the reference's constructor takes any counts, ant_gather_env.py:16-17): robots parked at every slot in
+    turn, identical inputs every step: pickups, cube contacts (the 16-item slices of the packed contact phase, item codes beyond the capsule
+    pairs), respawns with the 6-bit item field and the sensor over all slots equal the oracle bit for bit."""
+    n = 256
+    n_items = kw['n_food'] + kw['n_poison']
+    g, o = make(kind, n, seed=19, **kw)
+    assert g.items.shape[1] == orc.items_stride(o.cfg) == (64 if n_items == 32 else 128)
+    g.reset(); o.reset()
+    assert np.array_equal(g.items.cpu().numpy(), o.items) and obs_bad_rows(g.obs.cpu().numpy(), o.obs).sum() == 0
+    contact = 'robot_coll_dist' in kw
+    rng = np.random.RandomState(3)
+    paid = moved_hi = 0
+    for t in range(30):
+        k = (np.arange(n) * 2 + t * 5) % n_items
+        it = o.items[:, :2 * n_items].reshape(n, n_items, 2)[np.arange(n), k]
+        if contact and kind == K.HRL_POINT_GATHER:
+            side = rng.randint(0, 4, n); d = np.array([[1, 0], [-1, 0], [0, 1], [0, -1]], np.float32)[side]
+            lat = rng.uniform(-0.3, 0.3, n).astype(np.float32); gap = rng.uniform(-0.004, 0.01, n).astype(np.float32)
+            o.state[:, 0:2] = it - d * (np.float32(0.475) + gap)[:, None] + d[:, ::-1] * lat[:, None]
+            o.state[:, 2] = 0.35; o.state[:, 3:7] = [0, 0, 0, 1]; o.state[:, 7:13] = 0
+        else:
+            o.state[:, 0:2] = it + rng.uniform(-1.0, 1.0, (n, 2)).astype(np.float32) * np.float32(0.5 if not contact else 1.2)
+        push(g, o)
+        a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        it0 = o.items.copy()
+        go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(g.items.cpu().numpy(), o.items), t
+        assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(g.info.cpu().numpy(), o.info) and np.array_equal(gd.cpu().numpy(), o.done), t
+        assert np.array_equal(go.cpu().numpy(), o.obs, equal_nan=True), t
+        moved = np.any((o.items != it0).reshape(n, -1, 2), axis=2) & ~o.done.astype(bool)[:, None]
+        moved_hi += int(moved[:, 16:n_items].sum()) if n_items <= 48 else int(moved[:, 48:n_items].sum())
+        paid += int((o.info[:, 0] != 0).sum())
+    assert moved_hi >= 80 and paid >= 200, (moved_hi, paid)
+
+
+def test_manual_goal_lists_longer_than_15_through_the_c_abi():
+    """flag_goal_capacity = 40: hrl_set_goals takes the 40-goal list (`env.goals = [...]` takes any, ant_flagrun_env.py:45), the pending list
+    lives in a 96-float items record and is consumed back to front; one goal beyond the capacity is refused with a reason."""
+    import ctypes as C
+    from hrl_pybullet_envs_amd import _lib
+    n, G = 48, 40
+    g, o = make(K.HRL_ANT_FLAGRUN, n, seed=2, flag_manual_goals=1, flag_goal_capacity=G, flag_timeout=3, max_episode_steps=0)
+    assert g.items.shape[1] == 96
+    g.reset(); o.reset()
+    goals = np.random.RandomState(0).uniform(-4, 4, (n, G, 2)).astype(np.float32)
+    gobs = g.set_goals(torch.from_numpy(goals).cuda())
+    orc.lib().orc_set_goals_batch_f32(C.byref(o.cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(goals), G, None, orc.ptr(o.obs))
+    assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux) and obs_bad_rows(gobs.cpu().numpy(), o.obs).sum() == 0
+    with pytest.raises(_lib.HrlError, match='flag_goal_capacity'):
+        g.set_goals(torch.zeros(n, G + 1, 2).cuda())
+    rng = np.random.RandomState(1)
+    for t in range(3 * G + 2):
+        a = rng.uniform(-0.3, 0.3, (n, 8)).astype(np.float32)
+        go, gr, gd, _ = g.step(torch.from_numpy(a).cuda()); o.step(a)
+        if t % 10 == 0 or t > 3 * G - 3:
+            assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux), t
+            assert np.array_equal(g.state.cpu().numpy(), o.state) and obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
+    assert np.array_equal(gd.cpu().numpy(), o.done) and (o.done | (o.aux[:, 2] > 1)).all()   # every list ran out

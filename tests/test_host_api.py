@@ -60,7 +60,7 @@ def test_bad_config_is_rejected_with_a_reason():
     from hrl_pybullet_envs_amd import _lib
     L = _lib.lib()
     h = C.c_void_p()
-    for kw, frag in ((dict(n_food=12, n_poison=12), b'n_food'), (dict(num_envs=0), b'num_envs'),
+    for kw, frag in ((dict(n_food=40, n_poison=25), b'n_food'), (dict(num_envs=0), b'num_envs'),
                      (dict(abi_version=99), b'abi_version'), (dict(robot_coll_dist=0, model_item_collision=0), b'robot_coll_dist')):
         cfg = _lib.default_config(K.HRL_ANT_GATHER, **kw)
         assert L.hrl_create(C.byref(cfg), C.byref(h)) == K.HRL_ERR_BAD_ARG

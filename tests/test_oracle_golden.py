@@ -69,7 +69,10 @@ def test_sense_walls(dtype, tol):
 
 @pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-12), (np.float32, 1e-5)])
 def test_food_sensor_and_abs_pos(dtype, tol):
-    g = load('food_sensor')
+    check_food_sensor(load('food_sensor'), dtype, tol)
+
+
+def check_food_sensor(g, dtype, tol):
     cr = orc.creal(dtype)
     flips = 0
     for c in g:
@@ -95,7 +98,11 @@ def test_food_sensor_and_abs_pos(dtype, tol):
 
 def test_gather_scene_respawn():
     """gather_scene.py:38-62,95-114 replayed with the exact uniform draws the reference consumed."""
-    for sc in load('gather_scene'):
+    check_gather_scene(load('gather_scene'))
+
+
+def check_gather_scene(cases):
+    for sc in cases:
         ws = arr(sc['world'])
         draws = sc['restart_draws']
         n_items = sc['n_food'] + sc['n_poison']
@@ -135,10 +142,14 @@ def test_gather_scene_respawn():
 
 def test_gather_step_task_half():
     """ant_gather_env.py:81-119 / gather_base.py:80-109: pickups, respawn, sensor, alive/done/reward."""
-    for c in load('gather_step'):
+    check_gather_step(load('gather_step'))
+
+
+def check_gather_step(cases, **kw):
+    for c in cases:
         ant = c['cls'] == 'AntGatherBulletEnv'
-        cfg = orc.default_config(K.HRL_ANT_GATHER if ant else K.HRL_POINT_GATHER)
-        assert cfg.n_bins == c['n_bins']
+        cfg = orc.default_config(K.HRL_ANT_GATHER if ant else K.HRL_POINT_GATHER, **kw)
+        assert cfg.n_bins == c['n_bins'] and cfg.n_food + cfg.n_poison == len(c['items_before'])
         st = arr(c['state_in']); items = arr(c['items_before']).copy()
         draws = arr(c['respawn_draws']).reshape(-1, 2) if c['respawn_draws'] else np.zeros((1, 2))
         nobs = (26 if ant else 8) + 2 * c['n_bins']
@@ -157,11 +168,21 @@ def test_gather_step_task_half():
 
 def test_maze_step_task_half():
     """ant_maze_bullet_env.py:63-97,123-178 with the upstream step result supplied."""
+    check_maze_step(load('maze_step'))
+    spot = load('target_vec_spot')
+    for enc, key in ((0, 'normed'), (1, 'angle')):
+        tv = np.zeros(2)
+        orc.lib().orc_target_vec_obs_f64(enc, orc.ptr(arr([-2, 4])), orc.ptr(arr([0.3, -0.2])), C.c_double(0.4), orc.ptr(tv))
+        np.testing.assert_allclose(tv, spot[key], atol=1e-12)
+
+
+def check_maze_step(cases, n_bins=10, **kw):
     g = load('sense_walls')
     lines = arr(g['maze_bounds']).reshape(-1, 4)
-    for c in load('maze_step'):
-        cfg = orc.default_config(K.HRL_ANT_MAZE, target_encoding=c['encoding'], sense_target=int(c['sense_target']))
+    for c in cases:
+        cfg = orc.default_config(K.HRL_ANT_MAZE, target_encoding=c['encoding'], sense_target=int(c['sense_target']), n_bins=n_bins, **kw)
         nobs = orc.obs_dim(cfg)
+        assert nobs == len(c['obs'])
         obs = np.zeros(nobs); rew = C.c_double(); done = C.c_int()
         orc.lib().orc_maze_task_f64(C.byref(cfg), orc.ptr(arr(c['ant_obs'])), C.c_double(c['inner_rew']), 0,
                                     orc.ptr(arr(c['torso_xy'])), C.c_double(c['rpy'][2]), orc.ptr(arr(c['target'])),
@@ -173,16 +194,11 @@ def test_maze_step_task_half():
         orc.lib().orc_target_vec_obs_f64(c['encoding'], orc.ptr(arr(c['target'])), orc.ptr(arr(c['torso_xy'])),
                                          C.c_double(c['rpy'][2]), orc.ptr(tv))
         np.testing.assert_allclose(tv, c['target_vec_obs'], atol=1e-12)
-        ts = np.zeros(10)
-        orc.lib().orc_target_sensor_obs_f64(10, C.c_double(2 * math.pi), C.c_double(5.0), orc.ptr(arr(c['target'])),
+        ts = np.zeros(n_bins)
+        orc.lib().orc_target_sensor_obs_f64(n_bins, C.c_double(2 * math.pi), C.c_double(5.0), orc.ptr(arr(c['target'])),
                                             orc.ptr(arr(c['torso_xy'])), C.c_double(c['rpy'][2]),
                                             C.c_double(c['walk_target_dist']), orc.ptr(lines[4:]), 3, orc.ptr(ts))
         np.testing.assert_allclose(ts, c['target_sensor_obs'], atol=1e-12)
-    spot = load('target_vec_spot')
-    for enc, key in ((0, 'normed'), (1, 'angle')):
-        tv = np.zeros(2)
-        orc.lib().orc_target_vec_obs_f64(enc, orc.ptr(arr([-2, 4])), orc.ptr(arr([0.3, -0.2])), C.c_double(0.4), orc.ptr(tv))
-        np.testing.assert_allclose(tv, spot[key], atol=1e-12)
 
 
 def test_pointbot_calc_state():
@@ -209,14 +225,19 @@ def test_antmj_reward():
 
 def test_maze_mj_step_task_half():
     """ant_maze_mj_env.py:57-78 on top of MjAnt.py:36-97: observation assembly, t/1000, sparse reward."""
+    check_maze_mj_step(load('maze_mj_step'))
+
+
+def check_maze_mj_step(cases):
     lines = arr(load('sense_walls')['maze_bounds']).reshape(-1, 4)
-    for c in load('maze_mj_step'):
-        cfg = orc.default_config(K.HRL_ANT_MAZE_MJ, inner_rew_weight=c['inner_rew_weight'])
-        assert orc.obs_dim(cfg) == 60 == len(c['obs'])
+    for c in cases:
+        nb = c.get('n_bins', 10)
+        cfg = orc.default_config(K.HRL_ANT_MAZE_MJ, inner_rew_weight=c['inner_rew_weight'], n_bins=nb)
+        assert orc.obs_dim(cfg) == 30 + 3 * nb == len(c['obs'])
         inner = C.c_double(); idone = C.c_int()
         orc.lib().orc_antmj_reward_f64(orc.ptr(arr(c['state'])), C.c_double(c['potential_old']), C.c_double(c['potential_new']),
                                        c['joints_at_limit'], C.c_double(-0.1), C.byref(inner), C.byref(idone))
-        obs = np.zeros(60); rew = C.c_double(); done = C.c_int()
+        obs = np.zeros(30 + 3 * nb); rew = C.c_double(); done = C.c_int()
         orc.lib().orc_maze_mj_task_f64(C.byref(cfg), orc.ptr(arr(c['state'])), C.c_double(c['rpy'][2]), inner, idone,
                                        C.c_double(c['walk_target_dist']), c['t_before'], orc.ptr(lines), 7, orc.ptr(obs),
                                        C.byref(rew), C.byref(done))
@@ -307,7 +328,7 @@ def test_flagrun_manual_goal_sequences():
                 np.testing.assert_allclose(items[0:2], e['target'], atol=1e-12)
             elif e['op'] in ('set_goals', 'next_target'):
                 gl = arr(e['goals']).reshape(-1, 2)
-                L.orc_flag_goals_assign_f64(orc.ptr(items), orc.ptr(aux), orc.ptr(gl), len(gl))
+                L.orc_flag_goals_assign_f64(C.byref(cfg), orc.ptr(items), orc.ptr(aux), orc.ptr(gl), len(gl))
                 ok = L.orc_flag_next_target_f64(C.byref(cfg), C.c_int64(0), orc.ptr(st), orc.ptr(items), orc.ptr(aux))
                 assert bool(ok) == (not e.get('raised', False))
                 n_raise += int(not ok)
@@ -429,3 +450,19 @@ def test_reset_potential_belongs_to_the_previous_target():
                     else:
                         assert e['rew'] == pytest.approx(base * 1.0, abs=1e-6)  # inner_rew_weight = 1
                 prev_target, prev = e['target'], e
+
+
+def test_configs_beyond_the_default_sizes():
+    """tests/golden/big_config.json, generated from the reference like the others: 20 food + 12 poison items with 24 bins (and 40 + 24 with
+    64 bins) through get_sensor_readings / get_abs_pos / step / GatherScene, 12 maze targets with 33 bins, AntMazeMj with 16 and 64 bins --
+    constructor arguments the reference accepts (ant_gather_env.py:16-29, ant_maze_bullet_env.py:23-25, ant_maze_mj_env.py:50) and ABI <= 5
+    rejected."""
+    g = load('big_config')
+    check_food_sensor(g['food_sensor'], np.float64, 1e-12)
+    check_food_sensor(g['food_sensor'], np.float32, 1e-5)
+    check_gather_step(g['gather_step'], n_food=20, n_poison=12, n_bins=24)
+    check_gather_scene(g['gather_scene'])
+    check_maze_step(g['maze_step'], n_bins=33, targets=g['maze_targets'])
+    check_maze_mj_step(g['maze_mj_step'])
+    assert {len(c['food']) + len(c['poison']) for c in g['food_sensor']} == {32, 64}
+    assert any(c['food_rew'] != 0 for c in g['gather_step']) and any(c['done'] for c in g['maze_step'])

@@ -33,6 +33,7 @@ def main():
     obs_dim, act_dim = _lib.lib().hrl_obs_dim(C.byref(cfg)), _lib.lib().hrl_act_dim(C.byref(cfg))
     envs = {}
     acts = torch.rand(64, n, act_dim, device='cuda') * 2 - 1
+    libs['product+final'] = libs['product']  # the same library with the optional final_obs / truncated outputs of ABI v6 wired up
     for name, L in libs.items():
         h = C.c_void_p()
         assert L.hrl_create(C.byref(cfg), C.byref(h)) == 0
@@ -41,6 +42,9 @@ def main():
                  info=torch.zeros(n, 4, device='cuda'))
         b = K.hrl_buffers(t['state'].data_ptr(), t['items'].data_ptr(), t['aux'].data_ptr(), None, t['obs'].data_ptr(), t['rew'].data_ptr(),
                           t['done'].data_ptr(), t['info'].data_ptr())
+        if name.endswith('+final'):
+            t['final'] = torch.zeros(n, obs_dim, device='cuda'); t['trunc'] = torch.zeros(n, dtype=torch.uint8, device='cuda')
+            b.final_obs = t['final'].data_ptr(); b.truncated = t['trunc'].data_ptr()
         L.hrl_reset(h, C.byref(b), None, None)
         envs[name] = (L, h, b, t)
     res = {k: [] for k in envs}
