@@ -901,7 +901,11 @@ static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, 
         c[i] = -(invd * (wi + bias[i])); /* lambda_i = 0 */
         lam[i] = 0; lo[i] = 0; hi[i] = frn[i] >= 0 ? R_(0) : hic[i];
     }
-    for (int it = 0; it < iters; ++it)
+    for (int it = 0; it < iters; ++it) {
+#ifdef ORC_SWEEP_STATS /* diagnostic build (tools/sweep_stats.py): how often a whole sweep leaves every (c, lambda) bit unchanged -- the sweeps after it are then identical and could be skipped exactly */
+        REAL c0[ORC_MAXROWS], l0[ORC_MAXROWS];
+        memcpy(c0, c, sizeof(REAL) * nr); memcpy(l0, lam, sizeof(REAL) * nr);
+#endif
         for (int r = 0; r < nr; ++r) {
             REAL ln = FN(med3)(c[r], lo[r], hi[r]);
             REAL dl = ln - lam[r];
@@ -911,6 +915,15 @@ static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, 
                 if (frn[i] == r) { hi[i] = mu[i] * ln; lo[i] = -hi[i]; }
             }
         }
+#ifdef ORC_SWEEP_STATS
+        if (REAL_IS_FLOAT) {
+            const int fixed = memcmp(c0, c, sizeof(REAL) * nr) == 0 && memcmp(l0, lam, sizeof(REAL) * nr) == 0;
+            __atomic_fetch_add(&orc_sweep_stats[it][fixed], 1, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&orc_sweep_rows[it][fixed], nr, __ATOMIC_RELAXED);
+            if (fixed) { for (int k = it + 1; k < iters; ++k) { __atomic_fetch_add(&orc_sweep_stats[k][2], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&orc_sweep_rows[k][2], nr, __ATOMIC_RELAXED); } break; }
+        }
+#endif
+    }
     for (int d = 0; d < 16; ++d)
         for (int r = 0; r < nr; ++r) un[d] = FMA_(B[r][d], lam[r], un[d]);
 }
