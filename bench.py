@@ -52,7 +52,33 @@ def parse_args():
     ap.add_argument('--gather-every', type=int, default=100, help='all-gather episode returns every K steps (N>1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo only to rehearse N>1 on a box with fewer GPUs')
+    ap.add_argument('--watchdog', type=float, default=900.0, help='seconds a rank may take in total before it reports the stage it hangs in and exits 3 (0 = off)')
     return ap.parse_args()
+
+
+class Watchdog:
+    """A rank that stops making progress (a collective some rank never joined, a rendezvous that never completes) would otherwise sit until the
+    driver's limit with nothing on its output.  A daemon thread: after `seconds` it prints which stage the rank was in and ends THIS process
+    with status 3 (os._exit: no interpreter teardown that could block on the GPU; never a re-exec).  torch.distributed.run then ends the others."""
+
+    def __init__(self, seconds, rank):
+        import threading
+        self.stage, self.rank, self.seconds = 'start', rank, seconds
+        self._done = threading.Event()
+        if seconds > 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def _watch(self):
+        if not self._done.wait(self.seconds):
+            sys.stderr.write(f'bench.py watchdog: rank {self.rank} still in stage "{self.stage}" after {self.seconds:.0f} s, exiting 3\n')
+            sys.stderr.flush()
+            os._exit(3)
+
+    def at(self, stage):
+        self.stage = stage
+
+    def done(self):
+        self._done.set()
 
 
 def spawn_ranks(args):
@@ -195,7 +221,10 @@ def main():
     kinds = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER,
              'maze_mj': K.HRL_ANT_MAZE_MJ, 'flagrun': K.HRL_ANT_FLAGRUN}
 
+    wd = Watchdog(args.watchdog, int(os.environ.get('RANK', '0')))
+    wd.at('init_process_group')
     rank, world, local_rank = init_distributed(args.gpus, backend=args.backend)
+    wd.at('build envs')
     if args.backend == 'gloo':
         local_rank = local_rank % max(1, torch.cuda.device_count())
     dev = torch.device('cuda', local_rank)
@@ -228,10 +257,19 @@ def main():
             if gatherer is not None and (t + 1) % gather_every == 0:
                 gatherer.launch()
 
+    ranks_seen = None
+    if world > 1:  # every rank reports in before anything is timed: the line shows the job really was `world` ranks on `world` devices
+        wd.at('all_gather of (rank, device)')
+        ranks_seen = [None] * world
+        torch.distributed.all_gather_object(ranks_seen, (rank, local_rank, torch.cuda.get_device_name(dev)))
+    wd.at('warmup')
     run(0, args.warmup)
     torch.cuda.synchronize(dev)
+    n_warm_gathers = gatherer.k if gatherer is not None else 0
     if world > 1:
+        wd.at('barrier before the timed region')
         torch.distributed.barrier()
+    wd.at('timed region')
     t0 = time.perf_counter()
     ev = []
     for _, _, _, stream in envs:  # HIP events on the stream each kernel is launched on
@@ -243,8 +281,10 @@ def main():
         e1.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
+        wd.at('barrier after the timed region')
         torch.distributed.barrier()
     wall = time.perf_counter() - t0
+    wd.at('reductions after the timed region')
     dev_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     if world > 1:
         tt = torch.tensor([wall], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
@@ -253,12 +293,23 @@ def main():
     for _, env, _, _ in envs:
         assert bool(torch.isfinite(env.state).all()), 'non-finite state after the timed region'
     gathered_ok = None
+    rccl = None
     if gatherer is not None:
         g = gatherer.latest()
         gathered_ok = bool(g is not None and g.numel() == world * n and torch.isfinite(g).all())
+        times = gatherer.gather_times_us()[n_warm_gathers:]   # the collectives of the timed region, HIP events on the side stream
+        tmax = torch.tensor([max(times) if times else 0.0], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        rccl = {'backend': torch.distributed.get_backend(), 'world_size': torch.distributed.get_world_size(),
+                'ranks_seen': sorted(r for r, _, _ in ranks_seen), 'devices': [f'{r}:cuda:{lr}:{nm}' for r, lr, nm in sorted(ranks_seen)],
+                'gather_count': len(times), 'gather_every': gather_every, 'gather_bytes_per_rank': 4 * n,
+                'gather_us_max': float(tmax.item()), 'gather_us_median_rank0': float(sorted(times)[len(times) // 2]) if times else None,
+                'collective': 'all_gather_into_tensor of the episode returns on a side stream, off the step path'}
     if world > 1:  # all collectives are done: leave the group before rank 0 spends ~25 s of host time on the CPU baseline
+        wd.at('final barrier')
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    wd.at('report')
 
     if rank == 0:
         total_steps = world * n * args.steps
@@ -284,17 +335,22 @@ def main():
             'steady_state': args.warmup >= 50,
             'config': {'workload': f'{shard}, U(-1,1) actions pre-generated on device, auto-reset, max_episode_steps 2000',
                        'envs_per_gpu': n, 'global_envs': world * n,
-                       'substeps_per_step': 4, 'parallelism': f'env-sharded x{world}, no data-path collective; '
-                                                              f'RCCL all-gather of episode returns every {gather_every} steps'},
+                       'substeps_per_step': 4,
+                       'parallelism': 'one GPU, one process, no collective' if world == 1 else
+                                      f'env-sharded x{world} (one process per GPU), no data-path collective; all-gather of episode returns '
+                                      f'every {gather_every} steps on a side stream (see `rccl`)'},
             'roofline': roofline(dom_kind, dom_env.num_envs, launch_s),
         }
         if args.kind == 'mixed':
             out['roofline']['streams_ms_per_step'] = {k: ms / args.steps for (k, _, _, _), ms in zip(envs, dev_ms)}
         if gathered_ok is not None:
             out['config']['returns_gathered_ok'] = gathered_ok
+        if rccl is not None:
+            out['rccl'] = rccl
         if not args.no_cpu_baseline and world == 1:  # the CPU leg belongs to the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args.kind)
         print(json.dumps(out), flush=True)
+    wd.done()
 
 
 if __name__ == '__main__':

@@ -118,6 +118,7 @@ class ReturnGatherer:
         self.done_event = [None, None]
         self.k = 0          # launches so far
         self.last = None    # buffer index of the latest launch
+        self._timed = []    # (start, end) HIP events around every collective on the side stream: `gather_times_us()`
 
     def launch(self):
         b = self.k & 1
@@ -137,10 +138,21 @@ class ReturnGatherer:
         with torch.cuda.stream(self.stream):
             for ev in ready:
                 self.stream.wait_event(ev)
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(self.stream)
             all_gather_returns(self.local[b], self.world, self.out[b], counts=self.counts)
-            self.done_event[b] = torch.cuda.Event()
+            self.done_event[b] = torch.cuda.Event(enable_timing=True)
             self.done_event[b].record(self.stream)
+            self._timed.append((t0, self.done_event[b]))
         self.last = b
+
+    def gather_times_us(self):
+        """Duration of every collective launched so far, in microseconds, from HIP events on the side stream (waits for them)."""
+        out = []
+        for t0, t1 in self._timed:
+            t1.synchronize()
+            out.append(t0.elapsed_time(t1) * 1e3)
+        return out
 
     def latest(self):
         """The result of the most recent launch (waits for it); None before the first launch."""

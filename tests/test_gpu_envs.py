@@ -136,6 +136,23 @@ def test_bench_starts_two_ranks_from_a_bare_shell():
                        '--gather-every', '10', '--no-cpu-baseline'])
     assert out['n_gpus'] == 2 and out['config']['global_envs'] == 1024 and out['scaling'] == 'weak'
     assert out['config']['returns_gathered_ok'] is True and out['value'] > 0
+    # the N > 1 line proves what ran: backend, world size, every rank reported in, the timed region's collectives
+    r = out['rccl']
+    assert r['backend'] == 'gloo' and r['world_size'] == 2 and r['ranks_seen'] == [0, 1] and len(r['devices']) == 2
+    assert r['gather_count'] == 4 and r['gather_every'] == 10 and r['gather_us_max'] > 0 and r['gather_bytes_per_rank'] == 4 * 512
+    one = _bench_line(['--envs', '512', '--steps', '30', '--warmup', '5', '--no-cpu-baseline'])
+    assert 'rccl' not in one and one['config']['parallelism'] == 'one GPU, one process, no collective'   # nothing claimed that did not run
+
+
+def test_bench_watchdog_names_the_stage_a_rank_hangs_in():
+    """A rank that stops making progress exits 3 with the stage it hung in (here: a one-second limit that the run cannot meet)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs', '4096', '--steps', '200000', '--warmup', '5', '--no-cpu-baseline',
+                        '--watchdog', '8'], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3 and 'watchdog: rank 0 still in stage "timed region"' in p.stderr, (p.returncode, p.stderr[-500:])
 
 
 def test_gymnasium_adapter_on_a_real_batched_env():
