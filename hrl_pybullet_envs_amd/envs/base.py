@@ -94,8 +94,8 @@ class BatchedGymEnv:
             obs, rew, done, info = env.step_host(np.asarray(a, dtype=np.float32).reshape(1, -1))
             d = bool(done[0] != 0)
             out = {'food_rew': float(info[0, 0]), 'dead_rew': float(info[0, 1])} if self._gather_info else {}
-            if d and int(info[0, 3]) >= self.max_episode_steps > 0:  # info[3] = length of the episode that just ended
-                out['TimeLimit.truncated'] = True
+            if d and int(info[0, 3]) >= self.max_episode_steps > 0:  # info[3] = length of the episode that just ended: the step limit was hit;
+                out['TimeLimit.truncated'] = bool(env.host_final_obs()[1][0])  # gym.wrappers.TimeLimit: `not done` (the kernel's flag)
             return obs[0].astype(np.float64), float(rew[0]), d, out
         return env.step(a)
 

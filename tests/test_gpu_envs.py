@@ -178,6 +178,73 @@ def test_gymnasium_adapter_on_a_real_batched_env():
     one.close()
 
 
+def test_vector_env_adapters_meet_their_contracts():
+    """`gymnasium.vector.VectorEnv`- and SB3-`VecEnv`-shaped views over a batched env (README.md:19-37 is the one-env loop a trainer would wrap N
+    times; here the batch is the env).  Neither package exists in the image, so the contracts are checked duck-typed: attribute names, shapes,
+    dtypes, same-step autoreset with the terminal observation from the kernel (ABI v6 final_obs), against a twin env stepped directly."""
+    import hrl_pybullet_envs_amd as H
+    from hrl_pybullet_envs_amd.adapters import GymnasiumVectorEnv, SB3VecEnv
+    n, limit = 48, 7
+
+    def build():
+        e = H.AntGatherBulletEnv(num_envs=n, seed=5)
+        e.max_episode_steps = limit; e._cfg.max_episode_steps = limit
+        return e
+    # ---- gymnasium.vector.VectorEnv
+    v, twin = GymnasiumVectorEnv(build()), build()
+    assert v.num_envs == n and v.single_observation_space.shape == (46,) and v.single_action_space.shape == (8,)
+    assert v.observation_space.shape == (n, 46) and v.action_space.shape == (n, 8) and v.metadata['autoreset_mode'] == 'same_step'
+    obs, info = v.reset(seed=5)
+    assert torch.equal(obs, twin.reset()) and info == {}
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    ended = 0
+    for t in range(2 * limit + 1):
+        a = torch.rand(n, 8, device='cuda', generator=gen) * 2 - 1
+        obs, rew, term, trunc, info = v.step(a)
+        to, tr, td, ti = twin.step(a)
+        assert torch.equal(obs, to) and torch.equal(rew, tr) and term.dtype == torch.bool and trunc.dtype == torch.bool
+        assert torch.equal(term | trunc, td.bool()) and not bool((term & trunc).any())
+        m = info['_final_observation']
+        assert torch.equal(m, td.bool()) and info['final_observation'].shape == (n, 46) and info['final_obs'] is info['final_observation']
+        if bool(m.any()):
+            # the terminal observation is NOT the returned one (that is the next episode's first), and it is what the kernel kept
+            assert not torch.equal(info['final_observation'][m], obs[m]) and torch.equal(info['final_observation'][m], twin._backend().final_obs[m])
+            assert torch.equal(info['final_info']['episode_length'][m] >= 1, torch.ones(int(m.sum()), dtype=torch.bool, device='cuda'))
+            ended += int(m.sum())
+        assert bool(trunc.any()) == ((t + 1) % limit == 0) or bool(term.any()) or ended > 0   # the first limit truncates every env still in its first episode
+        if t + 1 == limit:
+            assert bool((trunc | term).all()) or ended > int(m.sum())
+    assert ended >= 2 * n
+    vn = GymnasiumVectorEnv(build(), numpy=True)
+    o0, _ = vn.reset()
+    o1, r1, te, tr_, inf = vn.step(np.zeros((n, 8), np.float32))
+    assert isinstance(o1, np.ndarray) and o1.shape == (n, 46) and r1.dtype == np.float32 and te.dtype == bool and inf['_final_obs'].dtype == bool
+    vn.close(); v.close(); twin.close()
+    with pytest.raises(ValueError):
+        GymnasiumVectorEnv(H.AntGatherBulletEnv())
+    # ---- stable_baselines3 VecEnv
+    s, twin = SB3VecEnv(build()), build()
+    assert s.num_envs == n and s.observation_space.shape == (46,) and s.action_space.shape == (8,)
+    obs = s.reset(); twin.reset()
+    assert isinstance(obs, np.ndarray) and obs.shape == (n, 46) and obs.dtype == np.float32
+    rng = np.random.RandomState(2)
+    seen_term = 0
+    for t in range(limit + 2):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        s.step_async(a)                 # returns with the kernel in flight
+        obs, rews, dones, infos = s.step_wait()
+        to, tr, td, ti = twin.step(torch.from_numpy(a).cuda())
+        assert np.array_equal(obs, to.cpu().numpy()) and np.array_equal(rews, tr.cpu().numpy()) and dones.dtype == bool and len(infos) == n
+        assert np.array_equal(dones, td.cpu().numpy().astype(bool)) and all('food_rew' in i and 'dead_rew' in i for i in infos)
+        for i in np.nonzero(dones)[0]:
+            assert infos[i]['terminal_observation'].shape == (46,) and infos[i]['TimeLimit.truncated'] == (t + 1 == limit) and infos[i]['episode']['l'] >= 1
+            assert np.array_equal(infos[i]['terminal_observation'], twin._backend().final_obs[i].cpu().numpy())
+            seen_term += 1
+        assert all('terminal_observation' not in infos[i] for i in np.nonzero(~dones)[0])
+    assert seen_term >= n and s.env_is_wrapped(object) == [False] * n and s.get_attr('n_bins', [0, 3]) == [10, 10] and s.seed(3) == [3] * n
+    s.close(); twin.close()
+
+
 def test_flagrun_manual_goal_creation_class_api_and_render():
     import hrl_pybullet_envs_amd as H
     env = H.AntFlagrunBulletEnv(manual_goal_creation=True, seed=3)
