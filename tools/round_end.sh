@@ -13,7 +13,7 @@ for k in gather flat point maze maze_mj flagrun; do
   bash tools/profile_round.sh gpurun_out/prof_${T}_$k $k $n > gpurun_out/prof_${T}_$k.log 2>&1 && echo profiled $k
 done
 # condense them where the bench runs, so that its line carries the counters of exactly these kernels; the files travel back under gpurun_out/
-R=${2:-r3}
+R=${2:-r4}
 for k in gather flat point maze maze_mj flagrun; do
   n=4096; [ $k = maze ] && n=8192
   name=${R}_$k; [ $k = gather ] && name=${R}_final

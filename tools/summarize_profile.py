@@ -21,13 +21,22 @@ def main():
     n_envs = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
     out_dir = os.path.join(ROOT, 'profiles')
     os.makedirs(out_dir, exist_ok=True)
+    WINDOW = 50  # launches of the timed region of tools/profile_round.sh (the settle steps before it are left out of every average)
     stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
-    kernel_us = None
+    kernel_us = kernel_us_all = None
+    trace = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_trace.csv'))
+    if trace:  # average duration of the last WINDOW k_step dispatches (the stats file averages over the settle steps too)
+        d = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(trace[0])) if 'k_step' in r['Kernel_Name']]
+        d = sorted(d)[-WINDOW:]
+        if d:
+            kernel_us = sum(e - s for s, e in d) / len(d) / 1e3
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         for r in rows:
             if 'k_step' in r['Name']:
-                kernel_us = float(r['AverageNs']) / 1e3
+                kernel_us_all = float(r['AverageNs']) / 1e3
+        if kernel_us is None:
+            kernel_us = kernel_us_all
         with open(os.path.join(out_dir, f'{tag}_kernel_stats.csv'), 'w') as f:
             w = csv.writer(f)
             w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
@@ -40,11 +49,14 @@ def main():
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 if 'k_step' in r['Kernel_Name']:
-                    acc[r['Counter_Name']].append(float(r['Counter_Value']))
+                    acc[r['Counter_Name']].append((int(r.get('Dispatch_Id', len(acc[r['Counter_Name']]))), float(r['Counter_Value'])))
             for k, v in acc.items():
+                v = [x for _, x in sorted(v)][-WINDOW:]  # dispatch order: the settled window
                 counters[k] = {'launches': len(v), 'mean_per_launch': sum(v) / len(v), 'mean_per_wave': sum(v) / len(v) / n_envs}
     meta = {'source': src, 'kernel': f'k_step<{kind}>', 'envs_per_launch': n_envs, 'source_sha256': kernel_source_hash(),
-            'command': 'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline',
+            'command': 'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 50 --warmup 300 --no-cpu-baseline; '
+                       'every figure = mean over the last 50 launches (the settled window)',
+            'kernel_us_window': kernel_us, 'kernel_us_all_launches': kernel_us_all,
             'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (rocprofv3); on gfx950 FETCH_SIZE is calibrated (x2) only for 16-B/lane '
                      'streams (MI355X_MICROARCH.md, HBM): the dword-per-lane scratch traffic and 4-B/lane record loads here are '
                      'reported uncorrected; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles',
