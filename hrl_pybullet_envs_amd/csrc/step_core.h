@@ -157,9 +157,6 @@ struct alignas(16) WaveLds {
 #ifdef HRL_WGTIME
     int dbg_rows; /* diagnostic build (tools/wg_times.py): solver rows | cube passes << 16 | self-contact substeps << 24, summed over the step */
 #endif
-#ifdef HRL_LDS_PAD
-    float pad_[HRL_LDS_PAD]; /* A/B builds (tools/variants.py): the stride between the four records of a group decides which LDS banks the leader's lanes of different envs hit */
-#endif
 };
 
 /* Per-lane registers that live across phases: the solver's working set.  On the GPU these are VGPRs (the row-space
