@@ -36,7 +36,11 @@ class GymnasiumAdapter:
             truncated = bool(info.get('TimeLimit.truncated', False))
             return obs, rew, bool(done) and not truncated, truncated, info
         d = done.bool()
-        truncated = info['TimeLimit.truncated'].bool()  # from the kernel: ended by the step limit alone (gym TimeLimit: `not done`)
+        if 'TimeLimit.truncated' in info:   # from the kernel: ended by the step limit alone (gym TimeLimit: `not done`)
+            truncated = info['TimeLimit.truncated'].bool()
+        else:                               # an old-gym shaped env without the flag: the episode length reached the limit
+            limit = getattr(self.env, 'max_episode_steps', 0)
+            truncated = d & (info['episode_length'] >= limit) if limit > 0 else d & False
         return obs, rew, d & ~truncated, truncated, info
 
     def close(self):

@@ -140,6 +140,16 @@ def test_gymnasium_adapter_five_tuple():
     assert o[1][2].tolist() == [False, True] and o[1][3].tolist() == [False, False]   # env 1 terminated at t=2
     assert o[4][2].tolist() == [False, False] and o[4][3].tolist() == [True, False]   # env 0 truncated at the limit
 
+    class WithFlag(Fake):  # the batched envs of this package hand the kernel's flag over: it wins over the length heuristic
+        def step(self, a):
+            ob, r, done, info = super().step(a)
+            info['TimeLimit.truncated'] = torch.tensor([0, 0], dtype=torch.uint8)   # e.g. died exactly at the limit: not a truncation
+            return ob, r, done, info
+    gf = GymnasiumAdapter(WithFlag(2))
+    gf.reset()
+    o = [gf.step(None) for _ in range(5)]
+    assert o[4][2].tolist() == [True, False] and o[4][3].tolist() == [False, False]
+
 
 def test_bench_spawns_its_own_ranks(monkeypatch):
     """bench.py --gpus N without WORLD_SIZE starts the N ranks itself (torch.distributed.run on 127.0.0.1) before it
