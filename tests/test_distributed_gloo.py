@@ -38,6 +38,7 @@ def _worker(rank, world, port, total, steps, out_dir):
     if r == 0:
         np.save(os.path.join(out_dir, 'gathered.npy'), gathered.numpy())
     np.save(os.path.join(out_dir, f'state{r}.npy'), env.state)
+    np.save(os.path.join(out_dir, f'final{r}.npy'), np.concatenate([env.final_obs, env.truncated[:, None].astype(np.float32)], axis=1))
     dist.destroy_process_group()
 
 
@@ -59,4 +60,6 @@ def test_two_rank_sharding_matches_single_process(tmp_path, total):
         full.step(acts[t])
     st = np.concatenate([np.load(tmp_path / f'state{r}.npy') for r in range(world)])
     assert np.array_equal(st, full.state)
+    fin = np.concatenate([np.load(tmp_path / f'final{r}.npy') for r in range(world)])   # terminal observations (the 20-step limit has passed) + last truncation flags
+    assert np.array_equal(fin[:, :-1], full.final_obs) and np.array_equal(fin[:, -1], full.truncated) and np.any(full.final_obs != 0)
     assert np.array_equal(np.load(tmp_path / 'gathered.npy'), full.info[:, 2])

@@ -33,7 +33,8 @@ class GpuSide:
 
     def outputs(self):
         g = self.g
-        return {k: v.cpu().numpy() for k, v in dict(state=g.state, items=g.items, aux=g.aux, obs=g.obs, rew=g.reward, done=g.done, info=g.info).items()}
+        return {k: v.cpu().numpy() for k, v in dict(state=g.state, items=g.items, aux=g.aux, obs=g.obs, rew=g.reward, done=g.done, info=g.info,
+                                                     final_obs=g.final_obs, truncated=g.truncated).items()}
 
 
 class EmuSide:
@@ -50,7 +51,7 @@ class EmuSide:
 
     def outputs(self):
         e = self.e
-        return dict(state=e.state, items=e.items, aux=e.aux, obs=e.obs, rew=e.rew, done=e.done, info=e.info)
+        return dict(state=e.state, items=e.items, aux=e.aux, obs=e.obs, rew=e.rew, done=e.done, info=e.info, final_obs=e.final_obs, truncated=e.truncated)
 
 
 def run(Side, kind, seed, auto_reset, n=48, T=10, kw=None):
@@ -74,12 +75,12 @@ def run(Side, kind, seed, auto_reset, n=48, T=10, kw=None):
                     idx = 15 + rng.randint(0, nv)
                     if idx >= 21 and np.isfinite(v) and abs(v) > 100: v = np.float32(100.0 * np.sign(v))  # joint rates leave a step clamped
                     o.state[r, idx] = v
-                elif what == 2 and kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER): o.items[r, rng.randint(0, 32)] = v
+                elif what == 2 and kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER): o.items[r, rng.randint(0, o.items.shape[1])] = v
                 else: a[r, rng.randint(0, o.ad)] = v
         pre = o.state.copy()
         s.step(o, a); o.step(a)
         out = s.outputs()
-        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
+        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info', 'final_obs', 'truncated'):
             A, B = getattr(o, name).reshape(n, -1), out[name].reshape(n, -1)
             ok = (A == B) | ((A != A) & (B != B))
             if not ok.all():
@@ -101,6 +102,14 @@ MATRIX = [  # non-default branches (the CONFIG_MATRIX of the parity tests), fuzz
     (K.HRL_ANT_FLAGRUN, dict(flag_max_targets=0, flag_max_target_dist=2.5, flag_timeout=6, flag_size=3.0, world_size=(5.0, 5.0), centroid_static_sum=(-2.5, 0.0))),
     (K.HRL_ANT_FLAGRUN, dict(flag_enclosed=0, centroid_n_static=1, centroid_static_sum=(0.0, 0.0), flag_timeout=8, flag_max_targets=5)),
     (K.HRL_ANT_FLAGRUN, dict(flag_switch_on_collision=0, flag_timeout=7, flag_max_targets=4)),
+    # beyond the capacity caps of ABI <= 5 (more than 16 / 48 items, observations wider than the wave, many targets) and with a step limit short
+    # enough that truncations, terminal observations and in-kernel resets happen inside the 10 fuzzed steps
+    (K.HRL_ANT_GATHER, dict(n_food=20, n_poison=12, n_bins=24, max_episode_steps=4)),
+    (K.HRL_POINT_GATHER, dict(n_food=40, n_poison=24, n_bins=30, robot_coll_dist=-1.0, max_episode_steps=3)),
+    (K.HRL_ANT_GATHER, dict(n_food=40, n_poison=24, n_bins=64, robot_coll_dist=0.0, max_episode_steps=5)),
+    (K.HRL_ANT_MAZE_MJ, dict(n_bins=64, max_episode_steps=4)),
+    (K.HRL_ANT_MAZE, dict(sense_target=1, n_bins=33, targets=[(-2.0 + 0.5 * i, -4.0 + 0.1 * i) for i in range(12)], max_episode_steps=3)),
+    (K.HRL_ANT_FLAGRUN, dict(use_sensor=1, n_bins=40, flag_timeout=2, flag_max_targets=2, max_episode_steps=6)),
 ]
 
 
