@@ -548,59 +548,58 @@ HRL_DEV void phase_base(WaveLds &L, const LaneRegs &g, int lane) {
     }
 }
 
-/* Phase V (dof map): forward pass of the lane's leg, then the unconstrained velocity update into the lane register. */
+/* Phase V (dof map): forward pass of the lane's leg, then the unconstrained velocity update into the lane register.
+ * Written without branches: every lane runs the joint recursion of ITS leg (the lanes of the torso dofs and the padding lanes that of leg 0,
+ * discarded) and picks its value at the end, so every LDS address is known at the top and the loads are one round trip -- as four nested
+ * divergent paths (torso angular / torso linear / hip / ankle) the phase was 185 instructions and four dependent LDS round trips on the
+ * leader's stream.  Per value the operations are unchanged. */
 HRL_DEV float phase_forward_vel(const DevCfg &c, const WaveLds &L, int lane) {
-    const int d = lane & 15;
-    float a0[6];
+    const int d = lane & 15, jd = d - 6;
+    const int j = jd < 0 ? 0 : (jd > 7 ? 7 : jd), jh = j & ~1, ja = jh + 1;
+    float a0[6], ap[6], ax_[6], wxv[3];
 #pragma unroll
     for (int k = 0; k < 6; ++k) a0[k] = L.a0[k];
-    if (d < 3) return fma_(c.h, a0[d], L.u[d]);
-    if (d < 6) {
-        float wxv[3];
-        cross3(wxv, L.u, L.u + 3);
-        return fma_(c.h, a0[d] + wxv[d - 3], L.u[d]);
-    }
-    if (d >= 14) return 0.f;
-    const int j = d - 6, jh = j & ~1, ja = jh + 1;
-    float ap[6], ax_[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ap[k] = a0[k] + L.cb[jh][k];
-    float qddh = (L.uterm[jh] - dot6(L.U[jh], ap)) * L.invD[jh];
-    if (j == jh) return fma_(c.h, qddh, L.u[d]);
+    const float qddh = (L.uterm[jh] - dot6(L.U[jh], ap)) * L.invD[jh];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ax_[k] = fma_(L.S[jh][k], qddh, ap[k]) + L.cb[ja][k];
-    float qdda = (L.uterm[ja] - dot6(L.U[ja], ax_)) * L.invD[ja];
-    return fma_(c.h, qdda, L.u[d]);
+    const float qdda = (L.uterm[ja] - dot6(L.U[ja], ax_)) * L.invD[ja];
+    cross3(wxv, L.u, L.u + 3);
+    const float a0d = L.a0[d < 6 ? d : 0];
+    const float lin = d == 4 ? wxv[1] : (d == 5 ? wxv[2] : wxv[0]);
+    const float acc = d < 3 ? a0d : (d < 6 ? a0d + lin : ((jd & 1) ? qdda : qddh));
+    const float r = fma_(c.h, acc, L.u[d]);
+    return d >= 14 ? 0.f : r;
 }
 
 /* velocity response du = M^-1 (generalized impulse) through the articulated-body quantities in LDS */
 HRL_DEV void response(const WaveLds &L, const float *phi, int level, int leg, float th, float ta, float *du) {
     const int jh = 2 * leg, ja = jh + 1;
-    float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ua = ta, uh = th;
-    if (level == 2) {
+    /* the lanes of a wave hold rows of all three levels: written with selects instead of three divergent branches (which ran one after the
+       other, each with its loads inside), so that every LDS address is known at the top; per value the operations are the ones of the branches */
+    float p[6], ua = ta, uh = th;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p[k] = -phi[k];
-        ua = ta - dot6(L.S[ja], p);
+    for (int k = 0; k < 6; ++k) p[k] = level == 2 ? -phi[k] : 0.f;
+    {
+        const float ua2 = ta - dot6(L.S[ja], p);
+        ua = level == 2 ? ua2 : ta;
     }
     {
         float s = ua * L.invD[ja];
 #pragma unroll
         for (int k = 0; k < 6; ++k) p[k] = fma_(L.U[ja][k], s, p[k]);
     }
-    if (level == 1) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
-    }
+    for (int k = 0; k < 6; ++k) { const float pm = p[k] - phi[k]; p[k] = level == 1 ? pm : p[k]; }
     uh = th - dot6(L.S[jh], p);
     {
         float s = uh * L.invD[jh];
 #pragma unroll
         for (int k = 0; k < 6; ++k) p[k] = fma_(L.U[jh][k], s, p[k]);
     }
-    if (level == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p[k] = p[k] - phi[k];
-    }
+    for (int k = 0; k < 6; ++k) { const float pm = p[k] - phi[k]; p[k] = level == 0 ? pm : p[k]; }
     float dv0[6];
     ldl6_solve(dv0, L.Lb, L.idb, p);
 #pragma unroll
@@ -751,33 +750,38 @@ HRL_DEV void phase_build_row(const DevCfg &c, WaveLds &L, LaneRegs &g, int lane,
         g.bias = 0.f; g.fn = -1; g.lam = 0.f; g.lo = 0.f; g.hi = 0.f;
         return;
     }
-    /* limit rows and contact rows only differ in their impulse (phi / joint impulse) and parameters: those are set
-     * in the (divergent) branches, the expensive impulse response is computed once, outside them */
-    float phi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, th = 0.f, ta = 0.f;
-    int level = 0, leg = 0;
-    if (row_id < nL) {
-        const int j = L.ljoint[row_id];
-        const float sgn = L.lsign[row_id], dist = L.ldist[row_id];
-        leg = j >> 1; th = (j & 1) ? 0.f : sgn; ta = (j & 1) ? sgn : 0.f;
-        Jh = th; Ja = ta; /* J = +-e_j */
-        bias = (dist > 0.f ? dist : c.erp_l * dist) * c.inv_h;
-        hi = c.limp_max;
-    } else {
-        const int row = row_id - nL;
+    /* limit rows and contact rows only differ in their impulse (phi / joint impulse) and parameters.  Both kinds sit in one wave, so the two
+     * descriptions are read side by side with indices every lane can use (a limit lane reads contact 0, a contact lane limit 0: in bounds,
+     * never used) and picked by selects: one LDS round trip for the lists, one for the joint axes of the row's leg -- as two divergent branches
+     * the wave ran both one after the other, each waiting for its own loads.  Per value the operations are the ones of the branches. */
+    float phi[6], th, ta;
+    int level, leg;
+    {
+        const bool is_lim = row_id < nL;
+        const int li = is_lim ? row_id : 0, row = is_lim ? 0 : row_id - nL;
         const int ci = row < nC ? row : (row - nC) >> 1, which = row < nC ? 0 : 1 + ((row - nC) & 1);
+        const int j = L.ljoint[li] & 7, link = L.clink[ci];
+        const float sgn = L.lsign[li], ldist = L.ldist[li], cdist = L.cdist_[ci], cmu = L.cmu[ci];
         const float r[3] = {L.cr[ci][0], L.cr[ci][1], L.cr[ci][2]};
         const float d[3] = {L.cdir[which][ci][0], L.cdir[which][ci][1], L.cdir[which][ci][2]}; /* the row's direction */
-        cross3(phi, r, d);
+        float cphi[6];
+        cross3(cphi, r, d);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) phi[3 + k] = d[k];
-        level = L.clink[ci] & 3; leg = L.clink[ci] >> 2;
-        const float jh = dot6(phi, L.S[2 * leg]), ja = dot6(phi, L.S[2 * leg + 1]);
-        Jh = level >= 1 ? jh : 0.f; Ja = level >= 2 ? ja : 0.f; /* J = [phi | phi.S on the joints between torso and body] */
-        if (which == 0) {
-            const float dist = L.cdist_[ci];
-            bias = (dist > 0.f ? dist : c.erp_c * dist) * c.inv_h;
-            hi = 1e30f;
-        } else { bias = 0.f; frn = nL + ci; mu = L.cmu[ci]; }
+        for (int k = 0; k < 3; ++k) cphi[3 + k] = d[k];
+        level = is_lim ? 0 : (link & 3);
+        leg = (is_lim ? (j >> 1) : (link >> 2)) & 3;
+        const float jh = dot6(cphi, L.S[2 * leg]), ja = dot6(cphi, L.S[2 * leg + 1]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) phi[k] = is_lim ? 0.f : cphi[k];
+        th = is_lim ? ((j & 1) ? 0.f : sgn) : 0.f; ta = is_lim ? ((j & 1) ? sgn : 0.f) : 0.f;
+        Jh = is_lim ? th : (level >= 1 ? jh : 0.f); /* limit: J = +-e_j; contact: J = [phi | phi.S on the joints between torso and body] */
+        Ja = is_lim ? ta : (level >= 2 ? ja : 0.f);
+        const float blim = (ldist > 0.f ? ldist : c.erp_l * ldist) * c.inv_h, bnor = (cdist > 0.f ? cdist : c.erp_c * cdist) * c.inv_h;
+        const bool normal = !is_lim & (which == 0), fric = !is_lim & (which != 0);
+        bias = is_lim ? blim : (normal ? bnor : 0.f);
+        hi = is_lim ? c.limp_max : (normal ? 1e30f : 0.f);
+        frn = fric ? nL + ci : -1;
+        mu = fric ? cmu : 0.f;
     }
     response(L, phi, level, leg, th, ta, B);
     if (active) {

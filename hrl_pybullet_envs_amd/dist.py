@@ -5,6 +5,7 @@ needs no exchange.  RNG streams are keyed by GLOBAL env id (hrl_config.env_id_of
 independent of the number of ranks.  The only collective is an all-gather of per-env episode returns
 (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests), issued on a side stream off the step path.
 """
+import collections
 import os
 
 import torch
@@ -118,7 +119,7 @@ class ReturnGatherer:
         self.done_event = [None, None]
         self.k = 0          # launches so far
         self.last = None    # buffer index of the latest launch
-        self._timed = []    # (start, end) HIP events around every collective on the side stream: `gather_times_us()`
+        self._timed = collections.deque(maxlen=4096)  # (start, end) HIP events around the latest collectives on the side stream: `gather_times_us()`
 
     def launch(self):
         b = self.k & 1
@@ -147,7 +148,7 @@ class ReturnGatherer:
         self.last = b
 
     def gather_times_us(self):
-        """Duration of every collective launched so far, in microseconds, from HIP events on the side stream (waits for them)."""
+        """Duration of the collectives launched so far (the latest 4096), in microseconds, from HIP events on the side stream (waits for them)."""
         out = []
         for t0, t1 in self._timed:
             t1.synchronize()
