@@ -134,7 +134,7 @@ struct alignas(16) WaveLds {
     int aux[4];
     float q[2][16];      /* ping-pong: substep s reads q[s&1], writes q[(s+1)&1] */
     float u[16], tau[8];
-    float XYZ[12];
+    float XYZ[12];       /* point bot: the columns of its rotation matrix */
     float ph[4][4], pa[4][4], tip[4][4];
     float S[NJ][8], U[NJ][8], cb[NJ][8];
     float invD[NJ], uterm[NJ];
@@ -457,12 +457,6 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
     /* one destination at a time: stores to consecutive addresses that follow each other merge into wide LDS writes */
     /* (the leg points ph / pa / tip are not published here: their only readers, the collision passes and the parts centroid, take
      * them from a POS_ONLY pass of their own -- ant_contacts runs on another wave at the same time as this phase) */
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.XYZ[k] = X[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.XYZ[3 + k] = Y[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) L.XYZ[6 + k] = Z[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) L.S[jh][k] = Sh[k];
 #pragma unroll
@@ -1403,8 +1397,10 @@ HRL_DEV void ant_env_block(X &x, const DevCfg &c, int qi) {
     WaveLds &L = x.lds();
     x.refresh();
     const int nC = x.uniform(L.nC), nL = x.uniform(L.nL), nS = x.uniform(L.nS);
-    x.each([&](int lane) { x.reg(lane).ud = L.ustar[lane & 15]; }); /* the velocity if no row turns up */
-    x.each([&](int lane) { phase_build_row(c, L, x.reg(lane), lane, nL, nC); });
+    x.each([&](int lane) {
+        x.reg(lane).ud = L.ustar[lane & 15]; /* the velocity if no row turns up */
+        phase_build_row(c, L, x.reg(lane), lane, nL, nC);
+    });
     if (nS > 0) x.each([&](int lane) { phase_self_rows(c, L, x.reg(lane), lane, nL, nC); });
     x.stamp(7);
     pgs_solve(x, c, nL, nC, true, nS > 0);
