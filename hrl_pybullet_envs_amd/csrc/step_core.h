@@ -101,7 +101,7 @@ struct DevBufs {
     unsigned long long *stamps; /* diagnostic builds only (tools/stamp_profile.py): per-phase cycle sums */
 };
 
-/* Per-wave LDS record ("LDS-staged link/joint state"), 6.3 KB, 16-byte aligned (wide LDS accesses).  Three users with disjoint lifetimes share the first
+/* Per-wave LDS record ("LDS-staged link/joint state"), 7.4 KB, 16-byte aligned (wide LDS accesses).  Three users with disjoint lifetimes share the first
  * block: the K1 -> K2 hand-off of a substep, the velocity responses B of the solver rows (written in phase R1, read
  * until the end of the substep) and the task scratch of the epilogue (observation packing, after the substeps). */
 struct alignas(16) WaveLds {
