@@ -476,3 +476,44 @@ def test_step_host_equals_the_device_path():
         b_env.step_host(a); a_env.step(torch.from_numpy(a).cuda())
         assert torch.equal(a_env.reset(), b_env.reset())
         a_env.close(); b_env.close()
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI (include/hrl_envs.h), not a Python extension: tests/c_abi/abi_demo.c -- plain C, gcc, hipMalloc'ed buffers, no torch
+    in the process -- creates envs, resets, steps them on its own stream and dumps what the library left in the buffers; the CPU oracle fed the same
+    LCG actions must agree bit for bit, terminal observations and truncation flags included (40-step limit: every env is reset on the way)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, 'tests', 'c_abi')
+    subprocess.check_call(['make', '-s', '-C', d, 'abi_demo'])
+    n, steps, seed = 96, 60, 7
+    for kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER, K.HRL_ANT_MAZE):
+        out = str(tmp_path / f'k{kind}.bin')
+        p = subprocess.run([os.path.join(d, 'abi_demo'), str(kind), str(n), str(steps), str(seed), out], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1000:]
+        assert 'hip-gfx950' in p.stdout
+        o = orc.OracleEnv(orc.default_config(kind, num_envs=n, seed=seed, auto_reset=1, max_episode_steps=40), np.float32)
+        o.reset()
+        lcg, mask = 0x9E3779B97F4A7C15, (1 << 64) - 1
+        for t in range(steps):
+            a = np.empty(n * o.ad, np.float32)
+            for i in range(n * o.ad):
+                lcg = (lcg * 6364136223846793005 + 1442695040888963407) & mask
+                a[i] = np.float32(float(lcg >> 11) * (2.0 / 9007199254740992.0) - 1.0)
+            o.step(a.reshape(n, o.ad))
+        raw = open(out, 'rb').read()
+        off = 0
+
+        def take(count, dtype):
+            nonlocal off
+            arr = np.frombuffer(raw, dtype=dtype, count=count, offset=off)
+            off += arr.nbytes
+            return arr
+        st = take(n * 32, np.float32).reshape(n, 32); it = take(n * o.items.shape[1], np.float32).reshape(n, -1)
+        aux = take(n * 4, np.int32).reshape(n, 4); ob = take(n * o.od, np.float32).reshape(n, o.od)
+        rew = take(n, np.float32); done = take(n, np.uint8); fin = take(n * o.od, np.float32).reshape(n, o.od); trunc = take(n, np.uint8)
+        assert off == len(raw)
+        assert np.array_equal(st, o.state) and np.array_equal(it, o.items) and np.array_equal(aux, o.aux), kind
+        assert np.array_equal(ob, o.obs, equal_nan=True) and np.array_equal(rew, o.rew) and np.array_equal(done, o.done), kind
+        assert np.array_equal(fin, o.final_obs, equal_nan=True) and np.array_equal(trunc, o.truncated) and np.any(fin != 0), kind
