@@ -1824,20 +1824,27 @@ HRL_DEV void phase_items(const DevCfg &c, WaveLds &L, int lane, long long env, b
                 bin = (float)b; inten = 1.0f - d2 / c.sensor_range;
             }
         }
-        if (pickups && !(c.coll_dist > 0.f)) {
+        if (pickups && !(c.coll_dist > 0.f)) { /* the item itself moves after the observation has been packed (phase_items_contact_move) */
             int hits = 0;
             for (int i = 0; i < n_contacts; ++i) hits += L.csurf[i] == surf_item(lane) ? 1 : 0;
-            if (hits > 0) {
-                rew = (lane < c.n_food ? 1.f : -1.f) * (float)hits;
-                /* the reference moves the item once per contact point (gather_scene.py:95-114); the moves are independent
-                 * draws, keyed item | move << 4 (<< 6 with more than 16 items), so the last one is where it ends up */
-                if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane | ((hits - 1) << c.item_shift), rx, ry, &ix, &iy);
-                else { ix = 100.f; iy = 0.f; }
-                L.items[2 * lane] = ix; L.items[2 * lane + 1] = iy;
-            }
+            rew = (lane < c.n_food ? 1.f : -1.f) * (float)hits;
         }
     }
     L.irew[lane] = rew; L.ibin[lane] = bin; L.iint[lane] = inten;
+}
+
+/* robot_coll_dist <= 0: an item the robot touched moves once the observation is packed -- get_food_obs (ant_gather_env.py:95-96) reads the
+ * item positions before reward_collision (:113-116) moves them, which shows where the observation holds positions (get_abs_pos).  The
+ * reference moves the item once per contact point (gather_scene.py:95-114); the moves are independent draws, keyed item | move << 4 (<< 6 with
+ * more than 16 items), so the last one is where it ends up.  The number of contact points is |L.irew|. */
+HRL_DEV void phase_items_contact_move(const DevCfg &c, WaveLds &L, int lane, long long env) {
+    if (lane >= c.n_food + c.n_poison) return;
+    const int hits = (int)fabsf(L.irew[lane]);
+    if (hits > 0) {
+        float ix = 100.f, iy = 0.f;
+        if (c.respawn) respawn_item(c, env, (uint32_t)L.aux[1], 0u, lane | ((hits - 1) << c.item_shift), L.st[0], L.st[1], &ix, &iy);
+        L.items[2 * lane] = ix; L.items[2 * lane + 1] = iy;
+    }
 }
 
 /* Phase O3: final observation vector into L.obs, non-finite flag into L.flags[0] */
@@ -1970,6 +1977,7 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode, i
        packing code: a wave-uniform loop that the default configs run once) */
 #pragma unroll 1
     for (int o = 0; o < c.obs_dim; o += 64) x.each([&](int lane) { phase_pack_obs<KIND>(c, L, lane + o, mtx, mty); });
+    if ((KIND == 1 || KIND == 3) && step_mode && !(c.coll_dist > 0.f)) x.each([&](int lane) { phase_items_contact_move(c, L, lane, env); });
 }
 
 /* ================================================================================================= RESET / STEP */

@@ -253,7 +253,7 @@ def test_item_cubes_collide_and_contact_pickup(kind):
     them, and with robot_coll_dist <= 0 every contact point with a cube pays +-1 and moves it (ant_gather_env.py:113-116).
     Both lane orders of the wave phases equal the oracle bit for bit."""
     n = 32
-    for kw in (dict(), dict(robot_coll_dist=0.0)):
+    for kw in (dict(), dict(robot_coll_dist=0.0), dict(robot_coll_dist=0.0, use_sensor=0)):
         cfg = orc.default_config(kind, num_envs=n, seed=13, auto_reset=1, **kw)
         (o, e), er = both(cfg), emu_env.EmuEnv(cfg, reverse=True)
         o.reset(); e.reset(); er.reset()
@@ -279,6 +279,12 @@ def test_item_cubes_collide_and_contact_pickup(kind):
             o.step(a); e.step(a); er.step(a)
             same(o, e, t); same(e, er, (t, 'lane order'))
             paid += int((o.info[:, 0] != 0).sum()); touched += int(np.any(o.items != it0, axis=1).sum())
+            if 'use_sensor' in kw:  # get_food_obs (ant_gather_env.py:95-96) ran before reward_collision (:113-116) moved the cubes: old positions
+                live = np.isfinite(o.obs).all(axis=1) & (o.done == 0)
+                m, nb = min(8, cfg.n_bins), o.od - 4 * min(8, cfg.n_bins)
+                for i in np.nonzero(live)[0]:
+                    old = it0[i, :16].reshape(8, 2)
+                    assert all(any(np.array_equal(f, q) for q in old) for f in e.obs[i, nb:nb + 2 * m].reshape(m, 2)), (t, i)
         if kw:
             assert paid > 20 and touched > 20, (paid, touched)
     # the cubes matter to the physics: the same rollout without them diverges
@@ -749,3 +755,21 @@ def test_next_target_pops_the_shared_list_of_a_non_manual_env():
     a = np.zeros((n, 8), np.float32)
     o.step(a); e.step(a)
     same(o, e, 'step')
+
+
+def test_random_legal_configs():
+    """tools/fuzz_configs.py, a slice of it: every constructor argument and engine parameter drawn at random (biased to the edges of the capacity
+    ranges), teleports / masked resets / manual goals between the steps; the wave phases equal the oracle bit for bit after every step.
+    (This fuzzer is what found that with robot_coll_dist <= 0 and use_sensor=0 the observation held the positions of touched items AFTER their
+    move; the hand-picked matrix had both branches, never together.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_configs as F
+    ended = 0
+    for seed in range(5000, 5016):
+        for kind in F.KINDS:
+            r, e = F.run(F.EmuSide, kind, seed * 16 + kind, 25)
+            assert r is None, r
+            ended += e
+    assert ended > 1000

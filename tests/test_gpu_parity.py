@@ -439,15 +439,17 @@ def test_non_default_configs_match_oracle(kind, n, kw):
     assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux)
 
 
+@pytest.mark.parametrize('use_sensor', [1, 0])
 @pytest.mark.parametrize('kind', [K.HRL_ANT_GATHER, K.HRL_POINT_GATHER])
-def test_contact_pickup_on_item_cubes(kind):
+def test_contact_pickup_on_item_cubes(kind, use_sensor):
     """robot_coll_dist <= 0 (ant_gather_env.py:113-116): robots teleported onto / next to cubes touch them, are paid +-1 per
-    contact point and the cube moves; device == oracle bit for bit (identical inputs every step)."""
+    contact point and the cube moves; device == oracle bit for bit (identical inputs every step).  The observation was taken before
+    the cube moved (:95-96 precede :113): with use_sensor=0 it holds the positions the items had when the step began."""
     n = 256
-    g, o = make(kind, n, seed=13, robot_coll_dist=0.0)
+    g, o = make(kind, n, seed=13, robot_coll_dist=0.0, use_sensor=use_sensor)
     g.reset(); o.reset()
     rng = np.random.RandomState(2)
-    paid = 0
+    paid = moved = 0
     for t in range(25):
         k = rng.randint(0, 16, n)
         off = rng.uniform(-1.0, 1.0, (n, 2)).astype(np.float32) * (1.4 if kind == K.HRL_ANT_GATHER else 0.45)
@@ -465,13 +467,22 @@ def test_contact_pickup_on_item_cubes(kind):
             o.state[:, 3:7] = quat.astype(np.float32); o.state[:, 2] = 0.35; o.state[:, 7:13] = 0
         push(g, o)
         a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
+        it0 = o.items.copy()
         go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
         assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(g.items.cpu().numpy(), o.items), t
         assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(g.info.cpu().numpy(), o.info) and np.array_equal(gd.cpu().numpy(), o.done), t
         fin = np.isfinite(o.obs).all(axis=1)
         assert obs_bad_rows(go.cpu().numpy()[fin], o.obs[fin]).sum() == 0
         paid += int((o.info[:, 0] != 0).sum())
+        if not use_sensor:   # 8 + 8 items, 10 / 5 slots per type: the food slots hold the nearest foods' OLD positions, whether or not they moved
+            live = fin & (o.done == 0)
+            nb = o.od - 2 * 2 * min(8, o.cfg.n_bins)
+            food = go.cpu().numpy()[live, nb:nb + 2 * min(8, o.cfg.n_bins)].reshape(live.sum(), -1, 2)
+            old = it0[live, :16].reshape(live.sum(), 8, 2)
+            assert all(any(np.array_equal(f, q) for q in old[i]) for i in range(len(food)) for f in food[i]), t
+            moved += int((np.any(it0[live, :16] != o.items[live, :16], axis=1)).sum())
     assert paid > 150, paid
+    assert use_sensor or moved > 40, moved
 
 
 def test_self_collision_rows_on_device():
@@ -752,3 +763,16 @@ def test_manual_goal_lists_longer_than_15_through_the_c_abi():
             assert np.array_equal(g.items.cpu().numpy(), o.items) and np.array_equal(g.aux.cpu().numpy(), o.aux), t
             assert np.array_equal(g.state.cpu().numpy(), o.state) and obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0, t
     assert np.array_equal(gd.cpu().numpy(), o.done) and (o.done | (o.aux[:, 2] > 1)).all()   # every list ran out
+
+
+def test_random_legal_configs_on_device():
+    """tools/fuzz_configs.py on the device: 600 random legal configs (constructor arguments, engine parameters, env counts that leave parked
+    waves, global ids beyond 2^32) x 30 steps with teleports, masked resets, manual goals in between; every buffer equals the oracle's bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_configs as F
+    for seed in range(7000, 7100):
+        for kind in F.KINDS:
+            r, _ = F.run(F.GpuSide, kind, seed * 16 + kind, 30)
+            assert r is None, r
