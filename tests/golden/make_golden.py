@@ -855,6 +855,101 @@ def main():
         big['maze_mj_step'].append(dict(maze_mj_case(700 + k, n_bins=64), n_bins=64))
     G['big_config'] = big
 
+    # ---------------------------------------------------------------- random constructor arguments, whole task half of step()
+    # ant_gather_env.py:76-119 / gather_base.py:74-109 with EVERY constructor argument drawn at random (n_food, n_poison, n_bins, use_sensor,
+    # robot_coll_dist of either sign, respawn, world size, spacing, sensor span / range, dying cost), the robot next to an item, for the contact
+    # mode a random list of touched bodies: the combinations of branches the fixtures above take one at a time (its own RandomStates again).
+    def f32(x):
+        return float(np.float32(x))
+
+    def random_gather_case(k):
+        lrs = np.random.RandomState(23000 + k)
+        cls = AntGatherBulletEnv if lrs.rand() < 0.6 else GatherBulletEnv
+        ant = cls is AntGatherBulletEnv
+        total = int(lrs.choice([1, 2, 7, 8, 15, 16, 17, 24, 33, 48, 49, 64]))
+        n_food = int(lrs.randint(0, total + 1)) if lrs.rand() < 0.8 else int(lrs.choice([0, total]))
+        n_poison = total - n_food
+        n_bins = int(lrs.choice([1, 2, 3, 5, 10, 16, 17, 24, 33, 64]))
+        use_sensor = bool(lrs.rand() < 0.5)
+        coll = float(lrs.choice([1.0, 1.0, 0.3, 4.0, 0.0, -1.0]))
+        respawn = bool(lrs.rand() < 0.7)
+        # the C-ABI carries these as fp32: draw values fp32 holds exactly (pi and 2 pi are recognised by the config, as in the other fixtures)
+        world = (f32(lrs.uniform(6, 24)), f32(lrs.uniform(6, 24)))
+        spacing = f32(lrs.uniform(0.3, min(world) / 3.2))
+        span = float(lrs.choice([np.pi, 2 * np.pi, f32(lrs.uniform(0.3, 6.5))]))
+        srange = float(lrs.choice([2.0, 9.0, 20.0, 60.0]))
+        dying_cost = float(lrs.choice([-10.0, 0.0, -1.5, 3.0]))
+        sc = GatherScene(None, 9.8, 0.0165 / 4, 4, world, n_food, n_poison, spacing, respawn)
+        sc.rs = LoggingRS(23500 + k)
+        sc.loaded = True
+        cl = FakeClient()
+        sc._p = cl
+        sc.episode_restart(cl)
+        n_restart = len(sc.rs.log)
+        items0 = [list(sc.all_items[i]) for i in sc.all_items]
+        ids = list(sc.all_items.keys())
+        tgt = sc.all_items[ids[lrs.randint(0, total)]]
+        xy = np.array(tgt[:2]) + lrs.uniform(-1.2, 1.2, 2)
+        z = 0.2 if k % 17 == 0 else lrs.uniform(0.3, 0.9)
+        rpy = [lrs.uniform(-.3, .3), lrs.uniform(-.3, .3), lrs.uniform(-np.pi, np.pi)]
+        body = Body([xy[0], xy[1], z], rpy)
+        st = lrs.uniform(-1, 1, 28 if ant else 8)
+        initial_z = 0.75 if ant else 1.0
+        st[0] = z - initial_z
+        st = st.astype(np.float32)
+        touched = []
+        if coll <= 0:
+            n_cp = int(lrs.randint(0, 9))
+            touched = [int(lrs.choice([3, 4] + ids[:min(total, 6)] + ids[-min(total, 4):])) for _ in range(n_cp)]
+        cl.getContactPoints = lambda body_id: [(0, body_id, oid, -1, -1) for oid in touched]
+        robot = NS(apply_action=lambda a: None, calc_state=lambda: st.copy(), initial_z=initial_z, objects=[1], body_rpy=rpy, robot_body=body,
+                   alive_bonus=(lambda zz, p: +1 if zz > 0.26 else -1) if ant else (lambda zz, p: 1))
+        self = cls.__new__(cls)
+        self.__dict__.update(dict(robot=robot, scene=NS(global_step=lambda: None), stadium_scene=sc, parts={'torso': body}, robot_body=body,
+                                  robot_coll_dist=coll, use_sensor=use_sensor, n_bins=n_bins, sensor_span=span, sensor_range=srange,
+                                  dying_cost=dying_cost, debug=False, _p=cl))
+        obs, rew, done, info = cls.step(self, np.zeros(8))
+        return {'cls': cls.__name__, 'n_food': n_food, 'n_poison': n_poison, 'n_bins': n_bins, 'use_sensor': use_sensor, 'coll_dist': coll,
+                'respawn': respawn, 'world': list(world), 'spacing': spacing, 'span': span, 'range': srange, 'dying_cost': dying_cost,
+                'state_in': st.astype(float).tolist(), 'initial_z': initial_z, 'torso_xyz': [float(xy[0]), float(xy[1]), float(z)],
+                'rpy': list(map(float, rpy)), 'items_before': [q[:2] for q in items0], 'respawn_draws': sc.rs.log[n_restart:],
+                'contact_items': [ids.index(o) if o in ids else -1 for o in touched],
+                'items_after': [list(sc.all_items[i])[:2] for i in sc.all_items],
+                'obs': tolist(obs), 'rew': float(rew), 'done': bool(done), 'food_rew': float(info['food_rew']), 'dead_rew': float(info['dead_rew'])}
+
+    def random_maze_case(k):
+        """ant_maze_bullet_env.py:63-97,123-178 with every constructor argument drawn at random"""
+        lrs = np.random.RandomState(24000 + k)
+        n_bins = int(lrs.choice([2, 3, 5, 10, 16, 17, 33, 64]))
+        span = float(lrs.choice([2 * np.pi, np.pi, f32(lrs.uniform(0.3, 6.5))]))
+        srange = float(lrs.choice([2.0, 5.0, 9.0, 30.0]))
+        nt = int(lrs.choice([1, 2, 4, 9, 33, 64]))
+        targets = [[f32(lrs.uniform(-4.5, 4.5)), f32(lrs.uniform(-8.5, 8.5))] for _ in range(nt)]
+        target = np.array(targets[lrs.randint(0, nt)])
+        tol = float(lrs.choice([1.5, 0.2, 0.8, 3.0, 12.0]))
+        xy = np.array([lrs.uniform(-4.5, 4.5), lrs.uniform(-8.5, 8.5)])
+        if lrs.rand() < 0.5:
+            xy = target + lrs.uniform(-1.0, 1.0, 2) * min(tol, 3.0)
+        rpy = [lrs.uniform(-.2, .2), lrs.uniform(-.2, .2), lrs.uniform(-np.pi, np.pi)]
+        body = Body([xy[0], xy[1], 0.45], rpy)
+        ant_obs = lrs.uniform(-1, 1, 28).astype(np.float32)
+        inner_rew, inner_done = float(lrs.uniform(-1, 1)), bool(lrs.rand() < 0.2)
+        wtd = float(np.linalg.norm(target - (xy + lrs.uniform(-0.3, 0.3, 2))))
+        args = dict(n_bins=n_bins, sensor_range=srange, sensor_span=span, sense_walls=bool(lrs.rand() < 0.7), sense_target=bool(lrs.rand() < 0.5),
+                    done_at_target=bool(lrs.rand() < 0.5), max_steps=int(lrs.choice([-1, 1, 2, 5, 26])), tol=tol,
+                    inner_rew_weight=float(lrs.choice([0.0, 0.5, 1.0, -2.0])), targ_dist_rew=bool(lrs.rand() < 0.5))
+        encoding, t0 = int(lrs.rand() < 0.5), int(lrs.choice([0, 0, 1, 3, 4, 24, 25]))
+        self = AntMazeBulletEnv.__new__(AntMazeBulletEnv)
+        self.__dict__.update(dict(args, targets=targets, t=t0, target_encoding=PositionEncoding(encoding), target=target, debug=0, scene=maze,
+                                  robot=NS(body_real_xyz=[xy[0], xy[1], 0.45], walk_target_dist=wtd), robot_body=body,
+                                  _super_step_result=(ant_obs, inner_rew, inner_done, {})))
+        obs, rew, d, _ = AntMazeBulletEnv.step(self, np.zeros(8))
+        return dict(args, encoding=encoding, t_before=t0, targets=targets, torso_xy=xy.tolist(), rpy=list(map(float, rpy)), target=target.tolist(),
+                    ant_obs=ant_obs.astype(float).tolist(), inner_rew=inner_rew, inner_done=inner_done, walk_target_dist=wtd,
+                    obs=tolist(obs), rew=float(rew), done=bool(d))
+
+    G['random_config'] = {'gather_step': [random_gather_case(k) for k in range(70)], 'maze_step': [random_maze_case(k) for k in range(70)]}
+
     only = set(sys.argv[1:])  # optional: names of the fixtures to (re)write; default all
     for name, val in G.items():
         if only and name not in only:

@@ -423,6 +423,63 @@ def test_gather_contact_pickup_step():
     assert multi > 5  # the fixture really contains items touched by several contact points
 
 
+def test_random_constructor_arguments_gather_step():
+    """`random_config.json`: the task half of the reference's step() (ant_gather_env.py:76-119, gather_base.py:74-109) with every constructor
+    argument drawn at random -- item counts up to 64, 1..64 bins, use_sensor on / off, robot_coll_dist of either sign (distance or contact
+    pickup), respawn on / off, world size, spacing, sensor span / range, dying cost: the branches the other fixtures take one at a time,
+    combined.  (The combination contact pickup + positions in the observation is where the device once disagreed with the oracle; the
+    reference's own output says the oracle was right: the positions are those BEFORE the move.)"""
+    combos = set()
+    moved_and_shown = 0
+    for c in load('random_config')['gather_step']:
+        ant = c['cls'] == 'AntGatherBulletEnv'
+        cfg = orc.default_config(K.HRL_ANT_GATHER if ant else K.HRL_POINT_GATHER, n_food=c['n_food'], n_poison=c['n_poison'], n_bins=c['n_bins'],
+                                 use_sensor=int(c['use_sensor']), robot_coll_dist=c['coll_dist'], respawn=int(c['respawn']),
+                                 world_size=tuple(c['world']), robot_object_spacing=c['spacing'], sensor_span=c['span'], sensor_range=c['range'],
+                                 dying_cost=c['dying_cost'])
+        st = arr(c['state_in']); items = arr(c['items_before']).copy()
+        draws = arr(c['respawn_draws']).reshape(-1, 2) if c['respawn_draws'] else np.zeros((1, 2))
+        ci = np.asarray(c['contact_items'], np.int32) if c['contact_items'] else np.zeros(1, np.int32)
+        assert orc.obs_dim(cfg) == len(c['obs'])
+        obs = np.zeros(len(c['obs'])); rew = C.c_double(); done = C.c_int(); fr = C.c_double(); dr = C.c_double()
+        head = (C.byref(cfg), int(ant), orc.ptr(st), len(st), orc.ptr(arr(c['torso_xyz'])), C.c_double(c['rpy'][2]), C.c_double(c['initial_z']),
+                C.c_double(0.26 if ant else -1.0), orc.ptr(items), orc.ptr(draws), len(c['respawn_draws']))
+        tail = (orc.ptr(obs), C.byref(rew), C.byref(done), C.byref(fr), C.byref(dr))
+        if c['coll_dist'] > 0:
+            used = orc.lib().orc_gather_task_f64(*head, *tail)
+        else:
+            used = orc.lib().orc_gather_task_contacts_f64(*head, orc.ptr(ci), len(c['contact_items']), *tail)
+        assert used == len(c['respawn_draws'])
+        np.testing.assert_allclose(items, c['items_after'], atol=1e-12)
+        np.testing.assert_allclose(obs, c['obs'], atol=1e-12, equal_nan=True)
+        assert rew.value == c['rew'] and bool(done.value) == c['done'] and fr.value == c['food_rew'] and dr.value == c['dead_rew']
+        combos.add((c['use_sensor'], c['coll_dist'] > 0, c['respawn']))
+        if not c['use_sensor'] and c['coll_dist'] <= 0 and c['items_before'] != c['items_after']:
+            moved_and_shown += 1
+    assert len(combos) == 8 and moved_and_shown >= 3
+
+
+def test_random_constructor_arguments_maze_step():
+    """`random_config.json`: AntMazeBulletEnv.step (ant_maze_bullet_env.py:63-97) with sense_walls / sense_target / target_encoding /
+    done_at_target / max_steps / tol / inner_rew_weight / targ_dist_rew / n_bins / sensor span and range / the target list drawn at random."""
+    lines = arr(load('sense_walls')['maze_bounds']).reshape(-1, 4)
+    seen = set()
+    for c in load('random_config')['maze_step']:
+        cfg = orc.default_config(K.HRL_ANT_MAZE, target_encoding=c['encoding'], sense_target=int(c['sense_target']), sense_walls=int(c['sense_walls']),
+                                 n_bins=c['n_bins'], sensor_span=c['sensor_span'], sensor_range=c['sensor_range'], done_at_target=int(c['done_at_target']),
+                                 max_steps=c['max_steps'], tol=c['tol'], inner_rew_weight=c['inner_rew_weight'], targ_dist_rew=int(c['targ_dist_rew']),
+                                 targets=c['targets'])
+        assert orc.obs_dim(cfg) == len(c['obs'])
+        obs = np.zeros(len(c['obs'])); rew = C.c_double(); done = C.c_int()
+        orc.lib().orc_maze_task_f64(C.byref(cfg), orc.ptr(arr(c['ant_obs'])), C.c_double(c['inner_rew']), int(c['inner_done']),
+                                    orc.ptr(arr(c['torso_xy'])), C.c_double(c['rpy'][2]), orc.ptr(arr(c['target'])),
+                                    C.c_double(c['walk_target_dist']), c['t_before'] + 1, orc.ptr(lines), 7, 3, orc.ptr(obs), C.byref(rew), C.byref(done))
+        np.testing.assert_allclose(obs, c['obs'], atol=1e-11)
+        assert rew.value == pytest.approx(c['rew'], abs=1e-12) and bool(done.value) == c['done']
+        seen.add((c['done'], c['done_at_target'], c['targ_dist_rew'], c['walk_target_dist'] < c['tol']))
+    assert len(seen) >= 12
+
+
 def test_reset_potential_belongs_to_the_previous_target():
     """Sequence fixture (reference reset()/next_target()/step() run in-tree around a restated upstream bookkeeping, see
     make_golden.py): the potential a reset leaves is the distance to the PREVIOUS target -- from the new pose (flagrun,
