@@ -44,6 +44,9 @@ class _Empty:
         pass
 
 
+REGISTERED = []   # what hrl_pybullet_envs/__init__.py hands to gym.envs.register
+
+
 def install_stubs():
     class Box(_Empty):
         def __init__(self, low=None, high=None, shape=None, **k):
@@ -104,7 +107,7 @@ def install_stubs():
     seeding = _mod('gym.utils.seeding', np_random=lambda s=None: (np.random.RandomState(s), s))
     utils = _mod('gym.utils', seeding=seeding)
     spaces = _mod('gym.spaces', Box=Box)
-    envs = _mod('gym.envs', register=lambda **k: None)
+    envs = _mod('gym.envs', register=lambda **k: REGISTERED.append(k))
     _mod('gym', utils=utils, spaces=spaces, envs=envs)
 
 
@@ -949,6 +952,30 @@ def main():
                     obs=tolist(obs), rew=float(rew), done=bool(d))
 
     G['random_config'] = {'gather_step': [random_gather_case(k) for k in range(70)], 'maze_step': [random_maze_case(k) for k in range(70)]}
+
+    # ---------------------------------------------------------------- the constructor surfaces and the registration (the boundary)
+    # inspect.signature of every env class a user constructs, and the keyword arguments hrl_pybullet_envs/__init__.py:11-16 registered with gym
+    import enum
+    import inspect
+    from hrl_pybullet_envs.envs.gather.point_gather_env import PointGatherBulletEnv
+    from hrl_pybullet_envs.envs.ant_flagrun.ant_flagrun_env import AntFlagrunBulletEnv
+    from hrl_pybullet_envs.envs.ant_maze.ant_maze_mj_env import AntMazeMjEnv as _AntMazeMjEnv
+
+    def plain(v):
+        if isinstance(v, enum.Enum): return {'enum': type(v).__name__, 'name': v.name}
+        if isinstance(v, (tuple, list)): return [plain(x) for x in v]
+        if isinstance(v, (bool, int, str)) or v is None: return v
+        if isinstance(v, (float, np.floating, np.integer)): return float(v)
+        return {'repr': repr(v)}
+
+    def signature(cls):
+        return [{'name': n, 'kind': q.kind.name, 'default': '<required>' if q.default is inspect.Parameter.empty else plain(q.default)}
+                for n, q in inspect.signature(cls.__init__).parameters.items() if n != 'self']
+
+    G['constructor_signatures'] = {
+        'classes': {f'{c.__module__}:{c.__name__}': signature(c) for c in (AntGatherBulletEnv, PointGatherBulletEnv, GatherBulletEnv, AntMazeBulletEnv,
+                                                                         _AntMazeMjEnv, AntFlagrunBulletEnv, AntMjEnv, PointBot, MjAnt)},
+        'registered': [{k: plain(v) for k, v in r.items()} for r in REGISTERED]}
 
     only = set(sys.argv[1:])  # optional: names of the fixtures to (re)write; default all
     for name, val in G.items():

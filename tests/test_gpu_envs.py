@@ -51,6 +51,12 @@ def test_batched_classes_and_maze_flat():
         for t in range(20):
             ob, rew, done, info = env.step(torch.rand(256, ad, device='cuda') * 2 - 1)
         assert rew.shape == (256,) and done.dtype == torch.uint8 and bool(torch.isfinite(ob).all())
+        if cls is H.AntMjEnv:   # MjAnt.py:10-28: env.robot is the MjAnt, its calc_state() the qpos | qvel the observation is made of
+            from hrl_pybullet_envs_amd.envs.MjAnt import MjAnt
+            assert isinstance(env.robot, MjAnt) and env.robot.power == 2.5
+            live = ~done.bool().cpu().numpy()   # (an env that ended shows its next episode's first observation)
+            assert np.array_equal(env.robot.calc_state()[live].astype(np.float32), ob.cpu().numpy()[live])
+            assert np.array_equal(env.robot.alive_bonus(env.robot.body_real_xyz[:, 2], 0.0) < 0, env.robot.body_real_xyz[:, 2] - 0.75 <= 0.26)
         env.close()
 
 

@@ -309,3 +309,48 @@ def test_committed_counter_summary_describes_the_committed_kernels():
     assert {'gather', 'flat', 'maze', 'point', 'maze_mj', 'flagrun'} <= set(summ)
     stale = [k for k, v in summ.items() if v.get('source_sha256') != kernel_source_hash()]
     assert not stale, f're-profile (tools/profile_round.sh + tools/summarize_profile.py): stale counter summaries for {stale}'
+
+
+def test_constructor_surfaces_equal_the_references():
+    """SURVEY 8b, pinned by data taken from the reference itself (`tests/golden/constructor_signatures.json`: inspect.signature of its classes and the
+    keyword arguments its __init__.py:11-16 registered, recorded by make_golden.py): every class sits at the mirrored module path, takes the
+    reference's parameters under the same names, in the same order, with the same defaults (this package's own -- num_envs, device, seed where the
+    reference has none -- come after them), and registers the same ids in the same order with the same step limit."""
+    import enum
+    import importlib
+    import inspect
+    import json
+    import os
+    import hrl_pybullet_envs_amd as H
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'constructor_signatures.json')))
+
+    def plain(v):
+        if isinstance(v, enum.Enum): return {'enum': type(v).__name__, 'name': v.name}
+        if isinstance(v, (tuple, list)): return [plain(x) for x in v]
+        if isinstance(v, (bool, int, str)) or v is None: return v
+        if isinstance(v, (float, np.floating, np.integer)): return float(v)
+        return {'repr': repr(v)}
+
+    assert len(g['classes']) == 9
+    for path, params in g['classes'].items():
+        mod, name = path.split(':')
+        cls = getattr(importlib.import_module(mod.replace('hrl_pybullet_envs', 'hrl_pybullet_envs_amd', 1)), name)
+        ours = [(n, q) for n, q in inspect.signature(cls.__init__).parameters.items() if n != 'self']
+        assert len(ours) >= len(params), path
+        for (n, q), ref in zip(ours, params):
+            assert n == ref['name'] and q.kind.name == ref['kind'], (path, n, ref)
+            d = '<required>' if q.default is inspect.Parameter.empty else plain(q.default)
+            assert d == ref['default'] and type(d) is type(ref['default']) or (isinstance(d, (int, float)) and not isinstance(d, bool) and d == ref['default']), (path, n, d, ref['default'])
+        extra = [n for n, _ in ours[len(params):]]
+        assert set(extra) <= {'num_envs', 'device', 'seed', 'goal_capacity'}, (path, extra)   # goal_capacity: the length bound of `env.goals` (ABI v6)
+
+    class FakeGym:
+        class envs:
+            calls = []
+
+            @staticmethod
+            def register(**kw):
+                FakeGym.envs.calls.append(kw)
+    H.register_with(FakeGym)
+    assert [(c['id'], c['max_episode_steps']) for c in FakeGym.envs.calls] == [(r['id'], r['max_episode_steps']) for r in g['registered']]
+    assert [c['entry_point'] for c in FakeGym.envs.calls] == [r['entry_point'].replace('hrl_pybullet_envs', 'hrl_pybullet_envs_amd', 1) for r in g['registered']]
