@@ -99,7 +99,7 @@ def draw_config(rng, kind):
         nt = int(pick(rng, [1, 2, 4, 5, 8, 9, 16, 33, 63, 64]))
         kw['targets'] = [(f32(rng.uniform(-4.5, 4.5)), f32(rng.uniform(-8.5, 8.5))) for _ in range(nt)]
         kw['done_at_target'] = int(rng.rand() < 0.6)
-        kw['max_steps'] = int(pick(rng, [-1, -1, 1, 4, 25]))
+        kw['max_steps'] = int(pick(rng, [-1, -1, 0, 1, 2, 4, 25]))
         kw['targ_dist_rew'] = int(rng.rand() < 0.4)
         kw['tol'] = f32(pick(rng, [1.5, 0.2, 0.8, 3.0, 12.0]))
         if rng.rand() < 0.4: kw['start_pos'] = (f32(rng.uniform(-4, 4)), f32(rng.uniform(-8, -3)), f32(pick(rng, [0.25, 0.4, 0.75])))
@@ -116,7 +116,7 @@ def draw_config(rng, kind):
             kw['flag_max_targets'] = int(pick(rng, [1, 2, 3, 7, 100, 65535])); kw['flag_max_target_dist'] = 0.0
         else:                  # goals near the robot
             kw['flag_max_targets'] = int(pick(rng, [0, -1])); kw['flag_max_target_dist'] = f32(2.0 * kw['tol'] + rng.uniform(0.1, 6.0))
-        kw['flag_timeout'] = int(pick(rng, [200, 1, 2, 5, 17, 32767]))
+        kw['flag_timeout'] = int(pick(rng, [200, 1, 2, 5, 17, 32767, 0, -3]))
         kw['flag_switch_on_collision'] = int(rng.rand() < 0.7)
         kw['flag_enclosed'] = int(rng.rand() < 0.7)
         if not kw['flag_enclosed'] and not kw['use_sensor']:
