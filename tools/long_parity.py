@@ -18,9 +18,10 @@ from hrl_pybullet_envs_amd.vec_env import BatchedEnv  # noqa: E402
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 kinds = [int(k) for k in sys.argv[3:] if k.isdigit()] or [0, 1, 2, 3, 4, 5]
-KW = dict(big=dict(n_food=20, n_poison=12, n_bins=24), huge=dict(n_food=40, n_poison=24, n_bins=64), short=dict(max_episode_steps=50))
+KW = dict(big=dict(n_food=20, n_poison=12, n_bins=24), huge=dict(n_food=40, n_poison=24, n_bins=64), short=dict(max_episode_steps=50),
+          contact=dict(robot_coll_dist=0.0, use_sensor=0, n_food=32, n_poison=32, world_size=(6.0, 6.0), robot_object_spacing=0.5))
 kw = {}
-for k in sys.argv[3:]:  # named config sets after the kinds: `big` (32 items, 24 bins), `huge` (64 items, 64 bins), `short` (50-step limit)
+for k in sys.argv[3:]:  # named config sets after the kinds: `big` (32 items, 24 bins), `huge` (64 items, 64 bins), `short` (50-step limit), `contact` (pickup by contact, positions in the observation, a crowded 6 x 6 arena)
     kw.update(KW.get(k, {}))
 names = ['flat', 'gather', 'maze', 'point', 'maze_mj', 'flagrun']
 for kind in kinds:
