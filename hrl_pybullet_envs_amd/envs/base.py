@@ -86,6 +86,14 @@ class BatchedGymEnv:
             return obs[0].double().cpu().numpy()
         return obs
 
+    def state_dict(self):
+        """Checkpoint of the simulation (vec_env.BatchedEnv.state_dict): torch.save()-able, resumes bit for bit."""
+        return self._backend().state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        obs = self._backend().load_state_dict(sd, strict)
+        return obs[0].double().cpu().numpy() if self.num_envs == 1 else obs
+
     def step(self, a):
         env = self._backend()
         if self.num_envs == 1:

@@ -176,6 +176,34 @@ class BatchedEnv:
             _lib.check(_lib.lib().hrl_next_target(self._h, C.byref(self._bufs), None if m is None else m.data_ptr(), ok.data_ptr(), self._stream()))
         return self.obs, ok
 
+    # checkpoint / resume: everything an env carries from one step to the next is three tensors -- `state` (pose, velocities, episode
+    # return, potential), `items` (item positions / pending goals) and `aux` (step, pickup, episode and goal counters: the keys of the counter-based
+    # random streams) -- plus the config (seed, env_id_offset, constructor arguments).  torch.save()-able; resuming continues bit for bit.
+    def state_dict(self):
+        self._before_device_launch()
+        out = {k: getattr(self, k).detach().cpu().clone() for k in ('state', 'items', 'aux', 'obs', 'reward', 'done', 'info', 'final_obs', 'truncated')}
+        out['config'] = bytes(self.cfg)
+        out['abi_version'] = K.HRL_ABI_VERSION
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        """Restores a state_dict() of an env with the same config.  strict: the whole config (seed and env_id_offset included: they key the
+        random streams) must be equal; strict=False only insists on what the buffers' shapes depend on."""
+        if sd.get('abi_version') != K.HRL_ABI_VERSION:
+            raise _lib.HrlError(f"checkpoint of ABI v{sd.get('abi_version')}, this library is v{K.HRL_ABI_VERSION}")
+        if strict and sd['config'] != bytes(self.cfg):
+            raise _lib.HrlError('checkpoint was taken from an env with another config (strict=False skips this check)')
+        for k in ('state', 'items', 'aux'):
+            if tuple(sd[k].shape) != tuple(getattr(self, k).shape):
+                raise _lib.HrlError(f'checkpoint {k} is {tuple(sd[k].shape)}, this env holds {tuple(getattr(self, k).shape)}')
+        self._before_device_launch()
+        for k in ('state', 'items', 'aux'):
+            getattr(self, k).copy_(sd[k])
+        for k in ('obs', 'reward', 'done', 'info', 'final_obs', 'truncated'):
+            if k in sd and tuple(sd[k].shape) == tuple(self._out[k].shape):
+                self._out[k].copy_(sd[k])
+        return self.obs
+
     # state access (identical-state parity tests)
     @property
     def qpos(self):
