@@ -241,3 +241,34 @@ def test_lcp_residual_five_sweeps_against_converged():
           f'{np.percentile(res[5], 90):.3e}, 200 sweeps {m200:.3e} / {np.percentile(res[200], 90):.3e}')
     assert m200 < 1e-6 and np.percentile(res[200], 90) < 0.05  # Gauss-Seidel converges slowly on the redundant-contact states
     assert m5 < 0.2 and np.percentile(res[5], 90) < 1.0
+
+
+def test_optimised_spec_equals_textbook_over_the_model_parameters():
+    """The engine parameters of `hrl_model` are part of the C-ABI: 400 random contact states, each with its OWN model -- density, gravity, time
+    step, both ERPs, both friction coefficients, contact distance, limit margin, rate clamp, limit impulse cap, ground height, 1..13 sweeps,
+    self collision on / off, arena size -- one substep of the optimised specification against the frozen textbook reference: the two derivations
+    agree to rounding everywhere in the parameter space, not only at the defaults."""
+    rng = np.random.RandomState(77)
+    worst, rows, selfc = 0.0, [], 0
+    for i in range(400):
+        f32 = lambda x: float(np.float32(x))
+        wx, wy = f32(rng.uniform(4, 20)), f32(rng.uniform(4, 20))
+        kw = dict(world_size=(wx, wy), model_density=f32(rng.choice([5.0, 200.0, 1000.0, 3000.0])), model_gravity=f32(rng.choice([0.0, 1.6, 9.8, 20.0])),
+                  model_timestep=f32(rng.uniform(0.001, 0.008)), model_contact_erp=f32(rng.uniform(0, 1)), model_limit_erp=f32(rng.uniform(0, 1)),
+                  model_friction_ground=f32(rng.choice([0.0, 0.3, 0.8, 3.0])), model_friction_robot=f32(rng.choice([0.0, 0.1, 1.5, 4.0])),
+                  model_contact_dist=f32(rng.choice([0.0, 0.005, 0.02, 0.08])), model_limit_margin=f32(rng.choice([0.0, 0.05, 0.25, 1.0])),
+                  model_max_joint_vel=f32(rng.choice([5.0, 30.0, 100.0, 1000.0])), model_limit_max_impulse=f32(rng.choice([0.5, 10.0, 100.0, 1e6])),
+                  model_ground_z=f32(rng.choice([0.0, 0.005, 0.05])), model_solver_iters=int(rng.choice([1, 2, 3, 5, 8, 13])),
+                  model_self_collision=int(rng.rand() < 0.5))
+        cfg = orc.default_config(K.HRL_ANT_GATHER, **kw)
+        p = tb.params(cfg)
+        q, u, tau = rand_state(rng, xy=(-wx / 2 - 0.1, wx / 2 + 0.1, -wy / 2 - 0.1, wy / 2 + 0.1), joint_slack=0.3 if i % 3 == 0 else 0.1)
+        q1, u1, out = tb.ant_substep(p, q, u, tau)
+        q2, u2, info = orc_substeps(cfg, q, u, tau)
+        assert (info[0], info[1], info[2]) == (out.n_rows, out.n_limits, out.n_contacts), (i, kw, info, out.n_rows)
+        err = max(np.abs(q1 - q2).max(), np.abs(u1 - u2).max())
+        scale = max(1.0, np.abs(u1).max())   # light bodies under 250 N m reach rates the clamp alone bounds: relative beyond 1
+        assert err <= TOL * scale, (i, kw, err, out.n_rows)
+        worst = max(worst, err / scale); rows.append(out.n_rows)
+    assert np.mean(rows) > 4 and max(rows) >= 12
+    print(f'random model parameters: worst scaled |diff| {worst:.2e}, rows mean {np.mean(rows):.1f} max {max(rows)}')
