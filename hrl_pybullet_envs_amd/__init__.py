@@ -1,7 +1,8 @@
 """hrl_pybullet_envs_amd -- MI355X-native batched step for the hrl_pybullet_envs environments.
 
 Same class names / constructor kwargs as the reference (hrl_pybullet_envs/__init__.py:3-16); `make(id)` resolves the
-reference's registered ids.  With gym installed the ids are also registered with `max_episode_steps=2000`."""
+reference's registered ids with their 2000-step limit.  With gym installed the ids are also registered with `max_episode_steps=2000`
+(gym.make then wraps the single-env object in its own TimeLimit, as it does with the reference's)."""
 from .envs.MjAnt import AntMjEnv
 from .envs.ant_flagrun.ant_flagrun_env import AntFlagrunBulletEnv
 from .envs.ant_maze.ant_maze_bullet_env import AntMazeBulletEnv
@@ -15,10 +16,13 @@ _REGISTRY = {f'{c.__name__}-v0': c for c in (AntGatherBulletEnv, AntMazeMjEnv, A
 
 
 def make(env_id, **kwargs):
-    """gym.make() analogue for the ids the reference registers (`<ClassName>-v0`)."""
+    """gym.make() analogue for the ids the reference registers (`<ClassName>-v0`): constructs the class and, like gym.make's TimeLimit
+    wrapper (`max_episode_steps=2000`, hrl_pybullet_envs/__init__.py:15), limits its episodes -- inside the kernel."""
     if env_id not in _REGISTRY:
         raise KeyError(f'unknown env id {env_id!r}; known: {sorted(_REGISTRY)}')
-    return _REGISTRY[env_id](**kwargs)
+    env = _REGISTRY[env_id](**kwargs)
+    env.max_episode_steps = env.REGISTERED_STEP_LIMIT
+    return env
 
 
 def register_with(gym_module):

@@ -3,9 +3,16 @@
 The reference's boundary is the old-gym (<= 0.21) class API (hrl_pybullet_envs/__init__.py:11-16, README.md:24-34):
     reset() -> obs ;  step(a) -> (obs, rew, done, info) ;  seed(s) ;  observation_space / action_space
 `num_envs == 1` (default) behaves like the reference object: numpy in, numpy/float/bool out, `info` a dict of
-python numbers, and the gym TimeLimit of the registration (max_episode_steps=2000) applied inside.  `num_envs > 1`
-is the batched form: torch tensors resident on the GPU, `done` envs auto-reset (the returned obs is then the first
-observation of the next episode, as vector-env wrappers do).
+python numbers.  `num_envs > 1` is the batched form: torch tensors resident on the GPU, `done` envs auto-reset (the
+returned obs is then the first observation of the next episode, as vector-env wrappers do).
+
+The step limit.  In the reference the classes have none: `gym.make(id)` wraps them in `TimeLimit(2000)` (__init__.py:15).  Here the limit
+lives in the kernel (`hrl_config.max_episode_steps`, `info['TimeLimit.truncated']`), switched on by whoever plays gym.make's part:
+  * `hrl_pybullet_envs_amd.make(id, ...)`            -> 2000, as gym.make;
+  * a class constructed directly with num_envs == 1  -> none, like the reference's object (so that a real `gym.make`, which wraps the object in
+                                                        its own TimeLimit, does not meet a second limit that would turn its truncation flag off);
+  * a class constructed directly with num_envs > 1   -> 2000: a batch is its own vector env, no wrapper of gym's can sit around it;
+  * `env.max_episode_steps = n` at any time (0: none).
 """
 import ctypes as C
 
@@ -49,13 +56,32 @@ class BatchedGymEnv:
 
     metadata = {'render.modes': ['rgb_array']}
     reward_range = (-float('inf'), float('inf'))
-    max_episode_steps = 2000  # hrl_pybullet_envs/__init__.py:15
+    REGISTERED_STEP_LIMIT = 2000  # hrl_pybullet_envs/__init__.py:15
+
+    @property
+    def max_episode_steps(self):
+        return int(self._cfg.max_episode_steps)
+
+    @max_episode_steps.setter
+    def max_episode_steps(self, n):
+        """The step limit of gym's TimeLimit, applied inside the kernel (0: none).  On a running env the simulation carries over."""
+        n = int(n)
+        if n < 0:
+            raise ValueError('max_episode_steps must be >= 0 (0: no limit)')
+        if n == self._cfg.max_episode_steps:
+            return
+        sd = self._env.state_dict() if self._env is not None else None
+        self._cfg.max_episode_steps = n
+        if sd is not None:   # the limit is a constant of the library handle: a new handle, the same buffers' contents
+            self._env.close()
+            self._env = None
+            self._backend().load_state_dict(sd, strict=False)
 
     def _finish_init(self, cfg, num_envs, device, seed):
         if num_envs < 1:
             raise ValueError('num_envs must be >= 1')
         cfg.num_envs = int(num_envs)
-        cfg.max_episode_steps = self.max_episode_steps
+        cfg.max_episode_steps = self.REGISTERED_STEP_LIMIT if num_envs > 1 else 0   # see the module docstring
         cfg.auto_reset = 1 if num_envs > 1 else 0
         cfg.seed = 0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
         self._cfg, self._device, self.num_envs = cfg, device, int(num_envs)

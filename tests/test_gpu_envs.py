@@ -35,11 +35,56 @@ def test_time_limit_truncation_flag():
     import hrl_pybullet_envs_amd as H
     env = H.PointGatherBulletEnv(seed=1)
     env.max_episode_steps = 5
-    env._cfg.max_episode_steps = 5
     env.reset()
     for t in range(5):
         ob, rew, done, info = env.step(np.array([1.0, 0.0]))
     assert done and info.get('TimeLimit.truncated') is True and ob.shape == (18,)
+
+
+def test_step_limit_is_gym_makes_part():
+    """In the reference the classes have no step limit; gym.make wraps them in TimeLimit(2000) (__init__.py:15).  Here: make() switches the kernel's
+    limit on, a directly constructed single env has none -- so a real gym.make, which wraps the object in gym's own TimeLimit, keeps its truncation
+    flag (gym 0.21: `info['TimeLimit.truncated'] = not done` AFTER the env's step: an inner limit firing at the same step would turn it False) --,
+    and a limit set on a running env carries the simulation over."""
+    import hrl_pybullet_envs_amd as H
+
+    class GymTimeLimit:   # gym/wrappers/time_limit.py of gym 0.21, the version the reference needs (SURVEY 5, seeding)
+        def __init__(self, env, max_episode_steps):
+            self.env, self._max, self._elapsed = env, max_episode_steps, None
+
+        def reset(self):
+            self._elapsed = 0
+            return self.env.reset()
+
+        def step(self, action):
+            observation, reward, done, info = self.env.step(action)
+            self._elapsed += 1
+            if self._elapsed >= self._max:
+                info['TimeLimit.truncated'] = not done
+                done = True
+            return observation, reward, done, info
+
+    acts = np.random.RandomState(0).uniform(-1, 1, (5, 2))
+    wrapped = GymTimeLimit(H.PointGatherBulletEnv(seed=1), 5)              # what a real gym.make builds
+    ours = H.make('PointGatherBulletEnv-v0', seed=1)                        # what make() builds
+    assert wrapped.env.max_episode_steps == 0 and ours.max_episode_steps == 2000
+    ours.max_episode_steps = 5
+    wrapped.reset(); ours.reset()
+    for t in range(5):
+        ow, rw, dw, iw = wrapped.step(acts[t]); oo, ro, do, io = ours.step(acts[t])
+        assert np.array_equal(ow, oo) and rw == ro and dw == do and iw.get('TimeLimit.truncated') == io.get('TimeLimit.truncated'), t
+    assert dw is True and iw['TimeLimit.truncated'] is True
+    # the limit switched on in the middle of an episode: the same episode goes on
+    late = H.PointGatherBulletEnv(seed=1)
+    late.reset()
+    for t in range(3):
+        late.step(acts[t])
+    late.max_episode_steps = 5
+    for t in range(3, 5):
+        ol, rl, dl, il = late.step(acts[t])
+    assert np.array_equal(ol, oo) and rl == ro and dl is True and il['TimeLimit.truncated'] is True
+    for e in (wrapped.env, ours, late):
+        e.close()
 
 
 def test_batched_classes_and_maze_flat():
@@ -167,7 +212,6 @@ def test_gymnasium_adapter_on_a_real_batched_env():
     from hrl_pybullet_envs_amd.adapters import GymnasiumAdapter
     env = H.PointGatherBulletEnv(num_envs=64, seed=2)
     env.max_episode_steps = 5
-    env._cfg.max_episode_steps = 5
     g = GymnasiumAdapter(env)
     obs, info = g.reset(seed=4)
     assert obs.shape == (64, 18) and info == {} and env._cfg.seed == 4
@@ -194,7 +238,7 @@ def test_vector_env_adapters_meet_their_contracts():
 
     def build():
         e = H.AntGatherBulletEnv(num_envs=n, seed=5)
-        e.max_episode_steps = limit; e._cfg.max_episode_steps = limit
+        e.max_episode_steps = limit
         return e
     # ---- gymnasium.vector.VectorEnv
     v, twin = GymnasiumVectorEnv(build()), build()
@@ -537,7 +581,7 @@ def test_checkpoint_and_resume_continue_bit_for_bit():
              (H.PointGatherBulletEnv, dict(robot_coll_dist=-1, use_sensor=False), 2), (H.AntFlagrunBulletEnv, dict(manual_goal_creation=True, goal_capacity=20, timeout=7), 8)]
     for cls, kw, ad in cases:
         a_env = cls(num_envs=n, seed=11, **kw)
-        a_env._cfg.max_episode_steps = 25
+        a_env.max_episode_steps = 25
         a_env.reset()
         if cls is H.AntFlagrunBulletEnv:
             a_env.set_goals((torch.rand(n, 20, 2) * 6 - 3).numpy())
@@ -548,7 +592,7 @@ def test_checkpoint_and_resume_continue_bit_for_bit():
         buf = io.BytesIO(); torch.save(a_env.state_dict(), buf); buf.seek(0)
         sd = torch.load(buf)
         b_env = cls(num_envs=n, seed=11, **kw)
-        b_env._cfg.max_episode_steps = 25
+        b_env.max_episode_steps = 25
         ob = b_env.load_state_dict(sd)
         assert torch.equal(ob.view(torch.int32), a_env._backend().obs.view(torch.int32))
         for t in range(40, 100):
@@ -558,7 +602,7 @@ def test_checkpoint_and_resume_continue_bit_for_bit():
         assert torch.equal(A.state.view(torch.int32), B.state.view(torch.int32)) and torch.equal(A.items.view(torch.int32), B.items.view(torch.int32)) and torch.equal(A.aux, B.aux)
         assert int(A.aux[:, 2].min()) >= 3        # episodes ended and restarted on the way
         other = cls(num_envs=n, seed=12, **kw)
-        other._cfg.max_episode_steps = 25
+        other.max_episode_steps = 25
         with pytest.raises(_lib.HrlError):
             other.load_state_dict(sd)
         other.load_state_dict(sd, strict=False)   # same shapes: allowed on request

@@ -93,7 +93,8 @@ def test_env_classes_mirror_reference_constructor_api():
         H.make('AntMjBulletEnv-0')  # README.md:13 names an id that is never registered (SURVEY C-12)
     c = H.AntGatherBulletEnv(n_food=4, n_poison=3, world_size=(9, 11), dying_cost=-3, seed=5)._cfg
     assert (c.n_food, c.n_poison, c.world_size[0], c.world_size[1], c.dying_cost, c.seed) == (4, 3, 9.0, 11.0, -3.0, 5)
-    assert c.max_episode_steps == 2000 and c.auto_reset == 0                     # __init__.py:15
+    assert c.max_episode_steps == 0 and c.auto_reset == 0                        # the class has no step limit (gym.make adds it, __init__.py:15)
+    assert H.make('AntGatherBulletEnv-v0')._cfg.max_episode_steps == 2000
 
 
 def test_shard_range_partitions_all_envs():
@@ -354,3 +355,17 @@ def test_constructor_surfaces_equal_the_references():
     H.register_with(FakeGym)
     assert [(c['id'], c['max_episode_steps']) for c in FakeGym.envs.calls] == [(r['id'], r['max_episode_steps']) for r in g['registered']]
     assert [c['entry_point'] for c in FakeGym.envs.calls] == [r['entry_point'].replace('hrl_pybullet_envs', 'hrl_pybullet_envs_amd', 1) for r in g['registered']]
+
+
+def test_who_sets_the_step_limit():
+    """hrl_pybullet_envs/__init__.py:15: the limit belongs to the registration, not to the classes.  make() = gym.make: 2000; a single env
+    constructed directly: none (the reference's object; gym's own TimeLimit may wrap it); a batch constructed directly: 2000 (its own vector env)."""
+    import hrl_pybullet_envs_amd as H
+    for cls in (H.AntGatherBulletEnv, H.PointGatherBulletEnv, H.AntMazeBulletEnv, H.AntMazeMjEnv, H.AntFlagrunBulletEnv, H.AntMjEnv):
+        assert cls().max_episode_steps == 0 and cls(num_envs=8).max_episode_steps == 2000
+        assert H.make(f'{cls.__name__}-v0').max_episode_steps == 2000 and H.make(f'{cls.__name__}-v0', num_envs=8).max_episode_steps == 2000
+    e = H.AntGatherBulletEnv()
+    e.max_episode_steps = 7
+    assert e._cfg.max_episode_steps == 7 and e.max_episode_steps == 7
+    with pytest.raises(ValueError):
+        e.max_episode_steps = -1
