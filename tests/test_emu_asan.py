@@ -20,6 +20,16 @@ for kind, kw in CASES:
         rng = np.random.RandomState(1)
         for t in range(60):
             e.step(rng.uniform(-1, 1, (6, e.ad)).astype(np.float32))
+# random legal configs (tools/fuzz_configs.py: capacity edges -- 64 items, 64 bins, 256-wide observations, 64 targets, 63 goals --, parked waves,
+# teleports, masked resets, manual goals): the records are sized for exactly these
+import os, sys
+os.environ['HRL_EMU_ASAN'] = '1'
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import fuzz_configs as F
+for seed in range(9000, 9020):
+    for kind in F.KINDS:
+        r, _ = F.run(F.EmuSide, kind, seed * 16 + kind, 12)
+        assert r is None, r
 print('asan-ok')
 """
 
@@ -28,7 +38,7 @@ def test_phases_under_address_sanitizer():
     asan = subprocess.check_output(['gcc', '-print-file-name=libasan.so'], text=True).strip()
     subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'tests', 'emu'), 'libhrl_emu_asan.so'])
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0', PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, 'tests'))
-    r = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, '-c', 'ROOT = %r\n' % ROOT + CHILD], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'asan-ok' in r.stdout, r.stderr[-3000:]
 
 

@@ -172,10 +172,12 @@ class GpuSide:
 
 
 class EmuSide:
+    ASAN = bool(os.environ.get('HRL_EMU_ASAN'))   # the AddressSanitizer + UBSan build of the executor (tests/test_emu_asan.py preloads libasan)
+
     def __init__(self, cfg):
         import emu_env
-        self.e = emu_env.EmuEnv(cfg)
-        msg = emu_env.lib().emu_validate(orc.C.byref(cfg))
+        self.e = emu_env.EmuEnv(cfg, asan=self.ASAN)
+        msg = emu_env.lib(self.ASAN).emu_validate(orc.C.byref(cfg))
         if msg: raise ValueError(msg.decode())
 
     def reset(self, mask=None): self.e.reset(mask)
@@ -187,12 +189,12 @@ class EmuSide:
 
     def set_goals(self, goals, mask):
         import emu_env
-        assert emu_env.lib().emu_set_goals(orc.C.byref(self.e.cfg), orc.C.byref(self.e._bufs()), orc.ptr(goals), goals.shape[1], orc.ptr(mask), 0) == 0
+        assert emu_env.lib(self.ASAN).emu_set_goals(orc.C.byref(self.e.cfg), orc.C.byref(self.e._bufs()), orc.ptr(goals), goals.shape[1], orc.ptr(mask), 0) == 0
 
     def next_target(self, mask):
         import emu_env
         ok = np.ones(self.e.N, np.uint8)
-        assert emu_env.lib().emu_next_target(orc.C.byref(self.e.cfg), orc.C.byref(self.e._bufs()), orc.ptr(mask), orc.ptr(ok), 0) == 0
+        assert emu_env.lib(self.ASAN).emu_next_target(orc.C.byref(self.e.cfg), orc.C.byref(self.e._bufs()), orc.ptr(mask), orc.ptr(ok), 0) == 0
         return ok
 
     def outputs(self):
