@@ -14,11 +14,14 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ROOT, 'oracle', 'liborc.so')
-        if not os.path.exists(path):
-            subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')])
+        asan = bool(os.environ.get('HRL_ORC_ASAN'))   # the AddressSanitizer + UBSan build (tests/test_emu_asan.py preloads libasan; no OpenMP in it)
+        path = os.path.join(ROOT, 'oracle', 'liborc_asan.so' if asan else 'liborc.so')
+        if asan or not os.path.exists(path):
+            subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), os.path.basename(path)])
         _LIB = C.CDLL(path)
-        if 'OMP_NUM_THREADS' not in os.environ:
+        if asan:
+            _LIB.omp_set_num_threads(1)
+        elif 'OMP_NUM_THREADS' not in os.environ:
             # OpenMP's default team is one thread per VISIBLE cpu; a GPU box shows all of the host's and grants a 16-core share, and a team
             # several times the share spends its time spinning at the barrier of every batch call (88 s instead of 1 s for 700 small steps)
             try:

@@ -1,5 +1,6 @@
 """The product's wave phases (csrc/step_core.h) on the lock-step host executor under AddressSanitizer + UBSan: every env
-kind and the non-default branches run free for a while; any out-of-bounds LDS-record / buffer access aborts the child."""
+kind and the non-default branches run free for a while; any out-of-bounds LDS-record / buffer access aborts the child.
+The CPU oracle runs as its sanitizer build in the same child ("host oracle under -fsanitize=address,undefined")."""
 import os
 import subprocess
 import sys
@@ -7,6 +8,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r"""
+import os
+os.environ['HRL_ORC_ASAN'] = '1'   # the oracle too (oracle/liborc_asan.so): the checker's own out-of-bounds accesses abort the child as well
 import numpy as np, orc, emu_env
 from hrl_pybullet_envs_amd import _capi as K
 CASES = [(0, {}), (1, {}), (2, {}), (3, {}), (4, {}), (5, dict(use_sensor=1, flag_max_targets=3, flag_timeout=9)),
