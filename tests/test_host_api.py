@@ -369,3 +369,53 @@ def test_who_sets_the_step_limit():
     assert e._cfg.max_episode_steps == 7 and e.max_episode_steps == 7
     with pytest.raises(ValueError):
         e.max_episode_steps = -1
+
+
+def test_constructor_arguments_reach_the_config():
+    """Every constructor argument of every env class, drawn at random, ends up in the hrl_config field the kernel reads (same
+    kwarg names; the mapping to the C-ABI is this package's).  No GPU: the backend is created on first use."""
+    import hrl_pybullet_envs_amd as H
+    rng = np.random.RandomState(12)
+    f32 = lambda x: float(np.float32(x))
+    for _ in range(40):
+        kw = dict(n_food=int(rng.randint(0, 30)), n_poison=int(rng.randint(0, 30)), world_size=(f32(rng.uniform(4, 30)), f32(rng.uniform(4, 30))),
+                  n_bins=int(rng.randint(1, 60)), sensor_range=f32(rng.uniform(1, 40)), sensor_span=f32(rng.uniform(0.5, 6)),
+                  robot_coll_dist=f32(rng.choice([1.0, 0.0, -1.0, 3.5])), robot_object_spacing=f32(rng.uniform(0.5, 3)), dying_cost=f32(rng.uniform(-20, 5)),
+                  use_sensor=bool(rng.randint(2)), respawn=bool(rng.randint(2)))
+        for cls, kind in ((H.AntGatherBulletEnv, K.HRL_ANT_GATHER), (H.PointGatherBulletEnv, K.HRL_POINT_GATHER)):
+            c = cls(num_envs=3, seed=9, **kw)._cfg
+            assert c.env_kind == kind and (c.n_food, c.n_poison, c.n_bins, c.use_sensor, c.respawn) == (kw['n_food'], kw['n_poison'], kw['n_bins'], int(kw['use_sensor']), int(kw['respawn']))
+            assert (c.world_size[0], c.world_size[1], c.sensor_range, c.sensor_span, c.robot_coll_dist, c.robot_object_spacing, c.dying_cost) == \
+                (*kw['world_size'], kw['sensor_range'], kw['sensor_span'], kw['robot_coll_dist'], kw['robot_object_spacing'], kw['dying_cost'])
+            assert (c.num_envs, c.seed, c.auto_reset, c.max_episode_steps) == (3, 9, 1, 2000)
+        nt = int(rng.randint(1, 20))
+        mk = dict(n_bins=int(rng.randint(2, 60)), sensor_range=f32(rng.uniform(1, 40)), sensor_span=f32(rng.uniform(0.5, 6)),
+                  targets=[(f32(rng.uniform(-4, 4)), f32(rng.uniform(-8, 8))) for _ in range(nt)], target_encoding=int(rng.randint(2)),
+                  tol=f32(rng.uniform(0.2, 4)), inner_rew_weight=f32(rng.uniform(-1, 1)))
+        extra = dict(sense_target=bool(rng.randint(2)), sense_walls=bool(rng.randint(2)), done_at_target=bool(rng.randint(2)), max_steps=int(rng.randint(-1, 50)),
+                     targ_dist_rew=bool(rng.randint(2)))
+        for cls, kind, kws in ((H.AntMazeBulletEnv, K.HRL_ANT_MAZE, dict(mk, **extra)), (H.AntMazeMjEnv, K.HRL_ANT_MAZE_MJ, mk)):
+            c = cls(seed=4, **kws)._cfg
+            assert c.env_kind == kind and (c.n_bins, c.sensor_range, c.sensor_span, c.target_encoding, c.tol, c.inner_rew_weight) == \
+                (mk['n_bins'], mk['sensor_range'], mk['sensor_span'], mk['target_encoding'], mk['tol'], mk['inner_rew_weight'])
+            assert c.n_targets == nt and [(c.targets[i][0], c.targets[i][1]) for i in range(nt)] == mk['targets']
+            assert (c.start_pos[0], c.start_pos[1], c.start_pos[2]) == (-2.0, -5.0, 0.25) and (c.num_envs, c.seed, c.auto_reset, c.max_episode_steps) == (1, 4, 0, 0)
+            if cls is H.AntMazeBulletEnv:
+                assert (c.sense_target, c.sense_walls, c.done_at_target, c.max_steps, c.targ_dist_rew) == tuple(int(extra[k]) for k in ('sense_target', 'sense_walls', 'done_at_target', 'max_steps', 'targ_dist_rew'))
+        close = bool(rng.randint(2))
+        fk = dict(size=f32(rng.uniform(2, 30)), tolerance=f32(rng.uniform(0.2, 1.0)), max_targets=0 if close else int(rng.randint(1, 200)),
+                  max_target_dist=f32(rng.uniform(2.5, 8)) if close else 0, timeout=int(rng.randint(0, 500)), enclosed=bool(rng.randint(2)),
+                  use_sensor=bool(rng.randint(2)), sensor_bins=int(rng.randint(2, 60)), sensor_span=f32(rng.uniform(0.5, 6)), sensor_range=f32(rng.uniform(1, 10)),
+                  switch_flag_on_collision=bool(rng.randint(2)), manual_goal_creation=bool(rng.randint(2)))
+        c = H.AntFlagrunBulletEnv(num_envs=2, goal_capacity=33, **fk)._cfg
+        assert c.env_kind == K.HRL_ANT_FLAGRUN and (c.flag_size, c.tol, c.flag_max_targets, c.flag_max_target_dist, c.flag_timeout) == \
+            (fk['size'], fk['tolerance'], fk['max_targets'], fk['max_target_dist'], fk['timeout'])
+        assert (c.flag_enclosed, c.use_sensor, c.n_bins, c.sensor_span, c.sensor_range, c.flag_switch_on_collision, c.flag_manual_goals, c.flag_goal_capacity) == \
+            (int(fk['enclosed']), int(fk['use_sensor']), fk['sensor_bins'], fk['sensor_span'], fk['sensor_range'], int(fk['switch_flag_on_collision']), int(fk['manual_goal_creation']), 33)
+        assert c.world_size[0] == c.world_size[1] == np.float32(fk['size'] + 2) and c.seed == 123                       # ant_flagrun_env.py:59-61; seed=123 is the reference's default (:16)
+        walls = fk['enclosed'] or fk['use_sensor']
+        assert (c.centroid_n_static, c.centroid_static_sum[0]) == ((2, np.float32(-(fk['size'] + 2) / 2)) if walls else (1, 0.0))
+    with pytest.raises(AssertionError, match='max_targets and max_target_dist'):
+        H.AntFlagrunBulletEnv(max_targets=5, max_target_dist=3.0)    # ant_flagrun_env.py:17-18
+    with pytest.raises(ValueError):
+        H.AntMazeBulletEnv(target_encoding=2)                        # PositionEncoding(2), utils.py:66-68
