@@ -4,7 +4,8 @@
 1 / 8 / 9 / 64 targets, env counts that leave parked waves in the last group), free-running with random and saturated actions, the wave phases (HIP
 kernels on a GPU box, `gpu`; the lock-step host executor of tests/emu, `emu`) against the fp32 oracle, every output compared bit for bit (NaNs as
 equal) after every step.  Between steps, at random: robots teleported next to items / walls / targets with random headings and velocities (the
-same state pushed into both sides), masked resets, and for AntFlagrun with manual goals `set_goals` / `next_target` on random masks.
+same state pushed into both sides), NaN / inf / 1e20 / denormals written into states and items, masked resets, and for AntFlagrun with manual
+goals `set_goals` / `next_target` on random masks.
 The hand-picked CONFIG_MATRIX of the parity tests covers the branches; this covers their combinations.
 
     python tools/fuzz_configs.py [runs] [gpu|emu] [first_seed] [steps]"""
@@ -23,6 +24,7 @@ KINDS = [K.HRL_ANT_FLAT, K.HRL_ANT_GATHER, K.HRL_ANT_MAZE, K.HRL_POINT_GATHER, K
 PI, TWO_PI = 3.14159265358979323846, 6.28318530717958647692
 EDGE_ITEMS = [0, 1, 2, 7, 8, 15, 16, 17, 24, 31, 32, 33, 47, 48, 49, 56, 63, 64]
 EDGE_BINS = [1, 2, 3, 5, 8, 10, 15, 16, 17, 19, 20, 31, 32, 33, 51, 63, 64]
+ABSURD = [np.nan, np.inf, -np.inf, 1e20, -1e20, 3e38, -3e38, 1e-40, -1e-40, -0.0, 0.0, 1e-20, 1e10, 5.0, -5.0, 100.0]
 
 
 def pick(rng, xs):
@@ -249,6 +251,23 @@ def run(Side, kind, seed, T):
                 o.state[r, 0:2] = xy; o.state[r, 2] = pick(rng, [0.35, 0.5, 0.75, 1.2]); o.state[r, 3:7] = [0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]
                 o.state[r, 15:21] = rng.uniform(-2, 2, 6)
             s.push(o)
+        if what == 4:      # absurd values in running envs (what a simulation that blows up can reach; tools/fuzz_parity.py does this on the default configs)
+            nq, nv = (7, 6) if kind == K.HRL_POINT_GATHER else (15, 14)
+            vmax = float(cfg.model.max_joint_vel)
+            for r in rng.permutation(n)[:max(1, n // 3)]:
+                field, v = rng.randint(0, 3), np.float32(ABSURD[rng.randint(len(ABSURD))])
+                if field == 0:    # a position, a quaternion component (unit or NaN), a joint angle (moderate or NaN)
+                    idx = rng.randint(0, nq)
+                    if 3 <= idx < 7: v = np.float32(np.nan)
+                    if idx >= 7: v = np.float32(rng.choice([np.nan, 2000.0, -1500.0, 3.0, -0.0]))
+                    o.state[r, idx] = v
+                elif field == 1:  # a velocity (joint rates leave a step clamped to the model's bound)
+                    idx = 15 + rng.randint(0, nv)
+                    if idx >= 21 and np.isfinite(v) and abs(v) > vmax: v = np.float32(vmax * np.sign(v))
+                    o.state[r, idx] = v
+                elif kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) and cfg.n_food + cfg.n_poison > 0:
+                    o.items[r, rng.randint(0, 2 * (cfg.n_food + cfg.n_poison))] = v
+            s.push(o)
         if what == 1:      # masked reset from outside
             m = some(0.3)
             o.reset(m); s.reset(m)
@@ -264,6 +283,7 @@ def run(Side, kind, seed, T):
             a = rng.uniform(-1, 1, (n, o.ad)).astype(np.float32)
             if mode == 1: a = np.sign(a).astype(np.float32)            # saturated
             if mode == 2: a *= np.float32(3.0)                         # beyond the clip
+            if mode == 3 and rng.rand() < 0.3: a[rng.randint(n), rng.randint(o.ad)] = np.float32(ABSURD[rng.randint(len(ABSURD))])   # NaN / inf / 1e20 torques
             t0 = time.time(); s.step(a); t1 = time.time(); o.step(a); t2 = time.time()
             CLOCK['side steps'] += t1 - t0; CLOCK['oracle steps'] += t2 - t1
             ended += int(o.done.sum())
