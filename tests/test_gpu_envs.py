@@ -608,3 +608,41 @@ def test_checkpoint_and_resume_continue_bit_for_bit():
         other.load_state_dict(sd, strict=False)   # same shapes: allowed on request
         for e in (a_env, b_env, other):
             e.close()
+
+
+def test_steps_can_be_captured_in_a_hip_graph():
+    """hrl_step is a plain launch on the caller's stream (no allocation, no synchronisation, no host read-back), so a rollout's inner loop can be
+    captured once and replayed (torch.cuda.graphs = hipGraph): four env steps per replay with the actions in a static tensor; after three replays
+    state, items, counters and observations equal the oracle stepped twelve times -- and the eager path continues from there."""
+    n, K_STEPS = 256, 4
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+    for kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER):
+        env = BatchedEnv(_lib.default_config(kind, num_envs=n, seed=6, auto_reset=1, max_episode_steps=7), 'cuda:0')
+        o = orc.OracleEnv(orc.default_config(kind, num_envs=n, seed=6, auto_reset=1, max_episode_steps=7), np.float32)
+        env.reset(); o.reset()
+        acts = torch.rand(4, n, env.act_dim, device='cuda') * 2 - 1
+        static_a = acts[0].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # the warm-up launch torch asks for before a capture
+            env.step(static_a)
+        torch.cuda.current_stream().wait_stream(side)
+        o.step(acts[0].cpu().numpy())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(K_STEPS):
+                env.step(static_a)
+        for r in range(3):
+            static_a.copy_(acts[r + 1])
+            g.replay()
+            for _ in range(K_STEPS):
+                o.step(acts[r + 1].cpu().numpy())
+        torch.cuda.synchronize()
+        assert np.array_equal(env.state.cpu().numpy(), o.state) and np.array_equal(env.items.cpu().numpy(), o.items) and np.array_equal(env.aux.cpu().numpy(), o.aux)
+        assert np.array_equal(env.obs.cpu().numpy(), o.obs) and np.array_equal(env.done.cpu().numpy(), o.done)
+        assert int(o.aux[:, 2].min()) >= 2      # the 7-step limit passed inside a replay: in-kernel resets are part of the graph
+        env.step(acts[0]); o.step(acts[0].cpu().numpy())
+        assert np.array_equal(env.state.cpu().numpy(), o.state)
+        del g
+        env.close()
