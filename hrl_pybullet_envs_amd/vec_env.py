@@ -20,6 +20,8 @@ class BatchedEnv:
         if self.device.type != 'cuda' or not torch.cuda.is_available():
             raise _lib.HrlError('BatchedEnv needs an MI355X (torch.cuda.is_available() is False or a CPU device was '
                                 'requested): the env step has no CPU path')
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         L = _lib.lib()
         self.num_envs = cfg.num_envs
         self.obs_dim, self.act_dim = L.hrl_obs_dim(C.byref(cfg)), L.hrl_act_dim(C.byref(cfg))
@@ -40,10 +42,20 @@ class BatchedEnv:
                      'final_obs': torch.zeros(n, self.obs_dim, dtype=f32, device=dev), 'truncated': torch.zeros(n, dtype=torch.uint8, device=dev)}
         self._host = None         # pinned host buffers of step_host(), made on first use
         self._host_fresh = False  # the last step wrote its outputs to the host buffers: the device tensors are stale until read
+        self._bind()
+
+    def _bind(self):
+        """The buffer record handed to the library and what step() hands out as `info`, from the tensors as they are now.  Both are made once:
+        the tensors never move, a view costs a microsecond or two of host time, and an eager rollout loop is host-bound long before the GPU is."""
         o = self._out
+        self._info_views = {'food_rew': o['info'][:, 0], 'dead_rew': o['info'][:, 1], 'episode_return': o['info'][:, 2], 'episode_length': o['info'][:, 3],
+                            # valid where done: the terminal observation (the returned obs of such an env is already the next episode's first
+                            # when auto_reset is on) and gym's TimeLimit flag
+                            'final_observation': o['final_obs'], 'TimeLimit.truncated': o['truncated']}
         self._bufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), None,
                                    o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
                                    o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr())
+        self._bufs_ref = C.byref(self._bufs)
 
     def _device_out(self, name):
         """Output tensor `name` on the device.  step_host() leaves the step's outputs in pinned host memory only (that is its point: one
@@ -106,16 +118,18 @@ class BatchedEnv:
                 or tuple(actions.shape) != (self.num_envs, self.act_dim):
             actions = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, self.act_dim).contiguous()
         self._bufs.actions = actions.data_ptr()
-        self._before_device_launch()
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().hrl_step(self._h, C.byref(self._bufs), self._stream()))
+        if self._host_fresh:
+            self._before_device_launch()
+        if torch.cuda.current_device() == self.device.index:   # the usual case; the context manager costs more host time than the launch
+            rc = _lib.lib().hrl_step(self._h, self._bufs_ref, self._stream())
+        else:
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().hrl_step(self._h, self._bufs_ref, self._stream())
+        if rc != K.HRL_OK:
+            _lib.check(rc)
         self._last_actions = actions  # keep alive until the stream has consumed it
-        info = {'food_rew': self.info[:, 0], 'dead_rew': self.info[:, 1], 'episode_return': self.info[:, 2],
-                'episode_length': self.info[:, 3],
-                # valid where done: the terminal observation (the returned obs of such an env is already the next episode's first
-                # when auto_reset is on) and gym's TimeLimit flag
-                'final_observation': self.final_obs, 'TimeLimit.truncated': self.truncated}
-        return self.obs, self.reward, self.done, info
+        o = self._out                 # (current: a pending host refresh was brought over before the launch)
+        return o['obs'], o['reward'], o['done'], dict(self._info_views)
 
     def step_host(self, actions):
         """One step with HOST input and outputs -- what the reference's numpy-in / numpy-out `env.step(a)` hands over

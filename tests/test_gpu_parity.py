@@ -316,8 +316,7 @@ def test_env_counts_that_do_not_fill_the_last_group(n):
             g._out[k] = big[k][:n]   # the step's outputs are read through properties over this dict
         else:
             setattr(g, k, big[k][:n])
-    g._bufs = K.hrl_buffers(g.state.data_ptr(), g.items.data_ptr(), g.aux.data_ptr(), None, g.obs.data_ptr(), g.reward.data_ptr(),
-                            g.done.data_ptr(), g.info.data_ptr(), g.final_obs.data_ptr(), g.truncated.data_ptr())
+    g._bind()   # the buffer record of the library from the tensors as they are now
     g.reset(); o.reset()
     rng = np.random.RandomState(3)
     for t in range(25):
