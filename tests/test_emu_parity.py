@@ -600,12 +600,12 @@ def test_envs_that_blow_up_match_too(kind, auto_reset):
 
 @pytest.mark.parametrize('kind', KINDS)
 def test_fuzzed_absurd_values_stay_bit_exact(kind):
-    """tools/fuzz_parity.py: NaN, +-inf, 1e20, 3e38, denormals and signed zeros written into positions, velocities, item coordinates and actions
+    """tests/tools/fuzz_parity.py: NaN, +-inf, 1e20, 3e38, denormals and signed zeros written into positions, velocities, item coordinates and actions
     of running envs; every output of the wave phases equals the oracle's at every step (this found a cube at a NaN place being everywhere for the
     oracle and nowhere for the phases)."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_parity.py'))
+    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'fuzz_parity.py'))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     for seed in (0, 1):
         for ar in (0, 1):
@@ -758,13 +758,13 @@ def test_next_target_pops_the_shared_list_of_a_non_manual_env():
 
 
 def test_random_legal_configs():
-    """tools/fuzz_configs.py, a slice of it: every constructor argument and engine parameter drawn at random (biased to the edges of the capacity
+    """tests/tools/fuzz_configs.py, a slice of it: every constructor argument and engine parameter drawn at random (biased to the edges of the capacity
     ranges), teleports / masked resets / manual goals between the steps; the wave phases equal the oracle bit for bit after every step.
     (This fuzzer is what found that with robot_coll_dist <= 0 and use_sensor=0 the observation held the positions of touched items AFTER their
     move; the hand-picked matrix had both branches, never together.)"""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
     import fuzz_configs as F
     ended = 0
     for seed in range(5000, 5016):

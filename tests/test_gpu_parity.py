@@ -644,11 +644,11 @@ def test_envs_that_blow_up_match_too(kind, auto_reset):
 
 @pytest.mark.parametrize('kind', KINDS)
 def test_fuzzed_absurd_values_stay_bit_exact(kind):
-    """tools/fuzz_parity.py on the device: NaN, +-inf, 1e20, 3e38, denormals and signed zeros in positions, velocities, item coordinates and
+    """tests/tools/fuzz_parity.py on the device: NaN, +-inf, 1e20, 3e38, denormals and signed zeros in positions, velocities, item coordinates and
     actions of running envs; every output equals the oracle's at every step."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_parity.py'))
+    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'fuzz_parity.py'))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     for seed in (0, 1, 2):
         for ar in (0, 1):
@@ -765,11 +765,11 @@ def test_manual_goal_lists_longer_than_15_through_the_c_abi():
 
 
 def test_random_legal_configs_on_device():
-    """tools/fuzz_configs.py on the device: 600 random legal configs (constructor arguments, engine parameters, env counts that leave parked
+    """tests/tools/fuzz_configs.py on the device: 600 random legal configs (constructor arguments, engine parameters, env counts that leave parked
     waves, global ids beyond 2^32) x 30 steps with teleports, masked resets, manual goals in between; every buffer equals the oracle's bit for bit."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
     import fuzz_configs as F
     for seed in range(7000, 7100):
         for kind in F.KINDS:

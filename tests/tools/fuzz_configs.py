@@ -8,14 +8,14 @@ same state pushed into both sides), NaN / inf / 1e20 / denormals written into st
 goals `set_goals` / `next_target` on random masks.
 The hand-picked CONFIG_MATRIX of the parity tests covers the branches; this covers their combinations.
 
-    python tools/fuzz_configs.py [runs] [gpu|emu] [first_seed] [steps]"""
+    python tests/tools/fuzz_configs.py [runs] [gpu|emu] [first_seed] [steps]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import orc  # noqa: E402
 from hrl_pybullet_envs_amd import _capi as K  # noqa: E402
@@ -251,7 +251,7 @@ def run(Side, kind, seed, T):
                 o.state[r, 0:2] = xy; o.state[r, 2] = pick(rng, [0.35, 0.5, 0.75, 1.2]); o.state[r, 3:7] = [0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]
                 o.state[r, 15:21] = rng.uniform(-2, 2, 6)
             s.push(o)
-        if what == 4:      # absurd values in running envs (what a simulation that blows up can reach; tools/fuzz_parity.py does this on the default configs)
+        if what == 4:      # absurd values in running envs (what a simulation that blows up can reach; tests/tools/fuzz_parity.py does this on the default configs)
             nq, nv = (7, 6) if kind == K.HRL_POINT_GATHER else (15, 14)
             vmax = float(cfg.model.max_joint_vel)
             for r in rng.permutation(n)[:max(1, n // 3)]:

@@ -2,13 +2,13 @@
 """Parity under absurd inputs: the wave phases (the HIP kernels on a GPU box, `gpu`; the lock-step host executor of tests/emu, `emu`) against
 the fp32 oracle while NaN, +-inf, 1e20, 3e38, denormals and signed zeros are written into positions, velocities, item coordinates and actions of
 running envs -- the values a simulation that blows up can reach (quaternions are unit or NaN, joint angles moderate, joint rates within their clamp).
-Every output is compared bit for bit (NaNs as equal) at every step.    python tools/fuzz_parity.py [seeds] [gpu|emu] [matrix]"""
+Every output is compared bit for bit (NaNs as equal) at every step.    python tests/tools/fuzz_parity.py [seeds] [gpu|emu] [matrix]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import orc  # noqa: E402
 from hrl_pybullet_envs_amd import _capi as K  # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Print the distribution of single-step differences between the HIP kernels and the fp32 CPU oracle
-(identical state/items/action each step).  Run on a GPU box: python tools/gpu_parity_report.py [kind] [N] [T]"""
+(identical state/items/action each step).  Run on a GPU box: python tests/tools/gpu_parity_report.py [kind] [N] [T]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import orc  # noqa: E402
 from hrl_pybullet_envs_amd import _lib  # noqa: E402

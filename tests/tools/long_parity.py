@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: HIP kernels and the fp32 CPU oracle run FREE (no state copying) side by side for T steps with random actions and
 auto-reset; state / items / counters / reward / done are compared bit for bit at every step, and so are the observations.
-    python tools/long_parity.py [T] [N] [kind ...]"""
+    python tests/tools/long_parity.py [T] [N] [kind ...]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import orc  # noqa: E402
 from hrl_pybullet_envs_amd import _lib  # noqa: E402
