@@ -646,3 +646,42 @@ def test_steps_can_be_captured_in_a_hip_graph():
         assert np.array_equal(env.state.cpu().numpy(), o.state)
         del g
         env.close()
+
+
+def test_four_host_threads_each_with_its_own_env_and_stream():
+    """The library keeps no global state between handles (the error text is thread-local): four host threads, each stepping its own env on its
+    own stream at the same time, all end bit-identical to the oracle."""
+    import threading
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+    kinds = [K.HRL_ANT_GATHER, K.HRL_POINT_GATHER, K.HRL_ANT_MAZE, K.HRL_ANT_FLAGRUN]
+    n, T = 192, 150
+    out, errs = {}, []
+
+    def work(i, kind):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                env = BatchedEnv(_lib.default_config(kind, num_envs=n, seed=20 + i, auto_reset=1, max_episode_steps=40), 'cuda:0')
+                env.reset()
+                acts = torch.from_numpy(np.random.RandomState(i).uniform(-1, 1, (T, n, env.act_dim)).astype(np.float32)).cuda()
+                for t in range(T):
+                    env.step(acts[t])
+                s.synchronize()
+                out[i] = (env.state.cpu().numpy(), env.items.cpu().numpy(), env.aux.cpu().numpy(), env.obs.cpu().numpy())
+                env.close()
+        except Exception as e:   # pragma: no cover
+            errs.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i, k)) for i, k in enumerate(kinds)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errs, errs
+    for i, kind in enumerate(kinds):
+        o = orc.OracleEnv(orc.default_config(kind, num_envs=n, seed=20 + i, auto_reset=1, max_episode_steps=40), np.float32)
+        o.reset()
+        acts = np.random.RandomState(i).uniform(-1, 1, (T, n, o.ad)).astype(np.float32)
+        for t in range(T):
+            o.step(acts[t])
+        st, it, au, ob = out[i]
+        assert np.array_equal(st, o.state, equal_nan=True) and np.array_equal(it, o.items) and np.array_equal(au, o.aux) and np.array_equal(ob, o.obs, equal_nan=True), kind
