@@ -951,7 +951,43 @@ def main():
                     ant_obs=ant_obs.astype(float).tolist(), inner_rew=inner_rew, inner_done=inner_done, walk_target_dist=wtd,
                     obs=tolist(obs), rew=float(rew), done=bool(d))
 
-    G['random_config'] = {'gather_step': [random_gather_case(k) for k in range(70)], 'maze_step': [random_maze_case(k) for k in range(70)]}
+    def random_flagrun_case(k):
+        """ant_flagrun_env.py:122-130,162-204 with tolerance / timeout (0 = off) / switch_flag_on_collision / the wall sensor over an arena of
+        any size drawn at random (list mode: goals are popped from the back of the list)"""
+        lrs = np.random.RandomState(25000 + k)
+        size = f32(lrs.choice([10.0, 3.0, 6.0, 25.0]))
+        n_goals = int(lrs.randint(0, 4))
+        goals = [tuple(lrs.uniform(-size / 2, size / 2, 2)) for _ in range(n_goals)]
+        tol, timeout = f32(lrs.choice([0.5, 0.2, 1.0, 2.0])), int(lrs.choice([0, 1, 3, 5, 200]))
+        switch = bool(lrs.rand() < 0.6)
+        steps0, rewarded0 = int(lrs.randint(0, 7)), bool(lrs.rand() < 0.3)
+        wtd = float(lrs.uniform(0.0, 2.5))
+        inner_r, inner_d = float(lrs.uniform(-2, 2)), bool(lrs.rand() < 0.15)
+        s_old = lrs.uniform(-1, 1, 28).astype(np.float32); s_new = lrs.uniform(-1, 1, 28).astype(np.float32)
+        use_sensor = bool(lrs.rand() < 0.6)
+        n_bins = int(lrs.choice([2, 5, 8, 17, 40])); span = float(lrs.choice([np.pi, 2 * np.pi, f32(lrs.uniform(0.4, 6.0))])); srange = f32(lrs.choice([1.0, 4.0, 9.0]))
+        pos = np.r_[lrs.uniform(-size / 2, size / 2, 2), 0.5]
+        yaw = float(lrs.uniform(-np.pi, np.pi))
+        scene = SizeableEnclosedScene(None, 9.8, 0.0165 / 4, 4, (size + 2, size + 2))
+        robot = NS(walk_target_dist=wtd, walk_target_x=0.0, walk_target_y=0.0, body_real_xyz=pos, robot_body=NS(get_position=lambda: pos),
+                   calc_potential=lambda: -wtd / 0.0165, calc_state=lambda: s_new.copy())
+        self = AntFlagrunBulletEnv.__new__(AntFlagrunBulletEnv)
+        self.__dict__.update(dict(robot=robot, tol=tol, timeout=timeout, switch_flag_on_collision=switch, max_targets=100, goals=list(goals),
+                                  steps_since_goal_change=steps0, _rewarded=rewarded0, debug=False, use_sensor=use_sensor, n_bins=n_bins,
+                                  sensor_span=span, sensor_range=srange, scene=scene, robot_body=Body(list(pos), [0.01, -0.02, yaw]),
+                                  isRender=False, flag=None, walk_target_x=1.0, walk_target_y=2.0, _sq_dist_goal=3.0,
+                                  _goal_start_pos=np.array([0.5, 0.5]), potential=-77.0, _super_step_result=(s_old.copy(), inner_r, inner_d, {})))
+        obs, r, d, info = AntFlagrunBulletEnv.step(self, np.zeros(8))
+        return {'size': size, 'n_goals': n_goals, 'last_goal': list(map(float, goals[-1])) if goals else None, 'tol': tol, 'timeout': timeout, 'switch': switch,
+                'steps_before': steps0, 'rewarded_before': rewarded0, 'walk_target_dist': wtd, 'inner_rew': inner_r, 'inner_done': inner_d,
+                'use_sensor': use_sensor, 'n_bins': n_bins, 'span': span, 'range': srange, 'pos': [float(pos[0]), float(pos[1])], 'yaw': yaw,
+                'arena_bounds': bounds_list(scene), 'rew': float(r), 'done': bool(d), 'steps_after': int(self.steps_since_goal_change),
+                'rewarded_after': bool(self._rewarded), 'goals_left': len(self.goals), 'retargeted': bool('target' in info),
+                'state_is_new': bool(np.array_equal(np.asarray(obs)[:28], s_new)), 'sensor': tolist(np.asarray(obs)[28:]),
+                'target_after': [float(self.walk_target_x), float(self.walk_target_y)]}
+
+    G['random_config'] = {'gather_step': [random_gather_case(k) for k in range(70)], 'maze_step': [random_maze_case(k) for k in range(70)],
+                          'flagrun_step': [random_flagrun_case(k) for k in range(80)]}
 
     # ---------------------------------------------------------------- the constructor surfaces and the registration (SURVEY 8b: the boundary)
     # inspect.signature of every env class a user constructs, and the keyword arguments hrl_pybullet_envs/__init__.py:11-16 registered with gym

@@ -480,6 +480,38 @@ def test_random_constructor_arguments_maze_step():
     assert len(seen) >= 12
 
 
+def test_random_constructor_arguments_flagrun_step():
+    """`random_config.json`: AntFlagrunBulletEnv.step (ant_flagrun_env.py:162-204) and its observation (:122-130) with tolerance, timeout (0: off),
+    switch_flag_on_collision and the wall sensor (bins, span, range, arena of any size) drawn at random; the arena's lines as the oracle derives
+    them from `size + 2` (:59-61) equal the reference scene's bounds."""
+    seen = set()
+    for c in load('random_config')['flagrun_step']:
+        cfg = orc.default_config(K.HRL_ANT_FLAGRUN, tol=c['tol'], flag_timeout=c['timeout'], flag_switch_on_collision=int(c['switch']), flag_size=c['size'],
+                                 world_size=(c['size'] + 2, c['size'] + 2), use_sensor=int(c['use_sensor']), n_bins=c['n_bins'], sensor_span=c['span'],
+                                 sensor_range=c['range'])
+        steps = C.c_int(c['steps_before']); rewarded = C.c_int(int(c['rewarded_before'])); left = C.c_int(c['n_goals'])
+        rew = C.c_double(); done = C.c_int(); retarget = C.c_int()
+        orc.lib().orc_flagrun_task_f64(C.byref(cfg), C.c_double(c['inner_rew']), int(c['inner_done']), C.c_double(c['walk_target_dist']),
+                                       C.byref(steps), C.byref(rewarded), C.byref(left), C.byref(rew), C.byref(done), C.byref(retarget))
+        assert rew.value == pytest.approx(c['rew'], abs=1e-9) and bool(done.value) == c['done']
+        assert steps.value == c['steps_after'] and bool(rewarded.value) == c['rewarded_after'] and left.value == c['goals_left']
+        assert bool(retarget.value) == c['retargeted'] == c['state_is_new']
+        if c['retargeted']:
+            assert c['target_after'] == c['last_goal']
+        hx = (c['size'] + 2) / 2
+        mine = [[[hx, hx], [-hx, hx]], [[hx, hx], [hx, -hx]], [[-hx, -hx], [-hx, hx]], [[-hx, -hx], [hx, -hx]]]   # orc_impl.h: the four arena lines of the flagrun observation
+        assert mine == c['arena_bounds']
+        assert len(c['sensor']) == (c['n_bins'] if c['use_sensor'] else 0)
+        if c['use_sensor']:
+            out = np.zeros(c['n_bins'])
+            ln = arr(c['arena_bounds']).reshape(-1, 4)
+            orc.lib().orc_sense_walls_f64(c['n_bins'], C.c_double(c['span']), C.c_double(c['range']), orc.ptr(arr(c['pos'])), C.c_double(c['yaw']), orc.ptr(ln), 4,
+                                          int(c['span'] == 2 * math.pi), orc.ptr(out))
+            np.testing.assert_allclose(out, c['sensor'], rtol=0, atol=1e-12)
+        seen.add((c['done'], c['retargeted'], c['timeout'] > 0, c['switch']))
+    assert len(seen) >= 8
+
+
 def test_reset_potential_belongs_to_the_previous_target():
     """Sequence fixture (reference reset()/next_target()/step() run in-tree around a restated upstream bookkeeping, see
     make_golden.py): the potential a reset leaves is the distance to the PREVIOUS target -- from the new pose (flagrun,
