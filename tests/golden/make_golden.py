@@ -986,8 +986,38 @@ def main():
                 'state_is_new': bool(np.array_equal(np.asarray(obs)[:28], s_new)), 'sensor': tolist(np.asarray(obs)[28:]),
                 'target_after': [float(self.walk_target_x), float(self.walk_target_y)]}
 
+    def random_maze_mj_case(k):
+        """ant_maze_mj_env.py:57-78 with n_bins / sensor span and range / tol / inner_rew_weight drawn at random"""
+        lrs = np.random.RandomState(26000 + k)
+        n_bins = int(lrs.choice([2, 3, 10, 16, 17, 33, 64]))
+        span = float(lrs.choice([2 * np.pi, np.pi, f32(lrs.uniform(0.3, 6.5))])); srange = f32(lrs.choice([2.0, 5.0, 9.0, 30.0]))
+        tol, w = f32(lrs.choice([1.5, 0.2, 0.8, 3.0, 12.0])), f32(lrs.choice([0.0, 0.5, 1.0, -2.0]))
+        target = np.array([f32(lrs.uniform(-4.5, 4.5)), f32(lrs.uniform(-8.5, 8.5))])
+        xy = np.array([lrs.uniform(-4.5, 4.5), lrs.uniform(-8.5, 8.5)])
+        if lrs.rand() < 0.5:
+            xy = target + lrs.uniform(-1.0, 1.0, 2) * min(tol, 3.0)
+        state = lrs.uniform(-1, 1, 29)
+        state[0], state[1], state[2] = xy[0], xy[1], lrs.uniform(0.2, 0.8)
+        rpy = [lrs.uniform(-.2, .2), lrs.uniform(-.2, .2), lrs.uniform(-np.pi, np.pi)]
+        pot_old = float(lrs.uniform(-700, -100)); pot_new = pot_old + float(lrs.uniform(-3, 3))
+        n_lim, t0 = int(lrs.randint(0, 4)), int(lrs.randint(0, 500))
+        wtd = float(np.linalg.norm(target - (xy + lrs.uniform(-0.3, 0.3, 2))))
+        robot = NS(apply_action=lambda a: None, calc_state=lambda: state.copy(), initial_z=0.25, body_rpy=rpy, calc_potential=lambda: pot_new, feet=[],
+                   feet_contact=np.zeros(4), joints_at_limit=n_lim, walk_target_dist=wtd)
+        robot.alive_bonus = lambda z, pitch: MjAnt.alive_bonus(robot, z, pitch)
+        self = _AntMazeMjEnv.__new__(_AntMazeMjEnv)
+        self.__dict__.update(dict(robot=robot, scene=maze, potential=pot_old, joints_at_limit_cost=-0.1, ground_ids=set(), reward=0.0, n_bins=n_bins,
+                                  sensor_span=span, sensor_range=srange, targets=[list(target)], tol=tol, inner_rew_weight=w, t=t0, target=target, debug=0,
+                                  robot_body=Body([xy[0], xy[1], state[2]], rpy)))
+        maze.global_step = lambda: None
+        obs, rew, d, _ = _AntMazeMjEnv.step(self, np.zeros(8))
+        return {'n_bins': n_bins, 'span': span, 'range': srange, 'tol': tol, 'state': state.tolist(), 'rpy': list(map(float, rpy)), 'target': target.tolist(),
+                't_before': t0, 'potential_old': pot_old, 'potential_new': pot_new, 'joints_at_limit': n_lim, 'walk_target_dist': wtd,
+                'inner_rew_weight': w, 'obs': tolist(obs), 'rew': float(rew), 'done': bool(d), 't_after': int(self.t)}
+
+    from hrl_pybullet_envs.envs.ant_maze.ant_maze_mj_env import AntMazeMjEnv as _AntMazeMjEnv
     G['random_config'] = {'gather_step': [random_gather_case(k) for k in range(70)], 'maze_step': [random_maze_case(k) for k in range(70)],
-                          'flagrun_step': [random_flagrun_case(k) for k in range(80)]}
+                          'flagrun_step': [random_flagrun_case(k) for k in range(80)], 'maze_mj_step': [random_maze_mj_case(k) for k in range(50)]}
 
     # ---------------------------------------------------------------- the constructor surfaces and the registration (SURVEY 8b: the boundary)
     # inspect.signature of every env class a user constructs, and the keyword arguments hrl_pybullet_envs/__init__.py:11-16 registered with gym

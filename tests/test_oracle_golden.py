@@ -228,11 +228,17 @@ def test_maze_mj_step_task_half():
     check_maze_mj_step(load('maze_mj_step'))
 
 
+def test_random_constructor_arguments_maze_mj_step():
+    """`random_config.json`: AntMazeMjEnv.step (ant_maze_mj_env.py:57-78) with n_bins, sensor span / range, tol and inner_rew_weight drawn at random."""
+    check_maze_mj_step(load('random_config')['maze_mj_step'])
+
+
 def check_maze_mj_step(cases):
     lines = arr(load('sense_walls')['maze_bounds']).reshape(-1, 4)
     for c in cases:
         nb = c.get('n_bins', 10)
-        cfg = orc.default_config(K.HRL_ANT_MAZE_MJ, inner_rew_weight=c['inner_rew_weight'], n_bins=nb)
+        extra = {k2: c[k1] for k1, k2 in (('span', 'sensor_span'), ('range', 'sensor_range'), ('tol', 'tol')) if k1 in c}   # (the random-argument cases carry them)
+        cfg = orc.default_config(K.HRL_ANT_MAZE_MJ, inner_rew_weight=c['inner_rew_weight'], n_bins=nb, **extra)
         assert orc.obs_dim(cfg) == 30 + 3 * nb == len(c['obs'])
         inner = C.c_double(); idone = C.c_int()
         orc.lib().orc_antmj_reward_f64(orc.ptr(arr(c['state'])), C.c_double(c['potential_old']), C.c_double(c['potential_new']),
