@@ -1019,6 +1019,18 @@ def main():
     G['random_config'] = {'gather_step': [random_gather_case(k) for k in range(70)], 'maze_step': [random_maze_case(k) for k in range(70)],
                           'flagrun_step': [random_flagrun_case(k) for k in range(80)], 'maze_mj_step': [random_maze_mj_case(k) for k in range(50)]}
 
+    def random_scene(k):
+        """gather_scene.py:38-62,95-114: spawn / restart / reward_collision with world size, item counts, spacing and respawn drawn at random"""
+        lrs = np.random.RandomState(27000 + k)
+        world = (f32(lrs.uniform(5, 26)), f32(lrs.uniform(5, 26)))
+        nf, npo = int(lrs.choice([0, 1, 8, 17, 30])), int(lrs.choice([0, 1, 8, 17, 30]))
+        if nf + npo == 0: nf = 1
+        spacing = f32(lrs.uniform(0.3, min(world) / 3.2))
+        hits = [(int(lrs.randint(0, nf + npo + 1)), (float(lrs.uniform(-world[0] / 2, world[0] / 2)), float(lrs.uniform(-world[1] / 2, world[1] / 2)), 0.5)) for _ in range(6)]
+        return scene_run(27500 + k, world, nf, npo, spacing, bool(lrs.rand() < 0.7), hits)
+
+    G['random_config']['gather_scene'] = [random_scene(k) for k in range(14)]
+
     # ---------------------------------------------------------------- the constructor surfaces and the registration (SURVEY 8b: the boundary)
     # inspect.signature of every env class a user constructs, and the keyword arguments hrl_pybullet_envs/__init__.py:11-16 registered with gym
     import enum

@@ -101,6 +101,12 @@ def test_gather_scene_respawn():
     check_gather_scene(load('gather_scene'))
 
 
+def test_random_constructor_arguments_gather_scene():
+    """`random_config.json`: GatherScene with world size, item counts (up to 60), spacing and respawn drawn at random: spawn, restart and
+    reward_collision replayed with the uniform draws the reference consumed."""
+    check_gather_scene(load('random_config')['gather_scene'])
+
+
 def check_gather_scene(cases):
     for sc in cases:
         ws = arr(sc['world'])
