@@ -33,6 +33,9 @@ def init_distributed(expected_world=None, backend=None, force=False):
                            f'python -m torch.distributed.run --nproc-per-node {expected_world} ... '
                            f'(bench.py spawns the ranks itself when WORLD_SIZE is unset)')
     if (world > 1 or force) and not dist.is_initialized():
+        # dmabuf IPC between the ranks' processes (RCCL over xGMI needs it on this driver); only effective if nothing has touched the GPU yet,
+        # which holds for bench.py and for anything that calls this first.  A launcher's own export wins.
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
