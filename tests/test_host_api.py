@@ -419,3 +419,31 @@ def test_constructor_arguments_reach_the_config():
         H.AntFlagrunBulletEnv(max_targets=5, max_target_dist=3.0)    # ant_flagrun_env.py:17-18
     with pytest.raises(ValueError):
         H.AntMazeBulletEnv(target_encoding=2)                        # PositionEncoding(2), utils.py:66-68
+
+
+def test_alias_makes_the_references_import_lines_work():
+    """`import hrl_pybullet_envs_amd.alias`: the import lines of a script written against the reference (README.md:19-22, the module paths of
+    hrl_pybullet_envs/__init__.py:3-7) resolve to this package.  Run in a child process: the alias is process-wide."""
+    import subprocess
+    import sys
+    code = '''
+import hrl_pybullet_envs_amd.alias
+import hrl_pybullet_envs
+from hrl_pybullet_envs.envs.gather.ant_gather_env import AntGatherBulletEnv
+from hrl_pybullet_envs.envs.gather.point_gather_env import PointGatherBulletEnv
+from hrl_pybullet_envs.envs.ant_maze.ant_maze_bullet_env import AntMazeBulletEnv
+from hrl_pybullet_envs.envs.ant_maze.ant_maze_mj_env import AntMazeMjEnv
+from hrl_pybullet_envs.envs.ant_flagrun.ant_flagrun_env import AntFlagrunBulletEnv
+from hrl_pybullet_envs.envs.MjAnt import AntMjEnv, MjAnt
+from hrl_pybullet_envs.utils import PositionEncoding
+import hrl_pybullet_envs_amd as H
+assert hrl_pybullet_envs is H and AntGatherBulletEnv is H.AntGatherBulletEnv and AntMazeMjEnv is H.AntMazeMjEnv and AntFlagrunBulletEnv is H.AntFlagrunBulletEnv
+assert AntGatherBulletEnv(n_food=3).observation_space.shape == (46,) and hrl_pybullet_envs.make('PointGatherBulletEnv-v0').max_episode_steps == 2000
+print('alias-ok')
+'''
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and 'alias-ok' in r.stdout, r.stderr[-2000:]
+    # with the real reference already imported the alias refuses instead of shadowing it
+    code2 = "import sys, types; sys.modules['hrl_pybullet_envs'] = types.ModuleType('hrl_pybullet_envs')\ntry:\n    import hrl_pybullet_envs_amd.alias\nexcept ImportError as e:\n    print('refused', e)"
+    r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert 'refused' in r.stdout, (r.stdout, r.stderr[-1000:])
