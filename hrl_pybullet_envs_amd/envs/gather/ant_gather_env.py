@@ -38,3 +38,11 @@ class AntGatherBulletEnv(BatchedGymEnv):
         self.n_food, self.n_poison, self.world_size = n_food, n_poison, world_size
         self.spacing, self.respawn, self.debug = robot_object_spacing, respawn, debug
         self._finish_init(cfg, num_envs, device, seed)
+
+    @property
+    def stadium_scene(self):
+        """`env.stadium_scene` (ant_gather_env.py:57-60): the items as the reference's scene holds them -- `food`, `poison`, `all_items` --, read from the env's tensors."""
+        from .gather_scene import GatherScene
+        return GatherScene(self)
+
+    scene = stadium_scene

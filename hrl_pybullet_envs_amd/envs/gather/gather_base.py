@@ -50,6 +50,14 @@ class GatherBulletEnv(BatchedGymEnv):
         self._finish_init(cfg, num_envs, device, seed)
 
     @property
+    def stadium_scene(self):
+        """`env.stadium_scene` (gather_base.py:57-60): the items as the reference's scene holds them -- `food`, `poison`, `all_items` --, read from the env's tensors."""
+        from .gather_scene import GatherScene
+        return GatherScene(self)
+
+    scene = stadium_scene
+
+    @property
     def robot(self):
         """The robot object handed to the constructor (gather_base.py:31); a PointBot reads its live pose attributes
         (body_real_xyz, body_xyz, body_rpy) from this env's state through `_view`."""

@@ -484,10 +484,15 @@ def test_attributes_a_trainer_reads_between_steps():
     p = H.PointGatherBulletEnv(seed=1)
     p.reset()
     p.step(np.array([1.0, 0.0]))
+    sc = p.stadium_scene                     # gather_scene.py:22-33: the item dictionaries of the scene, over the env's items tensor
+    it = p._backend().items[0].cpu().numpy()
+    assert len(sc.food) == 8 and len(sc.poison) == 8 and len(sc.all_items) == 16 and sc.food[3] == [float(it[6]), float(it[7]), 0.1] and sc.poison[8][:2] == [float(it[16]), float(it[17])]
+    assert p.scene.size == (15, 15) and (sc.n_food, sc.n_poison, sc.spacing, sc.respawn) == (8, 8, 2., True)
     assert np.allclose(p.robot.body_real_xyz, p._backend().state[0, 0:3].cpu().numpy()) and p.robot.alive_bonus(0, 0) == 1
     p.close()
     a = H.AntGatherBulletEnv(num_envs=8, seed=1)
     a.reset()
+    assert tuple(a.stadium_scene.food.shape) == (8, 8, 2) and torch.equal(a.stadium_scene.all_items.reshape(8, 32), a._backend().items[:, :32])   # a batch: tensors
     assert a.robot.body_xyz.shape == (8, 3) and a.robot.body_real_xyz.shape == (8, 3)
     a.close()
 
