@@ -447,3 +447,23 @@ print('alias-ok')
     code2 = "import sys, types; sys.modules['hrl_pybullet_envs'] = types.ModuleType('hrl_pybullet_envs')\ntry:\n    import hrl_pybullet_envs_amd.alias\nexcept ImportError as e:\n    print('refused', e)"
     r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert 'refused' in r.stdout, (r.stdout, r.stderr[-1000:])
+
+
+def test_intersection_utils_mirror_equals_the_references_values():
+    """hrl_pybullet_envs_amd/envs/intersection_utils.py (the host-side mirror a user script may import from the reference's path) against
+    `tests/golden/intersection.json`, produced by the reference's own functions."""
+    import json
+    from hrl_pybullet_envs_amd.envs import intersection_utils as iu
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'intersection.json')))
+    for c in g['lines']:
+        p = [iu.Point(*q) for q in c['p']]
+        r = iu.inf_intersection(*p)
+        assert (r is None) == (c['inf'] is None) and (r is None or (r.x, r.y) == tuple(c['inf']))
+        assert iu.segment_intersection(*p) == c['seg']
+    for c in g['quadrant']:
+        assert iu.quadrant(iu.Point(*c['p'])) == c['q']
+    for c in g['pol2cart']:
+        assert np.allclose(iu.pol2cart(c['rho'], c['phi']), c['xy'], rtol=0, atol=1e-15)
+    with pytest.raises(Exception, match='never happen'):
+        iu.quadrant(iu.Point(float('nan'), 1.0))
+    assert len(g['lines']) > 50
