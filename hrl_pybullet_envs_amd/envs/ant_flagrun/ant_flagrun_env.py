@@ -40,6 +40,17 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         self.use_sensor, self.n_bins, self.sensor_span, self.sensor_range, self.debug = use_sensor, sensor_bins, sensor_span, sensor_range, debug
         self._finish_init(cfg, num_envs, device, seed)
 
+    @property
+    def stadium_scene(self):
+        """`env.stadium_scene` / `env.scene` (ant_flagrun_env.py:57-64): the (size + 2)-sided arena when the env is enclosed or senses walls
+        (its bounding lines and a host-side `sense_walls`); the open stadium of the upstream env has no bounding lines: None."""
+        if not (self.enclosed or self.use_sensor):
+            return None
+        from ..sizeable_enclosed_scene import SizeableEnclosedScene
+        return SizeableEnclosedScene((self.size + 2, self.size + 2))
+
+    scene = stadium_scene
+
     # ---- the goal list (ant_flagrun_env.py:45,91-120) over the env's `items` / `aux` tensors (include/hrl_envs.h) ----
     def _listed(self):
         return self.manual_goal_creation and not self.max_target_dist > 0

@@ -29,6 +29,14 @@ class AntMazeBulletEnv(BatchedGymEnv):
         self.inner_rew_weight, self.targ_dist_rew, self.target_encoding, self.debug = inner_rew_weight, targ_dist_rew, target_encoding, debug
         self._finish_init(cfg, num_envs, device, seed)
 
+    @property
+    def stadium_scene(self):
+        """`env.stadium_scene` / `env.scene` (ant_maze_bullet_env.py:59-61): the maze's bounding lines and a host-side `sense_walls`."""
+        from .maze_scene import MazeScene
+        return MazeScene()
+
+    scene = stadium_scene
+
     # ant_maze_bullet_env.py:38,46,108-110: attributes a trainer reads between steps, over the state tensors
     @property
     def t(self):

@@ -25,6 +25,8 @@ class AntMazeMjEnv(BatchedGymEnv):
         self._finish_init(cfg, num_envs, device, seed)
 
     t = AntMazeBulletEnv.t                      # ant_maze_mj_env.py:38,70
+    stadium_scene = AntMazeBulletEnv.stadium_scene   # :52-54: the same MazeScene
+    scene = AntMazeBulletEnv.scene
     target = AntMazeBulletEnv.target            # :44,:91
     _walk_target = AntMazeBulletEnv._walk_target
     walk_target_x = AntMazeBulletEnv.walk_target_x

@@ -3,12 +3,15 @@ dictionaries and the scene's constructor arguments.  Spawning, respawning and th
 respawn_item, phase_items); this class is a read-only view over the env's `items` tensor."""
 
 
-class GatherScene:
+from ..sizeable_enclosed_scene import SizeableEnclosedScene
+
+
+class GatherScene(SizeableEnclosedScene):
     def __init__(self, env):
+        super().__init__(env.world_size)      # the arena's bounding lines and a host-side sense_walls (sizeable_enclosed_scene.py)
         self._e = env
         self.n_food, self.n_poison = env.n_food, env.n_poison
         self.spacing, self.respawn = env.spacing, env.respawn
-        self.size, self.center = tuple(env.world_size), (0, 0)
 
     def _xy(self):
         b = self._e._backend()
@@ -31,8 +34,3 @@ class GatherScene:
             return self._xy()
         return {**self.food, **self.poison}
 
-    @property
-    def bounds(self):
-        """The four lines of the arena, ((x1, y1), (x2, y2)) each, in the reference's order (sizeable_enclosed_scene.py:28-34)."""
-        hx, hy = self.size[0] / 2, self.size[1] / 2
-        return [((hx, hy), (-hx, hy)), ((hx, hy), (hx, -hy)), ((-hx, -hy), (-hx, hy)), ((-hx, -hy), (hx, -hy))]
