@@ -272,3 +272,35 @@ def test_optimised_spec_equals_textbook_over_the_model_parameters():
         worst = max(worst, err / scale); rows.append(out.n_rows)
     assert np.mean(rows) > 4 and max(rows) >= 12
     print(f'random model parameters: worst scaled |diff| {worst:.2e}, rows mean {np.mean(rows):.1f} max {max(rows)}')
+
+
+def test_pointbot_spec_equals_textbook_over_states_and_parameters():
+    """The PointBot's cube (ground + arena walls, no item cubes: the frozen reference predates the cube-corner contacts) from 400 random states --
+    any yaw, tipped up to 0.5 rad, against the walls, moving, pushed --, each with its own engine parameters: one substep of the optimised
+    specification against the frozen textbook reference <= 1e-9."""
+    rng = np.random.RandomState(91)
+    worst, contacts = 0.0, []
+    for i in range(400):
+        f32 = lambda x: float(np.float32(x))
+        wx, wy = f32(rng.uniform(4, 20)), f32(rng.uniform(4, 20))
+        cfg = orc.default_config(K.HRL_POINT_GATHER, world_size=(wx, wy), model_gravity=f32(rng.choice([1.6, 9.8, 20.0])), model_timestep=f32(rng.uniform(0.001, 0.008)),
+                                 model_contact_erp=f32(rng.uniform(0, 1)), model_friction_ground=f32(rng.choice([0.0, 0.3, 0.8, 3.0])),
+                                 model_friction_robot=f32(rng.choice([0.0, 0.1, 1.0])), model_contact_dist=f32(rng.choice([0.0, 0.005, 0.02, 0.08])),
+                                 model_ground_z=f32(rng.choice([0.0, 0.005, 0.05])), model_solver_iters=int(rng.choice([1, 2, 5, 13])))
+        p = tb.params(cfg)
+        q = np.zeros(7)
+        q[0], q[1] = rng.uniform(-wx / 2, wx / 2), rng.uniform(-wy / 2, wy / 2)
+        if i % 2: q[rng.randint(2)] = rng.choice([-1, 1]) * ((wx, wy)[0] / 2 - rng.uniform(0.2, 0.6))
+        q[2] = rng.uniform(0.3, 0.6)
+        ax = rng.normal(size=3); ax[2] *= 3; ax /= np.linalg.norm(ax); ang = rng.uniform(-np.pi, np.pi) if abs(ax[2]) > 0.95 else rng.uniform(-0.5, 0.5)
+        q[3:6], q[6] = ax * np.sin(ang / 2), np.cos(ang / 2)
+        u = rng.normal(size=6) * np.r_[np.full(3, 1.5), np.full(3, 2.0)]
+        force = np.r_[rng.uniform(-500, 500, 2), 0.0]
+        q1, u1, out = tb.point_substep(p, q, u, force)
+        q2, u2 = q.copy(), u.copy()
+        orc.lib().orc_point_substeps_f64(C.byref(cfg), orc.ptr(q2), orc.ptr(u2), orc.ptr(force), 1)
+        err = max(np.abs(q1 - q2).max(), np.abs(u1 - u2).max())
+        assert err <= TOL * max(1.0, np.abs(u1).max()), (i, err, out.n_contacts)
+        worst = max(worst, err); contacts.append(out.n_contacts)
+    assert np.mean(contacts) > 1.5 and max(contacts) >= 6
+    print(f'point bot, random states and parameters: worst |diff| {worst:.2e}, contacts mean {np.mean(contacts):.1f} max {max(contacts)}')
