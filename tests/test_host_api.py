@@ -492,3 +492,22 @@ def test_scene_mirrors_equal_the_references_bounds_and_wall_sensor():
         if c['use_sensor']:
             assert np.abs(np.array(f.scene.sense_walls(c['n_bins'], c['span'], c['range'], c['pos'], c['yaw']), float) - np.array(c['sensor'])).max() <= 1e-12
     assert H.AntFlagrunBulletEnv(enclosed=False).scene is None
+
+
+def test_evidence_index_points_at_files_that_exist():
+    """profiles/INDEX.md maps claims to raw files: every `r4_*` / `pmc_summary.json` name it cites is committed (globs expand to at least one file),
+    and so is every tool it names."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'profiles', 'INDEX.md')).read()
+    names = set(re.findall(r'`((?:r4_|pmc_summary)[A-Za-z0-9_{},.*]*\.(?:json|txt|csv|patch))`', text))
+    assert len(names) > 20
+    for n in names:
+        alts = [n]
+        m = re.search(r'\{([^}]*)\}', n)
+        if m:
+            alts = [n[:m.start()] + a + n[m.end():] for a in m.group(1).split(',')]
+        for a in alts:
+            assert glob.glob(os.path.join(root, 'profiles', a)), a
+    for t in set(re.findall(r'`(?:python |bash )?((?:tests/)?tools/[a-z_]+\.(?:py|sh))', text)):
+        assert os.path.exists(os.path.join(root, t)), t
