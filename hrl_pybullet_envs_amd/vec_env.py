@@ -52,10 +52,19 @@ class BatchedEnv:
                             # valid where done: the terminal observation (the returned obs of such an env is already the next episode's first
                             # when auto_reset is on) and gym's TimeLimit flag
                             'final_observation': o['final_obs'], 'TimeLimit.truncated': o['truncated']}
-        self._bufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), None,
+        # the items record is state of the gather kinds (item positions) and of a flagrun env with manual goals or goals near the robot; the other
+        # kinds keep nothing in it, and the library takes NULL for it (include/hrl_envs.h): 128 B per env and step less to read and to write back
+        c = self.cfg
+        self._uses_items = c.env_kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) or \
+            (c.env_kind == K.HRL_ANT_FLAGRUN and (bool(c.flag_manual_goals) or c.flag_max_target_dist > 0))
+        self._bufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr() if self._uses_items else None, self.aux.data_ptr(), None,
                                    o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
                                    o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr())
         self._bufs_ref = C.byref(self._bufs)
+        # set_goals always hands the items record over: an env that has no use for it is refused by the library with the reason (not a manual env)
+        self._bufs_with_items = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), None,
+                                              o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
+                                              o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr())
 
     def _device_out(self, name):
         """Output tensor `name` on the device.  step_host() leaves the step's outputs in pinned host memory only (that is its point: one
@@ -151,7 +160,7 @@ class BatchedEnv:
             self._host = t
             self._host_np = {k: v.numpy() for k, v in t.items()}
             self._host_ended = np.zeros(self.num_envs, bool)  # envs whose episode ended in a host step since the device tensors were refreshed
-            self._hbufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), t['act'].data_ptr(),
+            self._hbufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr() if self._uses_items else None, self.aux.data_ptr(), t['act'].data_ptr(),
                                         t['obs'].data_ptr(), t['rew'].data_ptr(), t['done'].data_ptr(), t['info'].data_ptr(),
                                         t['final_obs'].data_ptr(), t['trunc'].data_ptr())
         h = self._host_np
@@ -175,7 +184,7 @@ class BatchedEnv:
         m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
         self._before_device_launch()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().hrl_set_goals(self._h, C.byref(self._bufs), goals.data_ptr(), int(goals.shape[1]),
+            _lib.check(_lib.lib().hrl_set_goals(self._h, C.byref(self._bufs_with_items), goals.data_ptr(), int(goals.shape[1]),
                                                 None if m is None else m.data_ptr(), self._stream()))
         self._last_goals = goals  # keep alive until the stream has consumed it
         return self.obs

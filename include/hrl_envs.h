@@ -148,7 +148,7 @@ typedef struct hrl_config {
 /* Caller-owned buffers of one shard.  Unused pointers may be NULL (items for non-gather kinds). */
 typedef struct hrl_buffers {
     float *state;         /* [N][HRL_STATE_STRIDE]  in/out */
-    float *items;         /* [N][hrl_items_stride()] in/out (gather kinds; flagrun with max_target_dist or manual goals) */
+    float *items;         /* [N][hrl_items_stride()] in/out (gather kinds; flagrun with max_target_dist or manual goals); the other kinds keep nothing in it: pass NULL and the record is neither read nor written */
     int32_t *aux;         /* [N][HRL_AUX_STRIDE]    in/out */
     const float *actions; /* [N][act_dim]           in  (step only) */
     float *obs;           /* [N][obs_dim]           out */
