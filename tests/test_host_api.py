@@ -516,9 +516,10 @@ def test_evidence_index_points_at_files_that_exist():
 def test_readme_and_design_cite_tools_and_tests_that_exist():
     """Every `tools/...`, `tests/tools/...`, `tests/...py` path and every `tests/...::test_name` the top-level documents cite is in the tree."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for doc in ('README.md', 'DESIGN.md', 'INTEGRATION.md', os.path.join('profiles', 'INDEX.md')):
+    for doc in ('README.md', 'DESIGN.md', 'INTEGRATION.md', os.path.join('profiles', 'INDEX.md'), os.path.join('profiles', 'EXPERIMENTS.md')):
         text = open(os.path.join(root, doc)).read()
-        for path in set(re.findall(r'((?:tests/)?tools/(?:micro/)?[A-Za-z_0-9]+\.(?:py|sh|hip))', text)) | set(re.findall(r'(tests/[A-Za-z_0-9/]+\.(?:py|c|cpp|json))', text)):
+        for path in set(re.findall(r'((?:tests/)?tools/(?:micro/)?[A-Za-z_0-9]+\.(?:py|sh|hip))', text)) | set(re.findall(r'(tests/[A-Za-z_0-9/]+\.(?:py|c|cpp|json))', text)) \
+                | set(re.findall(r'(profiles/[A-Za-z_0-9]+\.(?:json|txt|csv|patch))', text)):
             assert os.path.exists(os.path.join(root, path)), (doc, path)
         for path, name in set(re.findall(r'(tests/[A-Za-z_0-9]+\.py)::([A-Za-z_0-9]+)', text)):
             src = open(os.path.join(root, path)).read()
