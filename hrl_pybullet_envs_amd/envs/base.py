@@ -106,8 +106,10 @@ class BatchedGymEnv:
             self._env = None
         return [seed]
 
-    def reset(self):
-        obs = self._backend().reset()
+    def reset(self, mask=None):
+        """`env.reset()` of the reference.  A batch may reset some of its envs only: `mask` [N] (bool / uint8 tensor), non-zero = reset;
+        the others keep their state and their row of the returned observations."""
+        obs = self._backend().reset(mask)
         if self.num_envs == 1:
             return obs[0].double().cpu().numpy()
         return obs

@@ -492,6 +492,13 @@ def test_attributes_a_trainer_reads_between_steps():
     p.close()
     a = H.AntGatherBulletEnv(num_envs=8, seed=1)
     a.reset()
+    st0 = a._backend().state.clone()
+    a.step(torch.rand(8, 8, device='cuda') * 2 - 1)
+    st1 = a._backend().state.clone()
+    a.reset(mask=torch.tensor([1, 0, 0, 1, 0, 0, 0, 0], dtype=torch.bool))       # a batch resets the envs the mask names, the others go on
+    st2 = a._backend().state
+    assert torch.equal(st2[[1, 2, 4, 5, 6, 7]], st1[[1, 2, 4, 5, 6, 7]]) and not torch.equal(st2[[0, 3]], st1[[0, 3]]) and bool((st2[[0, 3], 2] == 0.75).all())
+    a.reset()
     assert tuple(a.stadium_scene.food.shape) == (8, 8, 2) and torch.equal(a.stadium_scene.all_items.reshape(8, 32), a._backend().items[:, :32])   # a batch: tensors
     assert a.robot.body_xyz.shape == (8, 3) and a.robot.body_real_xyz.shape == (8, 3)
     a.close()
