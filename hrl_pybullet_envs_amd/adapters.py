@@ -86,9 +86,14 @@ class GymnasiumVectorEnv:
         return t.cpu().numpy() if self._numpy else t
 
     def reset(self, *, seed=None, options=None):
+        """options={'reset_mask': bool [N]} (gymnasium >= 1.0) resets the named envs only."""
         if seed is not None:
             self.env.seed(seed if isinstance(seed, int) else int(seed[0]))
-        return self._out(self.env.reset()), {}
+        mask = None if not options else options.get('reset_mask')
+        if mask is not None:
+            import torch
+            mask = torch.as_tensor(np.asarray(mask.cpu() if torch.is_tensor(mask) else mask, dtype=bool))
+        return self._out(self.env.reset(mask) if mask is not None else self.env.reset()), {}
 
     def step(self, actions):
         import torch

@@ -269,6 +269,9 @@ def test_vector_env_adapters_meet_their_contracts():
     o0, _ = vn.reset()
     o1, r1, te, tr_, inf = vn.step(np.zeros((n, 8), np.float32))
     assert isinstance(o1, np.ndarray) and o1.shape == (n, 46) and r1.dtype == np.float32 and te.dtype == bool and inf['_final_obs'].dtype == bool
+    rm = np.zeros(n, bool); rm[::3] = True     # gymnasium >= 1.0: options={'reset_mask': ...} resets the named envs only
+    o2, _ = vn.reset(options={'reset_mask': rm})
+    assert np.array_equal(o2[~rm], o1[~rm]) and not np.array_equal(o2[rm], o1[rm])
     vn.close(); v.close(); twin.close()
     with pytest.raises(ValueError):
         GymnasiumVectorEnv(H.AntGatherBulletEnv())
