@@ -147,11 +147,10 @@ class SB3VecEnv:
         self._pending = False
         obs, rew, done, info = self._out
         obs, rew, dones = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool)    # the first copy synchronises with the step
-        infos = [{} for _ in range(self.num_envs)]
-        if self._gather:
-            food, dead = info['food_rew'].cpu().numpy(), info['dead_rew'].cpu().numpy()
-            for i in range(self.num_envs):
-                infos[i]['food_rew'] = float(food[i]); infos[i]['dead_rew'] = float(dead[i])
+        if self._gather:   # (one list comprehension over .tolist(): per-element numpy indexing costs milliseconds per step at thousands of envs)
+            infos = [{'food_rew': f, 'dead_rew': d} for f, d in zip(info['food_rew'].cpu().tolist(), info['dead_rew'].cpu().tolist())]
+        else:
+            infos = [{} for _ in range(self.num_envs)]
         if dones.any():
             idx = np.nonzero(dones)[0]
             fin = info['final_observation'][done.bool()].cpu().numpy()
