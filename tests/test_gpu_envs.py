@@ -700,3 +700,18 @@ def test_four_host_threads_each_with_its_own_env_and_stream():
             o.step(acts[t])
         st, it, au, ob = out[i]
         assert np.array_equal(st, o.state, equal_nan=True) and np.array_equal(it, o.items) and np.array_equal(au, o.aux) and np.array_equal(ob, o.obs, equal_nan=True), kind
+
+
+def test_the_measuring_tools_of_the_readme_run():
+    """The light-weight tools of README's "Measuring" table run as documented (small arguments) and print what they say they print."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = [(['tools/soak.py', '30', '64'], 'final state finite True'), (['tools/readme_loop.py'], 'steps/s'), (['tools/host_overhead.py'], 'us per call'),
+            (['tools/solo_latency.py', '3', '1'], 'step_host'), (['tools/graph_rollout.py', '64'], 'one hipGraph'),
+            (['tests/tools/long_parity.py', '20', '64', '1'], 'bit-exact for 20 steps'), (['tests/tools/fuzz_parity.py', '1', 'gpu'], '0 with a difference'),
+            (['tests/tools/fuzz_configs.py', '2', 'gpu', '3', '10'], '0 with a difference')]
+    for cmd, expect in runs:
+        r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and expect in r.stdout, (cmd, r.returncode, r.stdout[-400:], r.stderr[-800:])
