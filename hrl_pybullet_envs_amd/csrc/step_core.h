@@ -20,7 +20,7 @@
  *   body map: lane >> 2 = rigid body (0-3 feet, 4-7 aux bodies, 8.. torso): phases K1, K2, B; the lanes of a group compute the same values
  *   leg map : leg = lane >> 4 (four 16-lane rows, one per leg)
  *   dof map : dof = lane & 15 (0-2 omega, 3-5 v, 6-13 joint rates, 14-15 zero padding)
- *   sphere map: lane = contact sphere x lateral surface (ballot-compacted into contacts)
+ *   shape map: lane = contact shape (torso sphere, 12 leg capsules / their end spheres) x surface (ballot-compacted into contacts)
  *   row map : lane = constraint row (limits, contact normals, friction pairs; <= 44 rows), its solver state in registers
  *   item map: lane = food/poison slot (<= 16);  bin map: lane = sensor bin
  *
@@ -645,8 +645,75 @@ HRL_DEV float sphere_vs_box(const float *p, float rad, const float *lo, const fl
     return -bd - rad;
 }
 
-/* Phase C helper: signed distance of contact sphere `sph` (0 torso, 1+3l hip, 2+3l ankle, 3+3l tip; -1 = idle lane)
- * to surface f: 0 ground, 1..n_planes lateral half-spaces, n_planes+1.. world boxes; item >= 0: the item cube `item` */
+/* Parameter t in [0, 1] of the point of the segment P(t) = p + t d closest to the axis-aligned box [lo, hi]; where a whole stretch of the
+ * segment is closest (it runs alongside a face, or through the box) the middle of that stretch.  g(t) = d . (P(t) - clamp(P(t), lo, hi)) is half
+ * the derivative of the squared distance: nondecreasing, piecewise linear, with corners where a coordinate of P crosses a face.  Candidates: 0, 1
+ * and the six crossing times clamped to [0, 1]; a = the largest candidate with g <= 0, b = the smallest with g >= 0; no candidate lies strictly
+ * between them, so g is linear there: b <= a is the stretch g = 0 (its middle is taken), else the root of the chord; g(0) > 0: t = 0,
+ * g(1) < 0: t = 1.  Written without branches (every lane of a collision pass holds another capsule); the operations and their order are the
+ * oracle's (orc_impl.h: seg_box_t). */
+HRL_DEV float seg_box_t(const float *p, const float *d, const float *lo, const float *hi) {
+    float T[8], a = -1.f, ga = 0.f, b = 2.f, gb = 0.f;
+    bool on[8]; /* candidate 2 + 2k / 3 + 2k IS the crossing of the low / high face of axis k (not clamped to an end of the segment) */
+    T[0] = 0.f; T[1] = 1.f; on[0] = on[1] = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float inv = d[k] != 0.f ? 1.f / d[k] : 0.f;
+        const float tl = (lo[k] - p[k]) * inv, th = (hi[k] - p[k]) * inv;
+        T[2 + 2 * k] = clampf(tl, 0.f, 1.f); T[3 + 2 * k] = clampf(th, 0.f, 1.f);
+        on[2 + 2 * k] = (d[k] != 0.f) & (T[2 + 2 * k] == tl); on[3 + 2 * k] = (d[k] != 0.f) & (T[3 + 2 * k] == th);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float e[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float x = fma_(d[k], T[i], p[k]);
+            e[k] = x - clampf(x, lo[k], hi[k]);
+            if (i >= 2 && k == (i - 2) / 2) e[k] = on[i] ? 0.f : e[k]; /* on the face by construction: exactly, not to rounding -- the stretch g = 0 is then found by comparisons with 0 */
+        }
+        const float g = dot3(d, e);
+        const bool ta = (g <= 0.f) & (T[i] > a), tb = (g >= 0.f) & (T[i] < b);
+        a = ta ? T[i] : a; ga = ta ? g : ga;
+        b = tb ? T[i] : b; gb = tb ? g : gb;
+    }
+    const float mid = 0.5f * (a + b), root = fma_(b - a, ga / (ga - gb), a);
+    float t = a < b ? root : mid;
+    t = b > 1.f ? 1.f : t;
+    t = a < 0.f ? 0.f : t;
+    return t;
+}
+
+/* Broad phase of a cube pass, per lane: can shape `sph` (0 torso sphere, else the capsule that ends in sphere sph) of pose q come within the
+ * contact distance of item cube `item` at all?  The capsule's bounding box, grown by radius + contact distance (+ 1 mm, so that the cull never
+ * decides a case the distance computation would see differently by rounding), against the cube's box, axis by axis.  No lane of a pass says yes:
+ * the pass finds nothing and is skipped -- the same contact list as running it.  A non-finite coordinate fails every comparison (such a
+ * capsule touches nothing: sphere_vs_box). */
+HRL_DEV bool shape_near_item(const DevCfg &c, const WaveLds &L, const float *q, int sph, int item) {
+    if (sph < 0 || sph >= 13 || item < 0) return false;
+    float r_torso = c.r_torso, r_caps = c.r_caps;
+    HRL_PIN_SCALAR(r_torso);
+    HRL_PIN_SCALAR(r_caps);
+    const int leg = sph > 0 ? (sph - 1) / 3 : 0, level = sph > 0 ? (sph - 1) % 3 : 0;
+    const float m = ((sph > 0 ? r_caps : r_torso) + c.cdist) + 1e-3f;
+    const float *e1 = level == 0 ? L.ph[leg] : (level == 1 ? L.pa[leg] : L.tip[leg]), *e0 = level == 1 ? L.ph[leg] : L.pa[leg];
+    const float ic[3] = {L.items[2 * item], L.items[2 * item + 1], ITEM_Z};
+    bool near = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float a = sph > 0 ? e1[k] : 0.f, b = level == 0 ? 0.f : e0[k];
+        const float pa = q[k] + a, pb = q[k] + b, mn = pa < pb ? pa : pb, mx = pa < pb ? pb : pa;
+        near = near & (mx + m >= ic[k] - ITEM_HALF) & (mn - m <= ic[k] + ITEM_HALF);
+    }
+    return near;
+}
+
+/* Phase C helper: signed distance of contact shape `sph` (-1 = idle lane) to surface f: 0 ground, 1..n_planes lateral half-spaces,
+ * n_planes+1.. world boxes; item >= 0: the item cube `item`.  Against the planes the shapes are the 13 spheres 0 torso, 1+3l hip point,
+ * 2+3l ankle point, 3+3l foot tip (the deepest point of a capsule against a plane is one of its ends); against the convex boxes -- the maze
+ * box, the food / poison cubes -- shape s > 0 is the whole CAPSULE that ends in sphere s (assets/ant.xml:16-55: O -> hip point, rigid with the
+ * torso; hip -> ankle point, the aux body; ankle point -> tip, the foot): the point of its axis closest to the box stands in for the sphere
+ * centre.  Shape and sphere share the owning body, so the lane map and the candidate order are the same in every pass. */
 HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q, int sph, int f, int item) {
     Hit h;
     float r_torso = c.r_torso, r_caps = c.r_caps, ctr[3] = {0.f, 0.f, 0.f};
@@ -664,15 +731,31 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
     }
     h.link = level | (leg << 2);
     float p[3] = {q[0] + ctr[0], q[1] + ctr[1], q[2] + ctr[2]};
-    if (item >= 0) {
-        const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
-        const float lo[3] = {ix - ITEM_HALF, iy - ITEM_HALF, ITEM_Z - ITEM_HALF}, hi[3] = {ix + ITEM_HALF, iy + ITEM_HALF, ITEM_Z + ITEM_HALF};
-        h.dist = sphere_vs_box(p, rad, lo, hi, h.n); h.surf = surf_item(item);
+    if (item >= 0 || f > c.n_planes) { /* a convex box: the capsule's axis point closest to it */
+        float lo[3], hi[3];
+        if (item >= 0) {
+            const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
+            lo[0] = ix - ITEM_HALF; lo[1] = iy - ITEM_HALF; lo[2] = ITEM_Z - ITEM_HALF; hi[0] = ix + ITEM_HALF; hi[1] = iy + ITEM_HALF; hi[2] = ITEM_Z + ITEM_HALF;
+            h.surf = surf_item(item);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = c.box_lo[k]; hi[k] = c.box_hi[k]; }
+            h.surf = SURF_BOX + (f - 1 - c.n_planes);
+        }
+        /* start of the axis relative to O: the O -> hip capsule starts at O, and so does the torso sphere (a segment of length zero) */
+        const float *s0 = level == 1 ? L.ph[leg] : L.pa[leg];
+        float c0[3], pw[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { c0[k] = level == 0 ? 0.f : s0[k]; pw[k] = q[k] + c0[k]; d[k] = ctr[k] - c0[k]; }
+        const float t = seg_box_t(pw, d, lo, hi);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ctr[k] = fma_(d[k], t, c0[k]); p[k] = q[k] + ctr[k]; }
+        h.dist = sphere_vs_box(p, rad, lo, hi, h.n);
     } else if (f == 0) h.dist = (p[2] - c.ground_z) - rad;
-    else if (f <= c.n_planes) {
+    else {
         h.n[0] = L.planes[f - 1][0]; h.n[1] = L.planes[f - 1][1]; h.n[2] = L.planes[f - 1][2];
         h.dist = (dot3(h.n, p) - L.planes[f - 1][3]) - rad; h.surf = f;
-    } else { h.dist = sphere_vs_box(p, rad, c.box_lo, c.box_hi, h.n); h.surf = SURF_BOX + (f - 1 - c.n_planes); }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) h.r[k] = fma_(-rad, h.n[k], ctr[k]);
     h.ok = h.dist < c.cdist;
@@ -1168,6 +1251,12 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
                 it[k] = -1;
                 if (near) { it[k] = (int)__builtin_ctzll(near); near &= near - 1; ++n_it; }
             }
+            const unsigned long long maybe = x.each_ballot([&](int lane) { /* see ant_contacts_group */
+                const int slot = lane / 13, sph = lane - 13 * slot;
+                const int item = slot == 0 ? it[0] : (slot == 1 ? it[1] : (slot == 2 ? it[2] : (slot == 3 ? it[3] : -1)));
+                return shape_near_item(c, L, q, sph, item);
+            });
+            if (!maybe) continue;
             int cnt = x.each_compact(
                 [&](int lane) {
                     const int slot = lane / 13, sph = lane - 13 * slot;
@@ -1316,6 +1405,13 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
         });
         while (near) {
             const unsigned long long cur = near;
+            /* can any capsule of any env reach its env's cube of this pass?  (mostly not: a cube within arm's length is usually a metre from the feet) */
+            const unsigned long long maybe = x.each_ballot([&](int lane) {
+                const WaveLds &L = x.lds(lane >> 4);
+                const unsigned sub = (unsigned)(cur >> (lane & 48)) & 0xffffu;
+                return shape_near_item(c, L, L.q[qi], (lane & 15) < 13 ? (lane & 15) : -1, sub ? ib + __builtin_ctz(sub) : -1);
+            });
+            if (maybe) {
             x.each_compact16(
                 [&](int lane) {
                     WaveLds &L = x.lds(lane >> 4);
@@ -1328,6 +1424,7 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
             x.each([&](int lane) {
                 if ((lane & 15) == 0) { WaveLds &L = x.lds(lane >> 4); const int n = L.nC + L.ncnt; L.nC = n > MAXC ? MAXC : n; }
             });
+            }
             unsigned long long low = 0; /* every env's lowest set bit is done */
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const unsigned sub = (unsigned)(near >> (16 * e)) & 0xffffu; low |= (unsigned long long)(sub & (0u - sub)) << (16 * e); }

@@ -966,6 +966,61 @@ static REAL FN(sphere_vs_box)(const REAL *p, REAL rad, const REAL *lo, const REA
     FN(v3set)(n, 0, 0, 0); n[best] = sgn;
     return -bd - rad;
 }
+/* The 12 leg capsules (assets/ant.xml:16-55: `fromto` capsules of radius 0.08) against the convex boxes of the world -- the maze box
+ * (assets/box.xml:12,19) and the food / poison cubes (assets/food.xml:12,19) -- are tested along their whole axis: shape `s` of the
+ * candidate list is the torso sphere (s = 0) or the capsule that ENDS in sphere s (1+3l: O -> hip point, rigid with the torso; 2+3l: hip
+ * point -> ankle point, the aux body; 3+3l: ankle point -> foot tip, the foot), so shapes and spheres share the owning body.  Against
+ * planes (ground, walls) the deepest point of a capsule is one of its end points, which is why those passes keep the end-point spheres.
+ * Start point of shape s relative to O (its end point is the sphere centre of sphere_info). */
+static void FN(capsule_start)(const FN(orc_dyn) * D, int s, REAL *c) {
+    const int l = (s - 1) / 3, w = (s - 1) % 3;
+    const REAL *src = (s == 0 || w == 0) ? 0 : (w == 1 ? D->ph[l] : D->pa[l]);
+    for (int k = 0; k < 3; ++k) c[k] = src ? src[k] : R_(0);
+}
+/* Parameter t in [0, 1] of the point of the segment P(t) = p + t d closest to the axis-aligned box [lo, hi]; where a whole stretch of
+ * the segment is closest (it runs alongside a face, or through the box) the middle of that stretch.  Exact up to rounding:
+ * g(t) = d . (P(t) - clamp(P(t), lo, hi)) is half the derivative of the squared distance -- nondecreasing, piecewise linear, with corners
+ * where a coordinate of P crosses a face of the box.  Candidates: 0, 1 and the six crossing times clamped to [0, 1]; a = the largest
+ * candidate with g <= 0, b = the smallest with g >= 0.  No candidate lies strictly between them, so g is linear there: b <= a is the stretch
+ * g = 0, else the root of the chord.  g(0) > 0: t = 0; g(1) < 0: t = 1.  A zero-length segment (the torso sphere) gives 0.5 (P = p for every t).
+ * Every operation is pinned; non-finite input ends in t = 0 (no candidate passes a comparison). */
+static REAL FN(seg_box_t)(const REAL *p, const REAL *d, const REAL *lo, const REAL *hi) {
+    REAL T[8], a = -1, ga = 0, b = 2, gb = 0;
+    int on[8]; /* candidate 2 + 2k / 3 + 2k IS the crossing of the low / high face of axis k (not clamped to an end of the segment) */
+    T[0] = 0; T[1] = 1; on[0] = on[1] = 0;
+    for (int k = 0; k < 3; ++k) {
+        const REAL inv = d[k] != 0 ? R_(1) / d[k] : R_(0);
+        const REAL tl = (lo[k] - p[k]) * inv, th = (hi[k] - p[k]) * inv;
+        T[2 + 2 * k] = FN(clampr)(tl, 0, 1); T[3 + 2 * k] = FN(clampr)(th, 0, 1);
+        on[2 + 2 * k] = d[k] != 0 && T[2 + 2 * k] == tl; on[3 + 2 * k] = d[k] != 0 && T[3 + 2 * k] == th;
+    }
+    for (int i = 0; i < 8; ++i) {
+        REAL e[3];
+        for (int k = 0; k < 3; ++k) {
+            const REAL x = FMA_(d[k], T[i], p[k]);
+            e[k] = x - FN(clampr)(x, lo[k], hi[k]);
+            if (i >= 2 && k == (i - 2) / 2 && on[i]) e[k] = 0; /* on the face by construction: exactly, not to rounding -- the stretch g = 0 is then found by comparisons with 0 */
+        }
+        const REAL g = FN(v3dot)(d, e);
+        if (g <= 0 && T[i] > a) { a = T[i]; ga = g; }
+        if (g >= 0 && T[i] < b) { b = T[i]; gb = g; }
+    }
+    if (a < 0) return 0;
+    if (b > 1) return 1;
+    if (!(a < b)) return R_(0.5) * (a + b);
+    return FMA_(b - a, ga / (ga - gb), a);
+}
+REAL FN(orc_seg_box_t)(const REAL *p, const REAL *d, const REAL *lo, const REAL *hi) { return FN(seg_box_t)(p, d, lo, hi); } /* tests */
+/* shape s of pose `pos` against the box: the point of its axis closest to the box stands in for the sphere centre of sphere_vs_box
+ * (an axis point inside the box leaves through the nearest face, as a sphere centre does).  c = that point relative to O. */
+static REAL FN(shape_vs_box)(const FN(orc_dyn) * D, const REAL *pos, int s, const REAL *c_end, REAL rad, const REAL *lo, const REAL *hi, REAL *c, REAL *n) {
+    REAL c0[3], pw[3], d[3], p[3];
+    FN(capsule_start)(D, s, c0);
+    for (int k = 0; k < 3; ++k) { pw[k] = pos[k] + c0[k]; d[k] = c_end[k] - c0[k]; }
+    const REAL t = FN(seg_box_t)(pw, d, lo, hi);
+    for (int k = 0; k < 3; ++k) { c[k] = FMA_(d[k], t, c0[k]); p[k] = pos[k] + c[k]; }
+    return FN(sphere_vs_box)(p, rad, lo, hi, n);
+}
 static void FN(item_box)(const REAL *item_xy, REAL *lo, REAL *hi) {
     lo[0] = item_xy[0] - ORC_ITEM_HALF; lo[1] = item_xy[1] - ORC_ITEM_HALF; lo[2] = ORC_ITEM_Z - ORC_ITEM_HALF;
     hi[0] = item_xy[0] + ORC_ITEM_HALF; hi[1] = item_xy[1] + ORC_ITEM_HALF; hi[2] = ORC_ITEM_Z + ORC_ITEM_HALF;
@@ -1010,13 +1065,13 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                 dist = (FN(v3dot)(n, p) - W->plane_d[f - 1]) - rad; surface = f;
             } else if (f <= W->n_planes + W->n_boxes) {
                 const int b = f - 1 - W->n_planes;
-                dist = FN(sphere_vs_box)(p, rad, W->box_lo[b], W->box_hi[b], n); surface = ORC_SURF_BOX + b;
+                dist = FN(shape_vs_box)(D, pos, s, c, rad, W->box_lo[b], W->box_hi[b], c, n); surface = ORC_SURF_BOX + b;
             } else {
                 const int k = f - 1 - W->n_planes - W->n_boxes;
                 REAL lo[3], hi[3];
                 if (items_xy[2 * k] != items_xy[2 * k] || items_xy[2 * k + 1] != items_xy[2 * k + 1]) continue; /* a cube at a NaN place is nowhere (a clamp between NaN bounds would put it everywhere) */
                 FN(item_box)(items_xy + 2 * k, lo, hi);
-                dist = FN(sphere_vs_box)(p, rad, lo, hi, n); surface = ORC_SURF_OF_ITEM(k);
+                dist = FN(shape_vs_box)(D, pos, s, c, rad, lo, hi, c, n); surface = ORC_SURF_OF_ITEM(k);
             }
             if (dist < K->cdist) {
                 if (f == 0) ground_touch[s] = 1;
@@ -1754,6 +1809,15 @@ void FN(orc_ant_energy_momentum)(const hrl_model *M, const REAL *q, const REAL *
         for (int k = 0; k < 3; ++k) L[k] += lw[k] + Iw[k];
     }
     out[0] = T; out[1] = V; for (int k = 0; k < 3; ++k) { out[2 + k] = P[k]; out[5 + k] = L[k]; }
+}
+/* hip point, ankle point and foot tip of every leg in world coordinates, [4][3][3] (tests) */
+void FN(orc_ant_leg_points)(const hrl_model *M, const REAL *q, REAL *out36) {
+    FN(orc_consts) K; FN(orc_dyn) D;
+    REAL u0[14] = {0};
+    FN(orc_consts_init)(M, &K);
+    FN(orc_dynamics)(&K, q, u0, 0, &D);
+    for (int l = 0; l < 4; ++l)
+        for (int k = 0; k < 3; ++k) { out36[9 * l + k] = q[k] + D.ph[l][k]; out36[9 * l + 3 + k] = q[k] + D.pa[l][k]; out36[9 * l + 6 + k] = q[k] + D.tip[l][k]; }
 }
 /* accelerations [a0(6) | qdd(8)] for tests */
 void FN(orc_ant_accel)(const hrl_model *M, const REAL *q, const REAL *u, const REAL *tau, REAL *out14) {

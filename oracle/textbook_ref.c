@@ -31,8 +31,13 @@
  * Conventions shared with the specification (they define WHAT is simulated, not how):
  *   q[15] = x,y,z, qx,qy,qz,qw, hip_1,ankle_1,...,hip_4,ankle_4      (MjAnt.py:19-20 order)
  *   u[14] = omega (world), v (world, torso COM), joint rates
- *   13 contact spheres (torso r .25; hip point, ankle point, foot tip of each leg r .08); candidate contacts in the
- *   order ground, lateral planes, boxes, self pairs; at most 12 kept; rows = limits, normals, friction pairs.
+ *   13 contact shapes: the torso sphere r .25 and the 12 leg capsules r .08 of assets/ant.xml:16-55 -- against planes through their end
+ *   spheres (hip point, ankle point, foot tip: the deepest point of a capsule against a plane is an end), against the convex boxes (maze box,
+ *   item cubes) through the point of their axis closest to the box; candidate contacts in the order ground, lateral planes, boxes, self
+ *   pairs; at most 12 kept; rows = limits, normals, friction pairs.
+ *
+ * Frozen = never touched by a performance change.  It changes with the MODEL only; so far once: round 5 replaced the end-point spheres
+ * against boxes by the capsules of the asset (a cube fits between the ankle and tip spheres of a foot capsule).
  */
 #include <math.h>
 #include <stdint.h>
@@ -330,6 +335,30 @@ static double tb_sphere_box(const double *p, double rad, const double *lo, const
     return -bd - rad;
 }
 
+/* Point of the segment p0 -> p1 closest to an axis-aligned box, by bisection: the squared distance D(t) of P(t) = p0 + t (p1 - p0) to the box
+ * is convex in t, so its one-sided slope changes sign once.  The set of minimisers is the interval [t_first, t_last] with t_first = the first t
+ * whose slope is >= 0 and t_last = the last t whose slope is <= 0 (one point, unless the segment runs alongside a face or through the box);
+ * its middle is returned -- the convention of the model for a capsule lying flat on a box. */
+static double tb_box_slope(const double *p0, const double *dd, double t, const double *lo, const double *hi) {
+    double g = 0;
+    for (int k = 0; k < 3; ++k) {
+        double x = p0[k] + t * dd[k], cp = x < lo[k] ? lo[k] : (x > hi[k] ? hi[k] : x);
+        g += dd[k] * (x - cp);
+    }
+    return g;
+}
+double tb_seg_box_param(const double *p0, const double *p1, const double *lo, const double *hi) {
+    double dd[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    double first, last;
+    if (tb_box_slope(p0, dd, 0.0, lo, hi) >= 0) first = 0.0;
+    else if (tb_box_slope(p0, dd, 1.0, lo, hi) < 0) first = 1.0;
+    else { double a = 0, b = 1; for (int it = 0; it < 200; ++it) { double m = 0.5 * (a + b); if (tb_box_slope(p0, dd, m, lo, hi) >= 0) b = m; else a = m; } first = b; }
+    if (tb_box_slope(p0, dd, 1.0, lo, hi) <= 0) last = 1.0;
+    else if (tb_box_slope(p0, dd, 0.0, lo, hi) > 0) last = 0.0;
+    else { double a = 0, b = 1; for (int it = 0; it < 200; ++it) { double m = 0.5 * (a + b); if (tb_box_slope(p0, dd, m, lo, hi) <= 0) a = m; else b = m; } last = a; }
+    return 0.5 * (first + last);
+}
+
 /* closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9), both of positive length */
 static void tb_seg_seg(const double *p1, const double *q1, const double *p2, const double *q2, double *c1, double *c2) {
     double d1[3], d2[3], r[3];
@@ -415,29 +444,37 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
     /* ---- contact candidates in order: ground, lateral planes, boxes, self pairs; first TB_MAXC kept */
     tb_contact C[TB_MAXC];
     int nc = 0, ncand = 0;
-    double sc[13][3], srad[13]; int sbody[13];
-    v3_set(sc[0], 0, 0, 0); srad[0] = R_TORSO; sbody[0] = 0;
+    double sc[13][3], s0[13][3], srad[13]; int sbody[13]; /* shape s: the torso sphere, or the capsule s0 -> sc of ant.xml:16-55 (three per leg) */
+    v3_set(sc[0], 0, 0, 0); v3_set(s0[0], 0, 0, 0); srad[0] = R_TORSO; sbody[0] = 0;
     for (int l = 0; l < 4; ++l)
         for (int w = 0; w < 3; ++w) {
             const double *src = w == 0 ? K.ph[l] : (w == 1 ? K.pa[l] : K.tip[l]);
+            const double zero[3] = {0, 0, 0}, *from = w == 0 ? zero : (w == 1 ? K.ph[l] : K.pa[l]);
             int s = 1 + 3 * l + w;
-            for (int k = 0; k < 3; ++k) sc[s][k] = src[k];
+            for (int k = 0; k < 3; ++k) { sc[s][k] = src[k]; s0[s][k] = from[k]; }
             srad[s] = R_CAPS; sbody[s] = w == 0 ? 0 : (w == 1 ? 1 + 2 * l : 2 + 2 * l);
         }
     const int nsurf = 1 + P->n_planes + P->n_boxes;
     for (int f = 0; f < nsurf; ++f)
         for (int s = 0; s < 13; ++s) {
-            double p[3] = {q[0] + sc[s][0], q[1] + sc[s][1], q[2] + sc[s][2]}, n[3], dist;
+            double ctr[3] = {sc[s][0], sc[s][1], sc[s][2]}; /* centre of the sphere that touches, relative to O */
+            double p[3] = {q[0] + ctr[0], q[1] + ctr[1], q[2] + ctr[2]}, n[3], dist;
             if (f == 0) { v3_set(n, 0, 0, 1); dist = p[2] - P->ground_z - srad[s]; }
             else if (f <= P->n_planes) { for (int k = 0; k < 3; ++k) n[k] = P->plane_n[f - 1][k]; dist = v3_dot(n, p) - P->plane_d[f - 1] - srad[s]; }
-            else dist = tb_sphere_box(p, srad[s], P->box_lo[f - 1 - P->n_planes], P->box_hi[f - 1 - P->n_planes], n);
+            else { /* a convex box: the whole capsule, through the point of its axis closest to the box (against a plane that point is an end) */
+                const double *blo = P->box_lo[f - 1 - P->n_planes], *bhi = P->box_hi[f - 1 - P->n_planes];
+                double w0[3] = {q[0] + s0[s][0], q[1] + s0[s][1], q[2] + s0[s][2]};
+                double t = tb_seg_box_param(w0, p, blo, bhi);
+                for (int k = 0; k < 3; ++k) { ctr[k] = s0[s][k] + t * (sc[s][k] - s0[s][k]); p[k] = q[k] + ctr[k]; }
+                dist = tb_sphere_box(p, srad[s], blo, bhi, n);
+            }
             if (!(dist < P->cdist)) continue;
             ++ncand;
             if (nc >= TB_MAXC) continue;
             tb_contact *c = &C[nc++];
             c->bodyA = sbody[s]; c->bodyB = -1; c->dist = dist; c->mu = P->mu;
             c->surface = f <= P->n_planes ? f : 100 + (f - 1 - P->n_planes);
-            for (int k = 0; k < 3; ++k) { c->n[k] = n[k]; c->p[k] = sc[s][k] - srad[s] * n[k]; }
+            for (int k = 0; k < 3; ++k) { c->n[k] = n[k]; c->p[k] = ctr[k] - srad[s] * n[k]; }
         }
     if (P->self_collision) { /* capsules of different legs (links that are not ancestors of each other) */
         int pair = 0;

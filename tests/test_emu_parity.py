@@ -773,3 +773,49 @@ def test_random_legal_configs():
             assert r is None, r
             ended += e
     assert ended > 1000
+
+
+def _item_boxes(o, i):
+    ni = o.cfg.n_food + o.cfg.n_poison
+    it = o.items[i, :2 * ni].reshape(ni, 2).astype(np.float64)
+    return {(16 + k if k < 48 else 64 + k): (np.r_[it[k] - 0.125, -0.025], np.r_[it[k] + 0.125, 0.225]) for k in range(ni)}
+
+
+@pytest.mark.parametrize('group', [0, 1])
+def test_capsule_mid_sections_against_cubes_and_the_maze_box(group):
+    """assets/ant.xml:16-55 capsules against assets/food.xml:12 cubes and the assets/box.xml:12 maze box: ants let down onto cubes with the
+    MIDDLE of their feet (contact pickup, ant_gather_env.py:113-116: the touch is paid) and feet laid across the vertical edges of the maze
+    box -- contacts no end-point sphere sees; wave phases == oracle bit for bit, both launch shapes."""
+    import capsule_cases as cc
+    n = 32
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=4, auto_reset=1, robot_coll_dist=0.0, model_step_group=group)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    rng = np.random.RandomState(8)
+    paid = mid = 0
+    for t in range(6):
+        cc.cubes_under_the_feet(o, rng)
+        mid += cc.count_mid_section_contacts(o, range(0, n, 4), lambda i: _item_boxes(o, i))
+        e.state[...] = o.state; e.items[...] = o.items; e.aux[...] = o.aux
+        for k in range(2):
+            a = (rng.uniform(-1, 1, (n, 8)) * (0.0 if k == 0 else 0.3)).astype(np.float32)
+            o.step(a); e.step(a)
+            for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info'):
+                assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, k, name)
+            paid += int((o.info[:, 0] != 0).sum())
+    assert mid >= 20 and paid >= 60, (mid, paid)
+    cfg = orc.default_config(K.HRL_ANT_MAZE, num_envs=n, seed=4, auto_reset=1, model_step_group=group)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    box = {8: (np.array([-5., -2, 0]), np.array([1., 2, 2]))}
+    mid = 0
+    for t in range(6):
+        cc.foot_across_the_maze_corner(o, rng)
+        mid += cc.count_mid_section_contacts(o, range(0, n, 2), lambda i: box)
+        e.state[...] = o.state; e.aux[...] = o.aux
+        for k in range(2):
+            a = (rng.uniform(-1, 1, (n, 8)) * 0.3).astype(np.float32)
+            o.step(a); e.step(a)
+            for name in ('state', 'aux', 'obs', 'rew', 'done', 'info'):
+                assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, k, name)
+    assert mid >= 25, mid

@@ -484,6 +484,49 @@ def test_contact_pickup_on_item_cubes(kind, use_sensor):
     assert use_sensor or moved > 40, moved
 
 
+def test_capsule_mid_sections_against_cubes_and_the_maze_box_on_device():
+    """assets/ant.xml:16-55 capsules against assets/food.xml:12 cubes and the assets/box.xml:12 maze box: ants let down onto cubes with the
+    MIDDLE of their feet (contact pickup, ant_gather_env.py:113-116: the touch is paid) and feet laid across the vertical edges of the maze
+    box -- contacts no end-point sphere sees.  Device == oracle bit for bit, identical inputs every round."""
+    import capsule_cases as cc
+    n = 256
+    g, o = make(K.HRL_ANT_GATHER, n, seed=4, robot_coll_dist=0.0)
+    g.reset(); o.reset()
+    rng = np.random.RandomState(8)
+    paid = mid = 0
+
+    def item_boxes(i):
+        it = o.items[i, :32].reshape(16, 2).astype(np.float64)
+        return {16 + k: (np.r_[it[k] - 0.125, -0.025], np.r_[it[k] + 0.125, 0.225]) for k in range(16)}
+    for t in range(4):
+        cc.cubes_under_the_feet(o, rng)
+        mid += cc.count_mid_section_contacts(o, range(0, n, 16), item_boxes)
+        push(g, o)
+        for k in range(3):
+            a = (rng.uniform(-1, 1, (n, 8)) * (0.0 if k == 0 else 0.3)).astype(np.float32)
+            go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+            assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(g.items.cpu().numpy(), o.items), (t, k)
+            assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(g.info.cpu().numpy(), o.info) and np.array_equal(gd.cpu().numpy(), o.done), (t, k)
+            assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0
+            paid += int((o.info[:, 0] != 0).sum())
+    assert mid >= 30 and paid >= 400, (mid, paid)
+    g, o = make(K.HRL_ANT_MAZE, n, seed=4)
+    g.reset(); o.reset()
+    box = {8: (np.array([-5., -2, 0]), np.array([1., 2, 2]))}
+    mid = 0
+    for t in range(4):
+        cc.foot_across_the_maze_corner(o, rng)
+        mid += cc.count_mid_section_contacts(o, range(0, n, 8), lambda i: box)
+        push(g, o)
+        for k in range(3):
+            a = (rng.uniform(-1, 1, (n, 8)) * 0.3).astype(np.float32)
+            go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+            assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True), (t, k)
+            assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done), (t, k)
+            assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0
+    assert mid >= 30, mid
+
+
 def test_self_collision_rows_on_device():
     """Hips forced beyond their range so that capsules of different legs meet: the two-body rows (second impulse response,
     10-term row products) on the device equal the oracle's bit for bit."""

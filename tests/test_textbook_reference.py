@@ -304,3 +304,173 @@ def test_pointbot_spec_equals_textbook_over_states_and_parameters():
         worst = max(worst, err); contacts.append(out.n_contacts)
     assert np.mean(contacts) > 1.5 and max(contacts) >= 6
     print(f'point bot, random states and parameters: worst |diff| {worst:.2e}, contacts mean {np.mean(contacts):.1f} max {max(contacts)}')
+
+
+# ----------------------------------------------------------------------------------------------- capsules against boxes
+# assets/ant.xml:16-55 defines every leg segment as a CAPSULE; against the convex boxes of the world (assets/box.xml:12,19, the 6 x 4 x 2 maze
+# box; assets/food.xml:12,19, the 0.25 m item cubes) the model tests the whole capsule through the point of its axis closest to the box.
+def leg_points(model, q):
+    out = np.zeros(36)
+    orc.lib().orc_ant_leg_points_f64(C.byref(model), orc.ptr(np.ascontiguousarray(q, np.float64)), orc.ptr(out))
+    return out.reshape(4, 3, 3)  # [leg][hip point, ankle point, tip][xyz]
+
+
+def seg_box_dist(p0, p1, lo, hi, n=4001):
+    ts = np.linspace(0, 1, n)[:, None]
+    P = p0 + ts * (p1 - p0)
+    return np.sqrt(((P - np.clip(P, lo, hi)) ** 2).sum(1)).min()
+
+
+def test_segment_box_parameter_is_the_closest_point():
+    """The corner-enumeration of the specification (orc_impl.h: seg_box_t) against the bisection of the textbook reference and a dense sampling:
+    same parameter to 1e-12, never farther from the box than the best sample; where a stretch of the segment is closest (parallel to a face,
+    through the box) both return its middle."""
+    L, T = orc.lib(), tb.lib()
+    L.orc_seg_box_t_f64.restype = C.c_double; L.orc_seg_box_t_f32.restype = C.c_float; T.tb_seg_box_param.restype = C.c_double
+    rng = np.random.RandomState(5)
+    worst = 0.0
+    for i in range(20000):
+        lo = rng.uniform(-1, 0, 3); hi = lo + rng.uniform(0.1, 2, 3)
+        p, q = rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3)
+        for m in (3, 5, 7):  # axis-parallel segments: whole stretches are closest
+            if i % m == 0:
+                k = rng.randint(3); q[k] = p[k]
+        if i % 11 == 0:
+            q = p.copy()  # a sphere
+        d = q - p
+        t1 = L.orc_seg_box_t_f64(orc.ptr(p), orc.ptr(d), orc.ptr(lo), orc.ptr(hi))
+        t2 = T.tb_seg_box_param(orc.ptr(p), orc.ptr(q), orc.ptr(lo), orc.ptr(hi))
+        assert 0.0 <= t1 <= 1.0 and abs(t1 - t2) < 1e-12, (i, t1, t2)
+        worst = max(worst, abs(t1 - t2))
+        if i % 20 == 0:
+            x = p + t1 * d
+            assert np.sqrt(((x - np.clip(x, lo, hi)) ** 2).sum()) <= seg_box_dist(p, q, lo, hi) + 1e-12
+        p32, d32, lo32, hi32 = (np.asarray(a, np.float32) for a in (p, d, lo, hi))
+        t3 = L.orc_seg_box_t_f32(orc.ptr(p32), orc.ptr(d32), orc.ptr(lo32), orc.ptr(hi32))
+        x3 = p32.astype(np.float64) + float(t3) * d32.astype(np.float64)
+        q32 = p32.astype(np.float64) + d32.astype(np.float64)
+        assert np.sqrt(((x3 - np.clip(x3, lo32, hi32)) ** 2).sum()) <= seg_box_dist(p32.astype(np.float64), q32, lo32.astype(np.float64), hi32.astype(np.float64), 401) + 2e-6
+    # a segment through the box: the middle of the part inside; alongside a face: the middle of the part over the face
+    lo, hi = np.array([0., 0, 0]), np.array([1., 1, 1])
+    for p, q, want in [((-1., .5, .5), (3., .5, .5), 0.375), ((-1., .5, 1.5), (3., .5, 1.5), 0.375), ((.2, .3, 2.), (.2, .3, 2.), 0.5)]:
+        p, q = np.array(p), np.array(q)
+        assert L.orc_seg_box_t_f64(orc.ptr(p), orc.ptr(q - p), orc.ptr(lo), orc.ptr(hi)) == pytest.approx(want, abs=1e-15)
+        assert T.tb_seg_box_param(orc.ptr(p), orc.ptr(q), orc.ptr(lo), orc.ptr(hi)) == pytest.approx(want, abs=1e-12)
+    print(f'seg_box_t vs bisection: worst |dt| {worst:.1e}')
+
+
+def orc_substeps_items(cfg, q, u, tau, items, n=1, dtype=np.float64):
+    q2, u2, info, dbg, lam = np.array(q, dtype), np.array(u, dtype), np.zeros(3, np.int32), np.zeros(1 + tb.MAXC, np.int32), np.zeros(tb.MAXR, dtype)
+    it = np.ascontiguousarray(items, dtype).reshape(-1)
+    orc.fn('orc_ant_substeps_items', dtype)(C.byref(cfg), orc.ptr(q2), orc.ptr(u2), orc.ptr(np.ascontiguousarray(tau, dtype)), n, orc.ptr(it), len(it) // 2,
+                                            orc.ptr(info), orc.ptr(dbg), orc.ptr(lam))
+    return q2, u2, info, dbg, lam
+
+
+def test_capsules_against_item_cubes_equal_textbook():
+    """Random states with the 16 cubes scattered under and around the legs: the optimised specification (corner enumeration, fma chains) and
+    the textbook reference (bisection, dense Jacobians) agree to 1e-9 per substep and in every count; a good part of the cube contacts are
+    ones NO end-point sphere would have found (both ends of the capsule farther than radius + contact distance from the cube)."""
+    cfg = orc.default_config(K.HRL_ANT_GATHER)
+    rng = np.random.RandomState(21)
+    worst, with_cube, mid_only = 0.0, 0, 0
+    for i in range(600):
+        q, u, tau = rand_state(rng, xy=(-5, 5, -5, 5), z=(0.2, 0.6), tilt=0.5)
+        items = q[:2] + rng.uniform(-1.2, 1.2, (16, 2))
+        p = tb.params(cfg, items=items)
+        q1, u1, out = tb.ant_substep(p, q, u, tau)
+        q2, u2, info, dbg, _ = orc_substeps_items(cfg, q, u, tau, items)
+        assert (info[0], info[1], info[2]) == (out.n_rows, out.n_limits, out.n_contacts) and dbg[0] == out.n_candidates, (i, info, out.n_rows)
+        surf_tb = [out.contact_surface[c] for c in range(out.n_contacts)]
+        surf_orc = [int(s) for s in dbg[1:1 + info[2]]]
+        assert [s - 100 if s >= 100 and s < 200 else None for s in surf_tb if 100 <= s < 200] == [s - 16 for s in surf_orc if 16 <= s < 64], (i, surf_tb, surf_orc)
+        err = max(np.abs(q1 - q2).max(), np.abs(u1 - u2).max())
+        assert err <= TOL, (i, err, out.n_rows)
+        worst = max(worst, err)
+        cubes = sorted({s - 16 for s in surf_orc if 16 <= s < 64})
+        with_cube += bool(cubes)
+        pts = leg_points(cfg.model, q)
+        for k in cubes:  # is it a contact the end-point spheres would have missed?
+            lo = np.r_[items[k] - 0.125, -0.025]; hi = np.r_[items[k] + 0.125, 0.225]
+            ends = np.vstack([q[:3][None], pts.reshape(12, 3)])
+            rad = np.r_[0.25, np.full(12, 0.08)]
+            if np.all(np.sqrt(((ends - np.clip(ends, lo, hi)) ** 2).sum(1)) - rad >= cfg.model.contact_dist):
+                mid_only += 1
+    assert with_cube > 150 and mid_only > 30, (with_cube, mid_only)
+    print(f'capsule-cube: worst |diff| {worst:.2e}; states with a cube contact {with_cube}, cube contacts no end-point sphere sees {mid_only}')
+
+
+def test_ant_stands_on_four_cubes_under_the_middle_of_its_feet():
+    """A cube (0.25 m) fits between the ankle and tip spheres of a 0.57 m foot capsule (assets/ant.xml:22 vs assets/food.xml:12).  Four cubes
+    under the mid-sections of the four feet, ankles at their stops (30 deg), the ant let go 2 mm above touching: it stands on them -- every
+    contact a cube's, no end sphere within 5 cm of anything, the tips 13 cm above the ground.  With end-point spheres alone the feet fall
+    through the cubes until the tips reach the ground (the last assertion: the same ant without the cubes)."""
+    cfg = orc.default_config(K.HRL_ANT_GATHER)
+    q = np.zeros(15); q[6] = 1.0
+    q[7:] = np.radians([0, 30, 0, -30, 0, -30, 0, 30])
+    q[2] = 1.0
+    pts = leg_points(cfg.model, q)
+    cen = pts[:, 1, :2] + 0.35 * (pts[:, 2, :2] - pts[:, 1, :2])  # under the foot axis, 35 % of the way from the ankle to the tip
+    items = np.vstack([cen, np.full((12, 2), 50.0)])
+    boxes = [(np.r_[c - 0.125, -0.025], np.r_[c + 0.125, 0.225]) for c in cen]
+
+    def gap(z):
+        q[2] = z
+        pts = leg_points(cfg.model, q)
+        return min(seg_box_dist(pts[l, 1], pts[l, 2], *boxes[l], 8001) for l in range(4)) - 0.08
+    a, b = 0.3, 1.0
+    for _ in range(40):  # the height at which the foot capsules are 2 mm above the cubes
+        m = 0.5 * (a + b)
+        a, b = (a, m) if gap(m) > 0.002 else (m, b)
+    q[2] = b
+    pts = leg_points(cfg.model, q)
+    ends = np.vstack([q[:3][None], pts.reshape(12, 3)])
+    rad = np.r_[0.25, np.full(12, 0.08)]
+    for lo, hi in boxes:
+        assert np.all(np.sqrt(((ends - np.clip(ends, lo, hi)) ** 2).sum(1)) - rad > 0.05)  # no end-point sphere is near a cube (contact distance: 0.02)
+    assert np.all(pts[:, 2, 2] - 0.08 > 0.13)  # nor near the ground
+    qq, uu, info, dbg, lam = orc_substeps_items(cfg, q, np.zeros(14), np.zeros(8), items, 100)
+    assert sorted(int(s) for s in dbg[1:1 + info[2]]) == [16, 17, 18, 19]  # one contact per (foot capsule, cube), nothing else
+    assert abs(qq[2] - q[2]) < 0.01 and np.abs(uu).max() < 0.02, (qq[2] - q[2], np.abs(uu).max())
+    assert np.all(lam[info[1]:info[1] + 4] > 0.5)  # all four carry load (m g h = 7.4 N s between them, friction included)
+    # the same in fp32, and in the textbook reference
+    q32, u32, info32, dbg32, _ = orc_substeps_items(cfg, q, np.zeros(14), np.zeros(8), items, 100, np.float32)
+    assert abs(q32[2] - q[2]) < 0.01 and sorted(int(s) for s in dbg32[1:1 + info32[2]]) == [16, 17, 18, 19]
+    p = tb.params(cfg, items=items[:4])
+    qt, ut = q.copy(), np.zeros(14)
+    for s in range(100):
+        qt, ut, out = tb.ant_substep(p, qt, ut, np.zeros(8))
+    assert np.abs(qt - qq).max() < 1e-6 and sorted(out.contact_surface[c] for c in range(out.n_contacts)) == [100, 101, 102, 103]
+    # without the cubes the same ant comes down until its tips reach the ground
+    qf, uf, infof, dbgf, _ = orc_substeps_items(cfg, q, np.zeros(14), np.zeros(8), np.full((16, 2), 50.0), 100)
+    assert qf[2] < q[2] - 0.1
+
+
+def test_foot_across_the_corner_of_the_maze_box_is_pushed_out():
+    """The vertical edge of the 6 x 4 x 2 maze box at (1, -2) (assets/box.xml:12, maze_scene.py:12-13): a foot capsule lying across it, both of
+    its end spheres 9 cm and more clear of the box.  The capsule is in contact (5 cm deep), the normal points away from the edge, and within a
+    few substeps the foot is out."""
+    cfg = orc.default_config(K.HRL_ANT_MAZE)
+    q = np.zeros(15); q[6] = 1.0
+    q[7:] = np.radians([0, 30, 0, -100, 0, -30, 0, 30])  # leg 1 (towards the box's south face) folded under the body
+    mid_off = (0.4 + 0.2 * np.cos(np.radians(30))) * np.array([1.0, 1.0])  # foot midpoint of leg 0 relative to the torso, level torso
+    out_dir = np.array([1.0, -1.0]) / np.sqrt(2)
+    q[:2] = np.array([1.0, -2.0]) + 0.03 * out_dir - mid_off  # its axis passes 3 cm outside the edge
+    q[2] = 0.75
+    pts = leg_points(cfg.model, q)
+    lo, hi = np.array([-5., -2, 0]), np.array([1., 2, 2])
+    ends = np.vstack([q[:3][None], pts.reshape(12, 3)])
+    clear = np.sqrt(((ends - np.clip(ends, lo, hi)) ** 2).sum(1)) - np.r_[0.25, np.full(12, 0.08)]
+    assert clear.min() > 0.09  # no end-point sphere is anywhere near
+    assert seg_box_dist(pts[0, 1], pts[0, 2], lo, hi) == pytest.approx(0.03, abs=1e-3)
+    q1, u1, info, dbg, lam = orc_substeps_items(cfg, q, np.zeros(14), np.zeros(8), np.zeros((0, 2)), 1)
+    assert info[2] == 1 and dbg[1] == 8 and lam[info[1]] > 0  # one contact, with the box, pushing
+    p = tb.params(cfg)
+    qt, ut, out = tb.ant_substep(p, q, np.zeros(14), np.zeros(8))
+    assert out.n_contacts == 1 and out.contact_surface[0] == 100 and out.contact_dist[0] == pytest.approx(0.03 - 0.08, abs=1e-3)
+    assert max(np.abs(qt - q1).max(), np.abs(ut - u1).max()) < TOL
+    qq, uu = q.copy(), np.zeros(14)
+    for s in range(12):
+        qq, uu, info, dbg, lam = orc_substeps_items(cfg, qq, uu, np.zeros(8), np.zeros((0, 2)), 1)
+    pts = leg_points(cfg.model, qq)
+    assert seg_box_dist(pts[0, 1], pts[0, 2], lo, hi) > 0.075  # out, to within the solver's slop
