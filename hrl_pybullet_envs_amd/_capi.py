@@ -1,7 +1,7 @@
 """ctypes mirror of include/hrl_envs.h (structs + constants only; no library loading here)."""
 import ctypes as C
 
-HRL_ABI_VERSION = 6
+HRL_ABI_VERSION = 7
 HRL_ANT_FLAT, HRL_ANT_GATHER, HRL_ANT_MAZE, HRL_POINT_GATHER, HRL_ANT_MAZE_MJ, HRL_ANT_FLAGRUN = 0, 1, 2, 3, 4, 5
 HRL_STATE_STRIDE = 32
 HRL_QPOS_OFF, HRL_QVEL_OFF, HRL_EPRET_OFF, HRL_INITZ_OFF, HRL_POTENTIAL_OFF = 0, 15, 29, 30, 31
@@ -12,7 +12,9 @@ HRL_MAX_OBS = 256
 HRL_AUX_STRIDE = 4
 HRL_INFO_STRIDE = 4
 HRL_MAX_TARGETS = 64
-HRL_MAX_GOALS = 63
+HRL_MAX_GOALS = 61
+HRL_FLAG_GOAL_OFF, HRL_FLAG_START_OFF, HRL_FLAG_SQDIST_OFF, HRL_FLAG_PENDING_OFF = 0, 2, 4, 6  # flagrun items record
+HRL_GOAL_STRIDE = 4
 HRL_OK, HRL_ERR_BAD_ARG, HRL_ERR_HIP, HRL_ERR_NO_DEVICE = 0, 1, 2, 3
 
 
@@ -22,7 +24,9 @@ class hrl_model(C.Structure):
                 ('contact_erp', C.c_float), ('limit_erp', C.c_float), ('friction_ground', C.c_float),
                 ('friction_robot', C.c_float), ('contact_dist', C.c_float), ('limit_margin', C.c_float),
                 ('max_joint_vel', C.c_float), ('limit_max_impulse', C.c_float), ('ground_z', C.c_float),
-                ('point_force', C.c_float), ('self_collision', C.c_int32), ('item_collision', C.c_int32), ('step_group', C.c_int32)]
+                ('point_force', C.c_float), ('self_collision', C.c_int32), ('item_collision', C.c_int32), ('step_group', C.c_int32),
+                ('linear_damping', C.c_float), ('angular_damping', C.c_float), ('restitution', C.c_float), ('restitution_threshold', C.c_float),
+                ('max_contacts', C.c_int32)]
 
 
 class hrl_config(C.Structure):
@@ -45,6 +49,7 @@ class hrl_config(C.Structure):
                 ('flag_size', C.c_float), ('flag_max_targets', C.c_int32), ('flag_timeout', C.c_int32),
                 ('flag_switch_on_collision', C.c_int32), ('flag_enclosed', C.c_int32), ('flag_max_target_dist', C.c_float),
                 ('flag_manual_goals', C.c_int32), ('flag_goal_capacity', C.c_int32),
+                ('flag_ant_env_rew_weight', C.c_float), ('flag_path_rew_weight', C.c_float), ('flag_dist_rew_weight', C.c_float), ('flag_goal_reach_rew', C.c_float),
                 ('model', hrl_model)]
 
     def copy(self):
@@ -54,6 +59,20 @@ class hrl_config(C.Structure):
 
 
 class hrl_buffers(C.Structure):
-    _fields_ = [('state', C.c_void_p), ('items', C.c_void_p), ('aux', C.c_void_p), ('actions', C.c_void_p),
+    """Build it with keywords (`hrl_buffers(state=..., obs=...)`) or through `make_buffers`: struct_size is filled in either way."""
+    _fields_ = [('struct_size', C.c_uint64),
+                ('state', C.c_void_p), ('items', C.c_void_p), ('aux', C.c_void_p), ('actions', C.c_void_p),
                 ('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('info', C.c_void_p),
-                ('final_obs', C.c_void_p), ('truncated', C.c_void_p)]
+                ('final_obs', C.c_void_p), ('truncated', C.c_void_p), ('goal', C.c_void_p), ('solver_rows', C.c_void_p)]
+
+    def __init__(self, *args, **kw):
+        if args:
+            raise TypeError('hrl_buffers takes keywords only (its first field is struct_size)')
+        super().__init__(**kw)
+        self.struct_size = C.sizeof(hrl_buffers)
+
+
+def make_buffers(state, items, aux, actions, obs, reward, done, info, final_obs=None, truncated=None, goal=None, solver_rows=None):
+    """An initialised buffer record from addresses (ints / c_void_p / None), in the order of include/hrl_envs.h."""
+    return hrl_buffers(state=state, items=items, aux=aux, actions=actions, obs=obs, reward=reward, done=done, info=info,
+                       final_obs=final_obs, truncated=truncated, goal=goal, solver_rows=solver_rows)

@@ -11,7 +11,7 @@ _lib = None
 
 # every symbol include/hrl_envs.h declares
 SYMBOLS = ['hrl_default_config', 'hrl_obs_dim', 'hrl_act_dim', 'hrl_items_stride', 'hrl_create', 'hrl_destroy', 'hrl_reset', 'hrl_step',
-           'hrl_get_state', 'hrl_set_state', 'hrl_set_goals', 'hrl_next_target', 'hrl_last_error', 'hrl_backend']
+           'hrl_get_state', 'hrl_set_state', 'hrl_set_goals', 'hrl_next_target', 'hrl_last_error', 'hrl_backend', 'hrl_buffers_init', 'hrl_observe']
 
 
 class HrlError(RuntimeError):
@@ -33,6 +33,8 @@ def lib():
         L.hrl_destroy.argtypes = [C.c_void_p]
         L.hrl_reset.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p]
         L.hrl_step.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p]
+        L.hrl_observe.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p]
+        L.hrl_buffers_init.argtypes = [C.POINTER(K.hrl_buffers)]
         L.hrl_get_state.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p, C.c_void_p]
         L.hrl_set_state.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p, C.c_void_p]
         L.hrl_set_goals.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]

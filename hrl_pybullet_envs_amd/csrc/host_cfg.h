@@ -42,6 +42,7 @@ inline int default_config(int32_t kind, hrl_config *c) {
     m.point_force = 500.f; /* point_bot.py:29 */
     m.self_collision = kind != HRL_POINT_GATHER; /* URDF_USE_SELF_COLLISION | ..._EXCLUDE_ALL_PARENTS */
     m.item_collision = kind == HRL_ANT_GATHER || kind == HRL_POINT_GATHER; /* food.xml / poison.xml are collidable boxes */
+    m.linear_damping = 0.f; m.angular_damping = 0.f; m.restitution = 0.f; m.restitution_threshold = 0.2f; m.max_contacts = MAXC; /* DESIGN.md 3.9 */
     if (kind != HRL_ANT_GATHER && kind != HRL_POINT_GATHER) c->walk_target[0] = 1000.f; /* upstream WalkerBase default walk target (1e3, 0) until the env sets one */
     if (kind == HRL_ANT_MAZE) {
         static const float t[4][2] = {{2, -3}, {2, 0}, {2, 3}, {-2, 4}}; /* ant_maze_bullet_env.py:13-14 */
@@ -61,6 +62,7 @@ inline int default_config(int32_t kind, hrl_config *c) {
     }
     c->flag_size = 10.f; c->flag_max_targets = 100; c->flag_timeout = 200; c->flag_switch_on_collision = 1; c->flag_enclosed = 1;
     c->flag_goal_capacity = 15;
+    c->flag_ant_env_rew_weight = 1.f; c->flag_path_rew_weight = 0.f; c->flag_dist_rew_weight = 0.f; c->flag_goal_reach_rew = 5000.f; /* ant_flagrun_env.py:157-160 */
     if (kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:14-16; arena (size+2)^2 :59-61; start (0,0,0.25) :144 */
         c->use_sensor = 0; c->n_bins = 8; c->sensor_span = 3.14159265358979323846f; c->sensor_range = 4.f; c->tol = 0.5f;
         c->world_size[0] = 12.f; c->world_size[1] = 12.f; c->start_pos[2] = 0.25f;
@@ -90,7 +92,7 @@ inline int act_dim(const hrl_config *c) { return c->env_kind == HRL_POINT_GATHER
 inline int items_stride(const hrl_config *c) {
     int words = 0;
     if (c->env_kind == HRL_ANT_GATHER || c->env_kind == HRL_POINT_GATHER) words = 2 * (c->n_food + c->n_poison);
-    if (c->env_kind == HRL_ANT_FLAGRUN && c->flag_manual_goals) words = 2 * (1 + c->flag_goal_capacity);
+    if (c->env_kind == HRL_ANT_FLAGRUN && c->flag_manual_goals) words = HRL_FLAG_PENDING_OFF + 2 * c->flag_goal_capacity;
     const int s = (words + 31) / 32 * 32;
     return s < HRL_ITEMS_STRIDE ? HRL_ITEMS_STRIDE : s;
 }
@@ -129,13 +131,15 @@ inline std::string validate(const hrl_config *c) {
         if (c->flag_timeout > 32767) return "flag_timeout must be <= 32767";
         if (!(c->flag_size > 1.0f)) return "flag_size must exceed 1 (targets are rejected within 0.5 of the origin)";
         if (c->use_sensor && (c->n_bins < 1 || c->n_bins > HRL_MAX_BINS)) return "sensor_bins must be within 1..64";
-        if (c->flag_manual_goals && (c->flag_goal_capacity < 1 || c->flag_goal_capacity > HRL_MAX_GOALS)) return "flag_goal_capacity must be within 1..63";
+        if (c->flag_manual_goals && (c->flag_goal_capacity < 1 || c->flag_goal_capacity > HRL_MAX_GOALS)) return "flag_goal_capacity must be within 1..61";
         if (c->use_sensor && c->n_bins < 2 && c->sensor_span != 6.28318530717958647692f) return "sensor_bins must be >= 2 unless sensor_span == 2 pi (the wall sensor divides by n_bins - 1)";
     }
     if (obs_dim(c) > HRL_MAX_OBS) { snprintf(buf, sizeof buf, "observation width %d exceeds %d", obs_dim(c), HRL_MAX_OBS); return buf; }
     const hrl_model &m = c->model;
     if (!(m.timestep > 0) || m.frame_skip < 1 || m.frame_skip > 64 || m.solver_iters < 1 || m.solver_iters > 64) return "bad timestep / frame_skip / solver_iters";
     if (!(m.density > 0)) return "density must be positive";
+    if (m.max_contacts < 1 || m.max_contacts > MAXC) return "model.max_contacts must be within 1..12";
+    if (!(m.linear_damping >= 0) || !(m.angular_damping >= 0) || !(m.restitution >= 0) || !(m.restitution_threshold >= 0)) return "model damping / restitution parameters must be >= 0";
     if (m.step_group != 0 && m.step_group != 1) return "model.step_group must be 0 (four env-waves per workgroup) or 1 (one wave per env)";
     return "";
 }
@@ -202,6 +206,12 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.flag_size = c.flag_size; d.flag_max_targets = c.flag_max_targets; d.flag_timeout = c.flag_timeout;
     d.flag_switch = c.flag_switch_on_collision; d.flag_mtd = c.flag_max_target_dist; d.flag_manual = c.flag_manual_goals;
     d.self_collision = m.self_collision; d.item_collision = m.item_collision; d.mu_self = m.friction_robot * m.friction_robot;
+    d.flag_path_on = c.env_kind == HRL_ANT_FLAGRUN && (c.flag_manual_goals || c.flag_max_target_dist > 0.f || c.flag_path_rew_weight != 0.f);
+    d.flag_w_env = c.flag_ant_env_rew_weight; d.flag_w_path = c.flag_path_rew_weight; d.flag_w_dist = c.flag_dist_rew_weight; d.flag_goal_rew = c.flag_goal_reach_rew;
+    d.max_contacts = m.max_contacts;
+    d.damping_on = (m.linear_damping != 0.f) || (m.angular_damping != 0.f);
+    { const float sl = 1.f - d.h * m.linear_damping, sa = 1.f - d.h * m.angular_damping; d.damp_lin = sl > 0.f ? sl : 0.f; d.damp_ang = sa > 0.f ? sa : 0.f; }
+    d.restitution = m.restitution; d.rest_thr = m.restitution_threshold;
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
     d.items_stride = items_stride(&c);
     d.item_shift = c.n_food + c.n_poison > 16 ? 6 : 4;

@@ -16,7 +16,9 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <string>
 
@@ -200,6 +202,13 @@ __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__rest
     GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
     reset_entry<KIND>(x, b, *cp, (int)blockIdx.x);
 }
+template <int KIND>
+__global__ __launch_bounds__(64, 4) void k_observe(DevBufs b, const DevCfg *__restrict__ cp) {
+    __shared__ WaveLds L[1];
+    LaneRegs regs;
+    GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
+    observe_entry<KIND>(x, b, *cp, (int)blockIdx.x);
+}
 __global__ __launch_bounds__(64, 4) void k_set_goals(DevBufs b, const DevCfg *__restrict__ cp, const float *goals_xy, int n_goals, uint8_t *ok) {
     __shared__ WaveLds L[1];
     LaneRegs regs;
@@ -235,6 +244,16 @@ kernel_fn reset_kernel(int kind) {
         default: return k_reset<HRL_POINT_GATHER>;
     }
 }
+kernel_fn observe_kernel(int kind) {
+    switch (kind) {
+        case HRL_ANT_FLAT: return k_observe<HRL_ANT_FLAT>;
+        case HRL_ANT_GATHER: return k_observe<HRL_ANT_GATHER>;
+        case HRL_ANT_MAZE: return k_observe<HRL_ANT_MAZE>;
+        case HRL_ANT_MAZE_MJ: return k_observe<HRL_ANT_MAZE_MJ>;
+        case HRL_ANT_FLAGRUN: return k_observe<HRL_ANT_FLAGRUN>;
+        default: return k_observe<HRL_POINT_GATHER>;
+    }
+}
 /* packed record <-> split qpos[N][15], qvel[N][14] */
 __global__ void k_get_state(const float *state, float *qpos, float *qvel, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, e = i >> 5, k = i & 31;
@@ -256,11 +275,14 @@ int fail(int code, const std::string &msg) {
 }
 int hip_fail(hipError_t e, const char *what) { return fail(HRL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
 
+/* An optional pointer of the record that lies within the caller's struct_size (hrl_buffers: a caller compiled against an older header of this ABI
+ * version handed over a shorter record; what lies beyond it is not the caller's to set). */
+#define HRL_OPT(b, field) ((b)->struct_size >= offsetof(hrl_buffers, field) + sizeof((b)->field) ? (b)->field : nullptr)
 DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
     DevBufs d;
     d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
     d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask;
-    d.final_obs = b->final_obs; d.truncated = b->truncated;
+    d.final_obs = HRL_OPT(b, final_obs); d.truncated = HRL_OPT(b, truncated); d.goal = HRL_OPT(b, goal); d.rows = HRL_OPT(b, solver_rows);
     d.stamps = g_stamps;
     return d;
 }
@@ -271,9 +293,27 @@ struct hrl_handle {
     hrl_config cfg;
     DevCfg dc;
     DevCfg *d_dc; /* device copy of the constants (the only device memory the library owns) */
-    int device;
+    int device;   /* the device that was current at hrl_create(): d_dc lives there, and so must the caller's buffers */
     int group;    /* envs per workgroup of the step kernel */
 };
+
+namespace {
+/* What every entry point that launches checks first: a handle, a buffer record that was initialised (hrl_buffers_init) and the device.
+ * A launch goes to the CURRENT device with the handle's constants pointer: from another device that is a fault in the kernel, not an error
+ * code -- so a host that drives several GPUs from one process gets HRL_ERR_BAD_ARG here and is told to hipSetDevice() first (hipGetDevice
+ * is a thread-local read: ~20 ns, tools/host_overhead.py). */
+int check_call(const hrl_handle *h, const hrl_buffers *b, const char *who) {
+    if (!h || !b) return fail(HRL_ERR_BAD_ARG, std::string(who) + ": null handle or buffer record");
+    if (b->struct_size < HRL_BUFFERS_SIZE_V7_BASE || b->struct_size > sizeof(hrl_buffers) || b->struct_size % sizeof(void *) != 0)
+        return fail(HRL_ERR_BAD_ARG, std::string(who) + ": hrl_buffers.struct_size = " + std::to_string((unsigned long long)b->struct_size) +
+                                         " is not the size of a known layout: initialise the record with hrl_buffers_init() (include/hrl_envs.h)");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device)
+        return fail(HRL_ERR_BAD_ARG, std::string(who) + ": the handle was created on HIP device " + std::to_string(h->device) + ", the current device is " +
+                                         std::to_string(cur) + ": hipSetDevice(" + std::to_string(h->device) + ") before calling (one handle per device)");
+    return HRL_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -317,36 +357,56 @@ int hrl_destroy(hrl_handle *h) {
 }
 
 static bool needs_items(const DevCfg &dc) {
-    return dc.kind == HRL_ANT_GATHER || dc.kind == HRL_POINT_GATHER || (dc.kind == HRL_ANT_FLAGRUN && (dc.flag_mtd > 0.f || dc.flag_manual));
+    return dc.kind == HRL_ANT_GATHER || dc.kind == HRL_POINT_GATHER || (dc.kind == HRL_ANT_FLAGRUN && dc.flag_path_on);
 }
+static const char *items_why = "this env keeps state in the items buffer (gather kinds; flagrun with max_target_dist, manual goals or a path reward weight)";
 
 int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *stream) {
-    if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_reset: null handle or buffer");
-    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_reset: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist or manual goals)");
+    if (const int rc = check_call(h, b, "hrl_reset")) return rc;
+    if (!b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_reset: null buffer");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, std::string("hrl_reset: ") + items_why);
     hipLaunchKernelGGL(reset_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_reset launch");
 }
 
 int hrl_step(hrl_handle *h, const hrl_buffers *b, void *stream) {
-    if (!h || !b || !b->state || !b->aux || !b->obs || !b->actions || !b->reward || !b->done || !b->info)
-        return fail(HRL_ERR_BAD_ARG, "hrl_step: null handle or buffer");
-    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_step: this env keeps state in the items buffer (gather kinds, flagrun with max_target_dist or manual goals)");
+    if (const int rc = check_call(h, b, "hrl_step")) return rc;
+    if (!b->state || !b->aux || !b->obs || !b->actions || !b->reward || !b->done || !b->info) return fail(HRL_ERR_BAD_ARG, "hrl_step: null buffer");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, std::string("hrl_step: ") + items_why);
     const int G = h->group;
     hipLaunchKernelGGL(step_kernel(h->dc.kind, G), dim3((h->dc.n_envs + G - 1) / G), dim3(64 * G), 0, (hipStream_t)stream, to_dev(b, nullptr), (const DevCfg *)h->d_dc);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_step launch");
 }
 
+int hrl_buffers_init(hrl_buffers *b) {
+    if (!b) return fail(HRL_ERR_BAD_ARG, "hrl_buffers_init: null record");
+    memset(b, 0, sizeof(*b));
+    b->struct_size = sizeof(*b);
+    return HRL_OK;
+}
+
+int hrl_observe(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *stream) {
+    if (const int rc = check_call(h, b, "hrl_observe")) return rc;
+    if (!b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_observe: null buffer");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, std::string("hrl_observe: ") + items_why);
+    hipLaunchKernelGGL(observe_kernel(h->dc.kind), dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_observe launch");
+}
+
 int hrl_get_state(hrl_handle *h, const hrl_buffers *b, float *qpos, float *qvel, void *stream) {
-    if (!h || !b || !b->state || !qpos || !qvel) return fail(HRL_ERR_BAD_ARG, "hrl_get_state: null argument");
+    if (const int rc = check_call(h, b, "hrl_get_state")) return rc;
+    if (!b->state || !qpos || !qvel) return fail(HRL_ERR_BAD_ARG, "hrl_get_state: null argument");
     const int n = h->dc.n_envs, total = n * 32;
     hipLaunchKernelGGL(k_get_state, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->state, qpos, qvel, n);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_get_state launch");
 }
 int hrl_set_state(hrl_handle *h, const hrl_buffers *b, const float *qpos, const float *qvel, void *stream) {
-    if (!h || !b || !b->state || !qpos || !qvel) return fail(HRL_ERR_BAD_ARG, "hrl_set_state: null argument");
+    if (const int rc = check_call(h, b, "hrl_set_state")) return rc;
+    if (!b->state || !qpos || !qvel) return fail(HRL_ERR_BAD_ARG, "hrl_set_state: null argument");
     const int n = h->dc.n_envs, total = n * 32;
     hipLaunchKernelGGL(k_set_state, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->state, qpos, qvel, n);
     const hipError_t e = hipGetLastError();
@@ -354,7 +414,8 @@ int hrl_set_state(hrl_handle *h, const hrl_buffers *b, const float *qpos, const 
 }
 
 int hrl_set_goals(hrl_handle *h, const hrl_buffers *b, const float *goals_xy, int32_t n_goals, const uint8_t *mask, void *stream) {
-    if (!h || !b || !b->state || !b->aux || !b->obs || !b->items || !goals_xy) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: null handle or buffer");
+    if (const int rc = check_call(h, b, "hrl_set_goals")) return rc;
+    if (!b->state || !b->aux || !b->obs || !b->items || !goals_xy) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: null buffer");
     if (h->dc.kind != HRL_ANT_FLAGRUN || !h->dc.flag_manual) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: only for AntFlagrun with flag_manual_goals (manual_goal_creation, ant_flagrun_env.py:27)");
     if (h->dc.flag_mtd > 0.f) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: with flag_max_targets < 1 next_target() draws a goal near the robot and ignores the list (ant_flagrun_env.py:113-114): use hrl_next_target");
     if (n_goals < 1 || n_goals > h->cfg.flag_goal_capacity) return fail(HRL_ERR_BAD_ARG, "hrl_set_goals: n_goals must be within 1..flag_goal_capacity (" + std::to_string(h->cfg.flag_goal_capacity) + ")");
@@ -364,9 +425,10 @@ int hrl_set_goals(hrl_handle *h, const hrl_buffers *b, const float *goals_xy, in
 }
 
 int hrl_next_target(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, uint8_t *ok, void *stream) {
-    if (!h || !b || !b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: null handle or buffer");
+    if (const int rc = check_call(h, b, "hrl_next_target")) return rc;
+    if (!b->state || !b->aux || !b->obs) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: null buffer");
     if (h->dc.kind != HRL_ANT_FLAGRUN) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: only for AntFlagrun (ant_flagrun_env.py:112-120)");
-    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, "hrl_next_target: this env keeps its goals in the items buffer (max_target_dist or manual goals)");
+    if (needs_items(h->dc) && !b->items) return fail(HRL_ERR_BAD_ARG, std::string("hrl_next_target: ") + items_why);
     hipLaunchKernelGGL(k_set_goals, dim3(h->dc.n_envs), dim3(64), 0, (hipStream_t)stream, to_dev(b, mask), (const DevCfg *)h->d_dc, (const float *)nullptr, 0, ok);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? HRL_OK : hip_fail(e, "hrl_next_target launch");

@@ -84,6 +84,12 @@ struct DevCfg {
     int self_collision, item_collision;
     float mu_self; /* friction between two ant links */
     int obs_dim, act_dim;
+    float flag_w_env, flag_w_path, flag_w_dist, flag_goal_rew; /* ant_flagrun_env.py:157-160 */
+    int flag_path_on;             /* the env keeps `_goal_start_pos` / `_sq_dist_goal` in its items record (manual goals, goals near the robot, or a path reward weight) */
+    int max_contacts;             /* contacts kept per substep, <= MAXC */
+    int damping_on;               /* base damping: the torso twist of the unconstrained update is scaled by damp_ang / damp_lin */
+    float damp_lin, damp_ang;
+    float restitution, rest_thr;  /* > 0: normal rows of fast approaches ask for a separating velocity */
     int items_stride; /* floats per env of the items buffer (hrl_items_stride): 32 for the default configs */
     int item_shift;   /* respawn key of a contact pickup: item | move << item_shift; 4 for up to 16 items (the streams of ABI <= 5), else 6 */
 };
@@ -97,6 +103,8 @@ struct DevBufs {
     float *info;
     float *final_obs;   /* optional: the observation of the step that ended an episode (include/hrl_envs.h) */
     uint8_t *truncated; /* optional: ended by the step limit alone */
+    float *goal;        /* optional, flagrun: goal x, y | switched to it in this step | steps since the goal changed */
+    int32_t *rows;      /* optional, diagnostic: += solver rows of the step (limits + 3 x contacts over its substeps) */
     const uint8_t *mask;
     unsigned long long *stamps; /* diagnostic builds only (tools/stamp_profile.py): per-phase cycle sums */
 };
@@ -999,10 +1007,16 @@ HRL_DEV void build_A_blocks(const WaveLds &L, LaneRegs &g, int nB, int nF, float
     (build_Af_group<SELF, Gf, WIDE>(L, g, nB, nF, ninvd, one, j2), ...);
 }
 template <bool SELF, int MB, class One> /* MB = most bounded rows the caller can have (a multiple of four): columns past it are not built */
-HRL_DEV void phase_build_A(const WaveLds &L, LaneRegs &g, int lane, int nB, int nF, One one) {
+HRL_DEV void phase_build_A(const DevCfg &c, const WaveLds &L, LaneRegs &g, int lane, int nL, int nB, int nF, One one) {
     J2pair j2{0.f, 0.f};
     if (SELF && lane < MAXR) { j2.h = L.J2[lane][0]; j2.a = L.J2[lane][1]; }
     constexpr bool FREE = MB != MAXB; /* the point bot's solver (no limit rows: at most MAXC bounded rows) */
+    if (c.restitution > 0.f) { /* hrl_model.restitution (default 0: skipped, wave-uniform): a normal row whose bodies approach faster than the threshold
+                                  (J . u at the start of the substep) asks for the separating velocity restitution * (approach speed) */
+        const float vn = row_dot<SELF, FREE>(g, L.u, j2);
+        const bool normal = (lane >= nL) & (lane < nB);
+        g.bias = (normal & (vn < -c.rest_thr)) ? fma_(c.restitution, vn, g.bias) : g.bias;
+    }
     const float invd = 1.f / row_dot<SELF, FREE>(g, L.Bt[lane < nB + nF ? lane : 0], j2); /* 1 / A_ii; idle lanes carry row 0's registers */
     build_A_blocks<SELF>(L, g, nB, nF, -invd, one, j2, std::make_integer_sequence<int, MB / 4>{}, std::make_integer_sequence<int, MAXF / 4>{});
     g.c = -(invd * (row_dot<SELF, FREE>(g, L.ustar, j2) + g.bias));
@@ -1103,8 +1117,9 @@ HRL_DEV void pgs_solve(X &x, const DevCfg &c, int nL, int nC, bool ant, bool sel
     WaveLds &L = x.lds();
     const int nB = ant ? nL + nC : nC, nF = 2 * nC, nR = nB + nF;
     if (nR <= 0) return;
-    if (self) x.each([&](int lane) { phase_build_A<true, MB>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
-    else x.each([&](int lane) { phase_build_A<false, MB>(L, x.reg(lane), lane, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
+    const int nLim = ant ? nL : 0;
+    if (self) x.each([&](int lane) { phase_build_A<true, MB>(c, L, x.reg(lane), lane, nLim, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
+    else x.each([&](int lane) { phase_build_A<false, MB>(c, L, x.reg(lane), lane, nLim, nB, nF, [&](int r) { return x.lane_one(lane, r); }); });
     if (MB != MAXB) /* the point bot's kernel sits at its register cap: lines spilled around the build are reloaded HERE, not inside the sweeps */
         x.each([&](int lane) {
             LaneRegs &g = x.reg(lane);
@@ -1175,7 +1190,12 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_leg_sum(L, lane & 15); phase_leg_sum(L, (lane & 15) + 16); });
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_base(L, x.reg(lane), (lane & 15) << 2); });
     x.stamp(3);
-    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); const float v = phase_forward_vel(c, L, lane & 15); L.ustar[lane & 15] = v; });
+    x.leader([&](int lane) {
+        WaveLds &L = x.lds(lane >> 4);
+        float v = phase_forward_vel(c, L, lane & 15);
+        if (c.damping_on) { const int d = lane & 15; v = v * (d < 3 ? c.damp_ang : (d < 6 ? c.damp_lin : 1.f)); } /* hrl_model.linear_damping / angular_damping (default: off, wave-uniform) */
+        L.ustar[lane & 15] = v;
+    });
     x.stamp(4);
 }
 
@@ -1185,6 +1205,7 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
 template <class X>
 HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_on) {
     const float *q = L.q[qi];
+    const int cap = c.max_contacts; /* contacts kept per substep (hrl_model.max_contacts <= MAXC) */
     x.refresh();
     x.each([&](int lane) { phase_kin_ankle<true>(c, L, x.reg(lane), q, lane); });
     /* contacts in surface-major, sphere-minor order (ballot ranks follow lane order), at most MAXC kept:
@@ -1233,7 +1254,7 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
             keep(nC, pass == 0),
             [&](int lane, const Hit &h) { if (pass == 0 && lane < 16) L.gtouch[lane] = h.ok ? 1 : 0; });
         nC += cnt;
-        if (nC > MAXC) nC = MAXC;
+        if (nC > cap) nC = cap;
     }
     if (items_on) { /* food / poison cubes: lane = item decides whether its cube is within reach of any sphere (the cube's
                        half extent more than the planes' bound, per axis), then the near cubes are tested four at a time */
@@ -1265,7 +1286,7 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
                 },
                 keep(nC), [&](int, const Hit &) {});
             nC += cnt;
-            if (nC > MAXC) nC = MAXC;
+            if (nC > cap) nC = cap;
         }
     }
     if (c.self_collision) { /* Seen from above in the torso frame, leg l is the jointless capsule O -> hip point followed by the aux
@@ -1281,7 +1302,7 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
         }) == 0;
         if (!x.uniform(spread)) {
             int cnt = x.each_compact([&](int lane) { return capsule_pair(c, L, lane < 48 ? lane : -1); }, keep(nC), [&](int, const Hit &) {});
-            nS = nC + cnt > MAXC ? MAXC - nC : cnt; /* self contacts among the kept ones: their rows take the two-body path */
+            nS = nC + cnt > cap ? cap - nC : cnt; /* self contacts among the kept ones: their rows take the two-body path */
             nC += nS;
         }
     }
@@ -1345,6 +1366,7 @@ HRL_DEV void store_contact(WaveLds &L, int i, const Hit &h, bool up) {
 template <class X>
 HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
     x.refresh();
+    const int cap = c.max_contacts;
     x.each([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_kin_ankle<true>(c, L, x.reg(lane), L.q[qi], (lane & 15) << 2); });
     const float reach = 0.2f * 1.41421356f + c.L1 + c.L2 + c.r_caps + c.cdist + 0.02f;
     /* ground pass of the four envs; its count starts the env's list */
@@ -1354,7 +1376,7 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
         [&](int lane, const Hit &h, int count) {
             WaveLds &L = x.lds(lane >> 4);
             L.gtouch[lane & 15] = h.ok ? 1 : 0;
-            if ((lane & 15) == 0) { L.nC = count > MAXC ? MAXC : count; L.nS = 0; }
+            if ((lane & 15) == 0) { L.nC = count > cap ? cap : count; L.nS = 0; }
         });
     /* lateral surfaces and the maze box: the envs within reach of one, one after the other (wave-uniform loop, all 64 lanes per env) */
     if (c.n_planes > 0 || c.n_boxes > 0) {
@@ -1386,7 +1408,7 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
                     [&L, nC](int, int rank, const Hit &h) { store_contact(L, nC + rank, h, false); },
                     [&](int, const Hit &) {});
                 nC += cnt;
-                if (nC > MAXC) nC = MAXC;
+                if (nC > cap) nC = cap;
             }
             x.each([&](int lane) { if (lane == 0) L.nC = nC; });
         }
@@ -1422,7 +1444,7 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
                 [&](int lane, int rank, const Hit &h) { WaveLds &L = x.lds(lane >> 4); store_contact(L, L.nC + rank, h, false); },
                 [&](int lane, const Hit &, int count) { if ((lane & 15) == 0) x.lds(lane >> 4).ncnt = count; });
             x.each([&](int lane) {
-                if ((lane & 15) == 0) { WaveLds &L = x.lds(lane >> 4); const int n = L.nC + L.ncnt; L.nC = n > MAXC ? MAXC : n; }
+                if ((lane & 15) == 0) { WaveLds &L = x.lds(lane >> 4); const int n = L.nC + L.ncnt; L.nC = n > cap ? cap : n; }
             });
             }
             unsigned long long low = 0; /* every env's lowest set bit is done */
@@ -1446,7 +1468,7 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
             const int nC = x.uniform(L.nC);
             int cnt = x.each_compact([&](int lane) { return capsule_pair(c, L, lane < 48 ? lane : -1); },
                                      [&L, nC](int, int rank, const Hit &h) { store_contact(L, nC + rank, h, false); }, [&](int, const Hit &) {});
-            const int nS = nC + cnt > MAXC ? MAXC - nC : cnt;
+            const int nS = nC + cnt > cap ? cap - nC : cnt;
             x.each([&](int lane) { if (lane == 0) { L.nC = nC + nS; L.nS = nS; } });
         }
     }
@@ -1490,7 +1512,7 @@ HRL_DEV void ant_limits_group(X &x, const DevCfg &c, int qi) {
  * block and the lists of ant_contacts are in the env's record; rows, sweeps, velocity reconstruction and clamp, then the
  * positions are integrated into L.q[qi ^ 1]. */
 template <class X>
-HRL_DEV void ant_env_block(X &x, const DevCfg &c, int qi) {
+HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi) { /* returns the substep's solver rows (wave-uniform) */
     WaveLds &L = x.lds();
     x.refresh();
     const int nC = x.uniform(L.nC), nL = x.uniform(L.nL), nS = x.uniform(L.nS);
@@ -1510,6 +1532,7 @@ HRL_DEV void ant_env_block(X &x, const DevCfg &c, int qi) {
     x.stamp(18);
     x.each([&](int lane) { phase_integrate(c, L, L.q[qi], L.q[qi ^ 1], lane & 15); });
     x.stamp(20);
+    return nL + 3 * nC;
 }
 
 /* Who finds the contacts and limit rows while the leader (wave 0) runs the group block (7.5 k cycles): wave 1 the contacts of all four
@@ -1537,6 +1560,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
     const float *q = L.q[qi];
     float *qn = L.q[qi ^ 1];
     const float m = 10.f, he = 0.35f, I = m * (0.7f * 0.7f) / 6.f;
+    const int cap = c.max_contacts;
     x.refresh();
     x.each([&](int lane) {
         const int d = lane & 15;
@@ -1544,6 +1568,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
         if (d == 3) v = fma_(c.h, L.tau[0] / m, L.u[3]);
         if (d == 4) v = fma_(c.h, L.tau[1] / m, L.u[4]);
         if (d == 5) v = fma_(c.h, L.tau[2] / m - c.g, L.u[5]);
+        if (c.damping_on) v = v * (d < 3 ? c.damp_ang : c.damp_lin); /* hrl_model.linear_damping / angular_damping (default: off) */
         x.reg(lane).ud = d < 6 ? v : 0.f;
         if (lane < 16) L.ustar[lane] = d < 6 ? v : 0.f;
         float ax_[3], ay_[3], az_[3];
@@ -1587,7 +1612,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
          corner-minor candidate order of the specification is the lane order */
         int cnt = x.each_compact([&](int lane) { return corner(lane, (lane >> 3) < 1 + c.n_planes, lane >> 3, -1); }, keep(nC), [&](int, const CornerHit &) {});
         nC += cnt;
-        if (nC > MAXC) nC = MAXC;
+        if (nC > cap) nC = cap;
     }
     if (items_on) { /* cubes whose box comes within reach of a corner (half diagonal 0.35 sqrt 3 = 0.607), four per pass */
         const float R = 0.35f * 1.7320508f + ITEM_HALF + c.cdist + 0.02f;
@@ -1610,7 +1635,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
                 },
                 keep(nC), [&](int, const CornerHit &) {});
             nC += cnt;
-            if (nC > MAXC) nC = MAXC;
+            if (nC > cap) nC = cap;
         }
         /* then the near cubes' own 8 corners against the player's oriented box -- what catches a cube under the middle of a face --,
            eight cubes per pass: the corner in the box frame, its closest surface point, the normal turned back to the world and
@@ -1650,7 +1675,7 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
                 },
                 keep(nC), [&](int, const CornerHit &) {});
             nC += cnt;
-            if (nC > MAXC) nC = MAXC;
+            if (nC > cap) nC = cap;
         }
         }
     }
@@ -1784,6 +1809,13 @@ HRL_DEV void flag_close_goal(const DevCfg &c, long long env, uint32_t ep, uint32
     }
 }
 
+/* ant_flagrun_env.py:98-103 `set_target`: besides the walk target, where the robot stands now (`robot_body.get_position()[:2]`) and
+ * `np.linalg.norm(goal - pos) ** 2` -- the norm squared, not the sum of squares -- for the path reward of :174-176; into the items record */
+HRL_DEV void flag_set_target_state(WaveLds &L, float gx, float gy, float px, float py) {
+    const float dx = gx - px, dy = gy - py, nrm = sqrtf(dx * dx + dy * dy);
+    L.items[HRL_FLAG_START_OFF] = px; L.items[HRL_FLAG_START_OFF + 1] = py; L.items[HRL_FLAG_SQDIST_OFF] = nrm * nrm;
+}
+
 /* sizeable_enclosed_scene.py:63-97 `sense_walls`, one bin: the ray and all 7 maze lines are INFINITE lines
  * (intersection_utils.py:74-90), filtered by range and quadrant */
 HRL_DEV float wall_sensor_bin(const DevCfg &c, float rx, float ry, float yaw, int i, bool arena) {
@@ -1833,6 +1865,7 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
         else flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.aux[3] & 0xffffu, &tx, &ty);
     }
     if (KIND == 2 || KIND == 4) { tx = mtx; ty = mty; } /* maze kinds: the episode's target (maze_target) */
+    if (KIND == 5) { L.red[4] = tx; L.red[5] = ty; } /* the goal this state looks at: path reward, `goal` output (every lane writes the same values) */
     float cx = qp[0], cy = qp[1];
     if (with_centroid) {
         float sx = 0.f, sy = 0.f;
@@ -2124,13 +2157,22 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
                 if (i < c.n_food + c.n_poison) respawn_item(c, env, ep, 1u, i, 0.f, 0.f, &px, &py);
                 L.items[2 * i] = px; L.items[2 * i + 1] = py;
             }
-        } else if (KIND == 5) {
-            if (c.flag_manual) { /* the walk target survives the reset, the pending goals do not (ant_flagrun_env.py:149-152) */
-                if (lane < 48) { L.items[2 * (lane - 32)] = lane == 32 ? ptx : 0.f; L.items[2 * (lane - 32) + 1] = lane == 32 ? pty : 0.f; }
-            } else if (c.flag_mtd > 0.f && lane < 48) { /* lanes 32..47: the items record = the current goal, zeros */
-                float px = 0.f, py = 0.f; /* reset -> next_target -> create_close_target around the start pose, new episode's stream */
-                if (lane == 32) flag_close_goal(c, env, ep + 1u, 1u, c.start_pos[0], c.start_pos[1], &px, &py);
-                L.items[2 * (lane - 32)] = px; L.items[2 * (lane - 32) + 1] = py;
+        } else if (KIND == 5 && c.flag_path_on) { /* lanes 32..63: the first 32 words of the items record (flagrun layout: include/hrl_envs.h, HRL_FLAG_*; an env
+                                                     of the shared goal list without a path reward keeps nothing in it) */
+            const int w = lane - 32;
+            if (c.flag_manual) { /* the walk target and the path-reward state survive the reset, the pending goals do not (ant_flagrun_env.py:149-152) */
+                if (w == 0) L.items[0] = ptx;
+                if (w == 1) L.items[1] = pty;
+                if (w >= HRL_FLAG_PENDING_OFF) L.items[w] = 0.f;
+            } else { /* reset -> next_target -> set_target(first goal of the new episode) with the robot at the start pose (:144-153) */
+                float gx = 0.f, gy = 0.f;
+                if (w == 0) {
+                    if (c.flag_mtd > 0.f) flag_close_goal(c, env, ep + 1u, 1u, c.start_pos[0], c.start_pos[1], &gx, &gy); /* create_close_target around the start pose, new episode's stream */
+                    else flag_goal(c, ep + 1u, 1u, &gx, &gy);
+                    flag_set_target_state(L, gx, gy, c.start_pos[0], c.start_pos[1]);
+                    L.items[0] = c.flag_mtd > 0.f ? gx : 0.f; L.items[1] = c.flag_mtd > 0.f ? gy : 0.f; /* the shared list's goals are functions of (seed, episode, k): not stored */
+                    L.items[HRL_FLAG_SQDIST_OFF + 1] = 0.f;
+                } else if (w >= HRL_FLAG_PENDING_OFF) L.items[w] = 0.f;
             }
         }
         if (lane < 16) L.u[lane] = 0.f;
@@ -2142,7 +2184,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
             L.aux[3] = (int)(r[0] % (uint32_t)c.n_targets);
         }
     });
-    if ((KIND == 1 || KIND == 3 || KIND == 5) && c.items_stride > 32) /* a longer items record: items 16.. of a gather env (gather_scene.py:38-50), zeros elsewhere */
+    if ((KIND == 1 || KIND == 3 || KIND == 5) && c.items_stride > 32) /* a longer items record: items 16.. of a gather env (gather_scene.py:38-50), zeros elsewhere (flagrun: the rest of the pending list) */
         x.each([&](int lane) {
             const uint32_t ep = (uint32_t)L.aux[2];
             const int i = 16 + lane;
@@ -2209,9 +2251,24 @@ HRL_DEV void reset_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     store_env(x, b, c, e);
 }
 
+/* hrl_observe for one env: the observation of the record as it stands (calc_state + the task's sensors, as after a teleport:
+ * ant_maze_bullet_env.py:117-121); nothing but `obs` is written */
+template <int KIND, class X>
+HRL_DEV void observe_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
+    if (b.mask && !b.mask[e]) return;
+    WaveLds &L = x.lds();
+    load_env(x, b, c, e, false);
+    compute_obs<KIND>(x, c, c.env_id_offset + e, false);
+    x.each([&](int lane) {
+#pragma unroll 1
+        for (int o = 0; o < c.obs_dim; o += 64)
+            if (o + lane < c.obs_dim) b.obs[(size_t)e * c.obs_dim + (o + lane)] = L.obs[o + lane];
+    });
+}
+
 /* hrl_set_goals / hrl_next_target for one env: `env.goals = [...]` (n_goals > 0) and `env.next_target()` of a
- * manual_goal_creation flagrun env (ant_flagrun_env.py:45,112-120).  The list is kept in list order behind the current goal
- * (items[2 + 2k..] = goals[k]); next_target() takes the LAST one (`self.goals.pop()`, :116), or with max_targets < 1 draws a
+ * manual_goal_creation flagrun env (ant_flagrun_env.py:45,112-120).  The list is kept in list order behind the current goal and the
+ * path-reward state (items[HRL_FLAG_PENDING_OFF + 2k..] = goals[k]); next_target() takes the LAST one (`self.goals.pop()`, :116), or with max_targets < 1 draws a
  * goal near the robot whatever the list holds (:113-114); _rewarded is cleared (:118), the potential is left alone (:119
  * re-reads the stale walk_target_dist), the observation is calc_state towards the new goal (:120).  ok[e] = 0 where the
  * reference raises IndexError (empty list): nothing but the observation is written then. */
@@ -2225,8 +2282,8 @@ HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, con
         x.each([&](int lane) {
 #pragma unroll 1
             for (int w = lane; w < c.items_stride; w += 64)
-                if (w >= 2) { /* items word w: pending slot (w - 2) >> 1 */
-                    const int k = (w - 2) >> 1, comp = w & 1;
+                if (w >= HRL_FLAG_PENDING_OFF) { /* items word w: pending slot (w - HRL_FLAG_PENDING_OFF) >> 1 */
+                    const int k = (w - HRL_FLAG_PENDING_OFF) >> 1, comp = w & 1;
                     L.items[w] = k < n_goals ? goals_xy[((size_t)e * n_goals + k) * 2 + comp] : 0.f;
                 }
             if (lane == 63) L.aux[3] = (int)(((uint32_t)n_goals & 0xffffu) | ((uint32_t)L.aux[3] & 0xffff0000u));
@@ -2245,8 +2302,13 @@ HRL_DEV void set_goals_entry(X &x, const DevBufs &b, const DevCfg &c, int e, con
                                         `cur` of its flag_max_targets goals are used up; popping one more is cur + 1 */
             if (cur >= (uint32_t)c.flag_max_targets) good = 0; else cur += 1u;
         } else if (cur == 0u) good = 0;
-        else { cur -= 1u; gx = L.items[2 + 2 * cur]; gy = L.items[3 + 2 * cur]; }
-        if (good) { L.items[0] = gx; L.items[1] = gy; L.aux[3] = (int)(cur | (a3 & 0x7fff0000u)); }
+        else { cur -= 1u; gx = L.items[HRL_FLAG_PENDING_OFF + 2 * cur]; gy = L.items[HRL_FLAG_PENDING_OFF + 1 + 2 * cur]; }
+        if (good) {
+            if (!c.flag_manual && !(c.flag_mtd > 0.f)) flag_goal(c, (uint32_t)L.aux[2], cur, &gx, &gy); /* the shared list's next goal, for set_target's bookkeeping */
+            else { L.items[0] = gx; L.items[1] = gy; }
+            if (c.flag_path_on) flag_set_target_state(L, gx, gy, L.st[0], L.st[1]); /* set_target (:98-103) with the robot where it is */
+            L.aux[3] = (int)(cur | (a3 & 0x7fff0000u));
+        }
         if (ok) ok[e] = (uint8_t)good;
     });
     compute_obs<5>(x, c, env, false);
@@ -2279,6 +2341,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     }
     x.stamp(12);
     int qi = 0, n_contacts = 0; /* n_contacts: the contacts of the step's last collision pass (contact-based pickup) */
+    int rows_acc = 0;           /* solver rows over the step's substeps (wave-uniform; the optional diagnostic output `solver_rows`) */
     const bool items_on = (KIND == 1 || KIND == 3) && c.item_collision != 0;
     HRL_PIN_INT(qi);
     const int slot = x.slot();
@@ -2287,6 +2350,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         for (int s = 0; s < c.nsub; ++s) { /* one copy of the substep body: it is the kernel's instruction-cache footprint */
             x.priority(slot + s); /* scheduling only, no effect on results: see GpuExec::priority */
             n_contacts = point_substep(x, c, qi, items_on);
+            rows_acc += 3 * n_contacts;
             qi ^= 1;
             HRL_PIN_INT(qi); /* keep the ping-pong index a run-time value so the body is not cloned per parity */
         }
@@ -2321,7 +2385,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             x.group_sync();
             x.stamp(17); /* waiting for the slower of the leader and the contact waves */
 #ifndef HRL_ABLATE_ENV
-            if (on) ant_env_block(x, c, qi);
+            if (on) rows_acc += ant_env_block(x, c, qi);
 #endif
             x.group_sync();
             x.stamp(19); /* waiting for the slowest env block of the group */
@@ -2374,10 +2438,17 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             const bool close = c.flag_mtd > 0.f, listed = c.flag_manual && !close; /* max_targets < 1: goals near the robot whoever made the env (:113-114) */
             const int step_cur = listed ? -1 : 1;
             auto more = [&]() { return close ? true : (listed ? cur > 0 : cur < c.flag_max_targets); };
-            rew = (alive + progress) * 1.f;
+            rew = (alive + progress) * c.flag_w_env; /* r *= ant_env_rew_weight (:169) */
+            if (c.flag_path_on) { /* :174-176: how far along the straight line from where the goal was received to the goal, over the squared distance then
+                                     (the record holds both; 0 / 0 before a manual env got its first goal: NaN, as in the reference) */
+                const float gsx = L.items[HRL_FLAG_START_OFF], gsy = L.items[HRL_FLAG_START_OFF + 1];
+                const float path = ((L.st[0] - gsx) * (L.red[4] - gsx) + (L.st[1] - gsy) * (L.red[5] - gsy)) / L.items[HRL_FLAG_SQDIST_OFF];
+                rew = rew + path * c.flag_w_path;
+            }
+            rew = rew + (-wtd) * c.flag_w_dist; /* :178 */
             done = idone;
             if (wtd < c.tol) {
-                if (!rewarded) { rew += 5000.f; rewarded = 1; }
+                if (!rewarded) { rew += c.flag_goal_rew; rewarded = 1; }
                 if (c.flag_switch) {
                     if (more()) { cur += step_cur; rewarded = 0; steps = 0; retarget = 1; } else done = 1;
                 }
@@ -2425,20 +2496,21 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
         if (lane == 0) {
             L.aux[0] = L.aux[0] + 1; b.reward[eo] = L.scal[0]; b.done[eo] = (uint8_t)L.flags[1];
             if (b.truncated) b.truncated[eo] = (uint8_t)L.flags[2];
+            if (b.rows) b.rows[eo] += rows_acc;
         }
         if (lane == 1) L.aux[1] = L.aux[1] + 1;
         if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
         if (lane == 8 && KIND == 5) L.aux[3] = L.flags[4];
-        if (lane == 9 && KIND == 5 && c.flag_manual && !(c.flag_mtd > 0.f) && L.flags[3]) { /* goals.pop() (ant_flagrun_env.py:116): the last goal of the pending list */
-            const int top = L.flags[4] & 0xffff;
-            const float gx = L.items[2 + 2 * top], gy = L.items[3 + 2 * top];
-            L.items[0] = gx; L.items[1] = gy;
-        }
-        if (lane == 9 && KIND == 5 && c.flag_mtd > 0.f && L.flags[3]) { /* set_target(*create_close_target()) around the robot's xy */
+        if (lane == 9 && KIND == 5 && L.flags[3]) { /* next_target() (ant_flagrun_env.py:110-118) -> set_target(new goal) with the robot where it is */
             float gx, gy;
-            flag_close_goal(c, env, (uint32_t)L.aux[2], (uint32_t)L.flags[4] & 0xffffu, L.st[0], L.st[1], &gx, &gy);
-            L.items[0] = gx; L.items[1] = gy;
+            if (c.flag_mtd > 0.f) flag_close_goal(c, env, (uint32_t)L.aux[2], (uint32_t)L.flags[4] & 0xffffu, L.st[0], L.st[1], &gx, &gy); /* create_close_target around the robot's xy */
+            else if (c.flag_manual) { /* goals.pop() (:116): the last goal of the pending list */
+                const int top = L.flags[4] & 0xffff;
+                gx = L.items[HRL_FLAG_PENDING_OFF + 2 * top]; gy = L.items[HRL_FLAG_PENDING_OFF + 1 + 2 * top];
+            } else flag_goal(c, (uint32_t)L.aux[2], (uint32_t)L.flags[4] & 0xffffu, &gx, &gy); /* the shared list's next goal */
+            if (c.flag_mtd > 0.f || c.flag_manual) { L.items[0] = gx; L.items[1] = gy; }
+            if (c.flag_path_on) flag_set_target_state(L, gx, gy, L.st[0], L.st[1]);
         }
         if (lane >= 4 && lane < 8) {
             const int k = lane - 4;
@@ -2447,7 +2519,13 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
     });
     const int done_u = x.uniform(L.flags[1]);
     if constexpr (KIND == 5) { /* ant_flagrun_env.py:110-118: the returned state is calc_state() w.r.t. the NEW goal */
-        if (x.uniform(L.flags[3])) compute_obs<KIND>(x, c, env, true);
+        const int retarget_u = x.uniform(L.flags[3]);
+        if (retarget_u) compute_obs<KIND>(x, c, env, true);
+        if (b.goal) /* `info['target'] = self.goal` of the steps that switched goals (:191,199): the goal this step's state looks at (phase_calc_state) */
+            x.each([&](int lane) {
+                if (lane < HRL_GOAL_STRIDE)
+                    b.goal[(size_t)eo * HRL_GOAL_STRIDE + lane] = lane == 0 ? L.red[4] : (lane == 1 ? L.red[5] : (lane == 2 ? (retarget_u ? 1.f : 0.f) : (float)((L.aux[3] >> 16) & 0x7fff)));
+            });
     }
     if (done_u && b.final_obs) /* the terminal observation (ant_gather_env.py:96,118-119): a reset below replaces L.obs by the next episode's first */
         x.each([&](int lane) {
@@ -2471,6 +2549,17 @@ HRL_DEV void step_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
         case 3: step_entry<3>(x, b, c, e); break;
         case 4: step_entry<4>(x, b, c, e); break;
         default: step_entry<5>(x, b, c, e); break;
+    }
+}
+template <class X>
+HRL_DEV void observe_dispatch(X &x, const DevBufs &b, const DevCfg &c, int e) {
+    switch (c.kind) {
+        case 0: observe_entry<0>(x, b, c, e); break;
+        case 1: observe_entry<1>(x, b, c, e); break;
+        case 2: observe_entry<2>(x, b, c, e); break;
+        case 3: observe_entry<3>(x, b, c, e); break;
+        case 4: observe_entry<4>(x, b, c, e); break;
+        default: observe_entry<5>(x, b, c, e); break;
     }
 }
 template <class X>

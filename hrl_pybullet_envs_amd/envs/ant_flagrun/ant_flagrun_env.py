@@ -8,10 +8,16 @@ from ..base import BatchedGymEnv
 
 
 class AntFlagrunBulletEnv(BatchedGymEnv):
-    ant_env_rew_weight = 1   # ant_flagrun_env.py:157-160
+    """Class-level reward weights, as in the reference (ant_flagrun_env.py:157-160; `step` reads them off the CLASS, :169-186):
+        r = ant_env_rew_weight * r_upstream + path_rew_weight * path_rew - dist_rew_weight * walk_target_dist (+ goal_reach_rew per goal reached).
+    Set them on the class before constructing an env -- `AntFlagrunBulletEnv.path_rew_weight = 0.5` -- : the constructor hands the values of
+    that moment to the kernel (hrl_config.flag_*_rew_weight, flag_goal_reach_rew); `env.set_reward_weights(...)` changes them on a live env
+    (the simulation carries over)."""
+    ant_env_rew_weight = 1
     path_rew_weight = 0
     dist_rew_weight = 0
     goal_reach_rew = 5000
+    _goal_info = True
 
     def __init__(self, size=10, tolerance=0.5, max_targets=100, max_target_dist=0, timeout=200, enclosed=True,
                  use_sensor=False, sensor_bins=8, sensor_span=np.pi, sensor_range=4,
@@ -21,12 +27,15 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
             'cannot have both max_targets and max_target_dist set at the same time'  # ant_flagrun_env.py:17-18
         cfg = _lib.default_config(K.HRL_ANT_FLAGRUN, flag_size=float(size), tol=float(tolerance), flag_max_targets=int(max_targets),
                                   flag_manual_goals=int(bool(manual_goal_creation)),
-                                  flag_goal_capacity=int(goal_capacity),  # longest `env.goals` list of a manual env (1..63; 15 fits the default record)
+                                  flag_goal_capacity=int(goal_capacity),  # longest `env.goals` list of a manual env (1..61)
                                   flag_max_target_dist=float(max_target_dist),
                                   flag_timeout=int(timeout), flag_enclosed=int(bool(enclosed)), use_sensor=int(bool(use_sensor)),
                                   n_bins=int(sensor_bins), sensor_span=float(sensor_span), sensor_range=float(sensor_range),
                                   flag_switch_on_collision=int(bool(switch_flag_on_collision)),
-                                  world_size=(float(size) + 2, float(size) + 2))
+                                  world_size=(float(size) + 2, float(size) + 2),
+                                  # the class attributes as they are NOW (the reference reads AntFlagrunBulletEnv.<name> in step, :169-186)
+                                  flag_ant_env_rew_weight=float(type(self).ant_env_rew_weight), flag_path_rew_weight=float(type(self).path_rew_weight),
+                                  flag_dist_rew_weight=float(type(self).dist_rew_weight), flag_goal_reach_rew=float(type(self).goal_reach_rew))
         if enclosed or use_sensor:  # ant_flagrun_env.py:59-64: the arena's floor and last wall join upstream's parts dict
             cfg.centroid_n_static = 2
             cfg.centroid_static_sum[0] = -(float(size) + 2) / 2
@@ -39,6 +48,41 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         self.switch_flag_on_collision = switch_flag_on_collision
         self.use_sensor, self.n_bins, self.sensor_span, self.sensor_range, self.debug = use_sensor, sensor_bins, sensor_span, sensor_range, debug
         self._finish_init(cfg, num_envs, device, seed)
+
+    def set_reward_weights(self, ant_env_rew_weight=None, path_rew_weight=None, dist_rew_weight=None, goal_reach_rew=None):
+        """Changes the reward weights of THIS env (None: keep).  They are constants of the library handle: a running env gets a new handle with
+        the same buffers' contents.  Switching a path reward on for an env built without one (shared goal list, no record of where the robot stood
+        when it got its goal) starts the path bookkeeping at the next goal / reset."""
+        c = self._cfg
+        new = [c.flag_ant_env_rew_weight if ant_env_rew_weight is None else float(ant_env_rew_weight),
+               c.flag_path_rew_weight if path_rew_weight is None else float(path_rew_weight),
+               c.flag_dist_rew_weight if dist_rew_weight is None else float(dist_rew_weight),
+               c.flag_goal_reach_rew if goal_reach_rew is None else float(goal_reach_rew)]
+        sd = self._env.state_dict() if self._env is not None else None
+        c.flag_ant_env_rew_weight, c.flag_path_rew_weight, c.flag_dist_rew_weight, c.flag_goal_reach_rew = new
+        if sd is not None:
+            self._env.close()
+            self._env = None
+            self._backend().load_state_dict(sd, strict=False)
+
+    reward_weights = property(lambda self: dict(ant_env_rew_weight=self._cfg.flag_ant_env_rew_weight, path_rew_weight=self._cfg.flag_path_rew_weight,
+                                                dist_rew_weight=self._cfg.flag_dist_rew_weight, goal_reach_rew=self._cfg.flag_goal_reach_rew))
+
+    def _host_state(self):
+        return {'create_calls': self._create_calls}
+
+    def _load_host_state(self, host):
+        self._create_calls = int(host.get('create_calls', self._create_calls))
+
+    @property
+    def _goal_start_pos(self):  # ant_flagrun_env.py:49,102
+        p = self._backend().items[:, K.HRL_FLAG_START_OFF:K.HRL_FLAG_START_OFF + 2]
+        return p[0].double().cpu().numpy() if self.num_envs == 1 else p
+
+    @property
+    def _sq_dist_goal(self):  # ant_flagrun_env.py:48,101
+        d = self._backend().items[:, K.HRL_FLAG_SQDIST_OFF]
+        return float(d[0]) if self.num_envs == 1 else d
 
     @property
     def stadium_scene(self):
@@ -66,7 +110,7 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
             return [] if self.num_envs == 1 else (torch.zeros(self.num_envs, 0, 2, device=env.device), torch.zeros(self.num_envs, dtype=torch.int32, device=env.device))
         cur = (env.aux[:, 3] & 0xffff)
         if self._listed():
-            pend = env.items[:, 2:2 + 2 * self.goal_capacity].reshape(self.num_envs, self.goal_capacity, 2)
+            pend = env.items[:, K.HRL_FLAG_PENDING_OFF:K.HRL_FLAG_PENDING_OFF + 2 * self.goal_capacity].reshape(self.num_envs, self.goal_capacity, 2)
             if self.num_envs == 1:
                 return [tuple(g) for g in pend[0, :int(cur[0])].tolist()]
             return pend, cur
@@ -85,7 +129,7 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
     @goals.setter
     def goals(self, goals):
         """`env.goals = [...]` of a manual_goal_creation env: stores the list (one for every env: [n, 2]; or [N, n, 2]), at
-        most `goal_capacity` goals (constructor argument of this package, default 15, up to 63); nothing else changes until
+        most `goal_capacity` goals (constructor argument of this package, default 15, up to 61); nothing else changes until
         next_target() / a goal is reached."""
         import torch
         if not self._listed():
@@ -99,8 +143,8 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         if g.shape[0] != self.num_envs or g.shape[2] != 2 or n > self.goal_capacity:
             raise ValueError(f'goals must be [n <= goal_capacity = {self.goal_capacity}, 2] or [num_envs, n, 2] (build the env with a larger '
                              f'goal_capacity, up to {K.HRL_MAX_GOALS})')
-        env.items[:, 2:] = 0
-        env.items[:, 2:2 + 2 * n] = g.reshape(self.num_envs, 2 * n)
+        env.items[:, K.HRL_FLAG_PENDING_OFF:] = 0
+        env.items[:, K.HRL_FLAG_PENDING_OFF:K.HRL_FLAG_PENDING_OFF + 2 * n] = g.reshape(self.num_envs, 2 * n)
         env.aux[:, 3] = (env.aux[:, 3] & ~0xffff) | n
 
     def next_target(self, mask=None):

@@ -115,12 +115,22 @@ class BatchedGymEnv:
         return obs
 
     def state_dict(self):
-        """Checkpoint of the simulation (vec_env.BatchedEnv.state_dict): torch.save()-able, resumes bit for bit."""
-        return self._backend().state_dict()
+        """Checkpoint of the simulation (vec_env.BatchedEnv.state_dict): torch.save()-able, resumes bit for bit.  `host` holds what the
+        Python object itself carries from call to call (AntFlagrun: how many goal lists create_targets() has drawn)."""
+        sd = self._backend().state_dict()
+        sd['host'] = self._host_state()
+        return sd
 
     def load_state_dict(self, sd, strict=True):
         obs = self._backend().load_state_dict(sd, strict)
+        self._load_host_state(sd.get('host', {}))
         return obs[0].double().cpu().numpy() if self.num_envs == 1 else obs
+
+    def _host_state(self):
+        return {}
+
+    def _load_host_state(self, host):
+        pass
 
     def step(self, a):
         env = self._backend()
@@ -132,6 +142,10 @@ class BatchedGymEnv:
             out = {'food_rew': float(info[0, 0]), 'dead_rew': float(info[0, 1])} if self._gather_info else {}
             if d and int(info[0, 3]) >= self.max_episode_steps > 0:  # info[3] = length of the episode that just ended: the step limit was hit;
                 out['TimeLimit.truncated'] = bool(env.host_final_obs()[1][0])  # gym.wrappers.TimeLimit: `not done` (the kernel's flag)
+            if self._goal_info:  # ant_flagrun_env.py:191,199: `i['target'] = self.goal` on the steps in which next_target() ran
+                g = env.host_goal()[0]
+                if g[2] != 0:
+                    out['target'] = (float(g[0]), float(g[1]))
             return obs[0].astype(np.float64), float(rew[0]), d, out
         return env.step(a)
 
@@ -153,6 +167,7 @@ class BatchedGymEnv:
         return draw_env(self._cfg, st, items, size)
 
     _gather_info = False
+    _goal_info = False    # AntFlagrun: info['target']
     _centroid_obs = True  # kinds whose walk target distance is measured from upstream's parts centroid
 
     def _walk_target(self):

@@ -40,6 +40,8 @@ class BatchedEnv:
         self._out = {'obs': torch.zeros(n, self.obs_dim, dtype=f32, device=dev), 'reward': torch.zeros(n, dtype=f32, device=dev),
                      'done': torch.zeros(n, dtype=torch.uint8, device=dev), 'info': torch.zeros(n, K.HRL_INFO_STRIDE, dtype=f32, device=dev),
                      'final_obs': torch.zeros(n, self.obs_dim, dtype=f32, device=dev), 'truncated': torch.zeros(n, dtype=torch.uint8, device=dev)}
+        if cfg.env_kind == K.HRL_ANT_FLAGRUN:  # the goal being chased and whether this step switched to it: info['target'] (ant_flagrun_env.py:191,199)
+            self._out['goal'] = torch.zeros(n, K.HRL_GOAL_STRIDE, dtype=f32, device=dev)
         self._host = None         # pinned host buffers of step_host(), made on first use
         self._host_fresh = False  # the last step wrote its outputs to the host buffers: the device tensors are stale until read
         self._bind()
@@ -56,15 +58,19 @@ class BatchedEnv:
         # kinds keep nothing in it, and the library takes NULL for it (include/hrl_envs.h): 128 B per env and step less to read and to write back
         c = self.cfg
         self._uses_items = c.env_kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) or \
-            (c.env_kind == K.HRL_ANT_FLAGRUN and (bool(c.flag_manual_goals) or c.flag_max_target_dist > 0))
-        self._bufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr() if self._uses_items else None, self.aux.data_ptr(), None,
-                                   o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
-                                   o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr())
+            (c.env_kind == K.HRL_ANT_FLAGRUN and (bool(c.flag_manual_goals) or c.flag_max_target_dist > 0 or c.flag_path_rew_weight != 0))
+        goal = o['goal'].data_ptr() if 'goal' in o else None
+        if 'goal' in o:  # `target`: the goal after the step; `retargeted`: the rows whose step switched to it (the reference sets info['target'] on those steps only)
+            self._info_views['target'] = o['goal'][:, 0:2]
+            self._info_views['retargeted'] = o['goal'][:, 2]
+        self._bufs = K.make_buffers(self.state.data_ptr(), self.items.data_ptr() if self._uses_items else None, self.aux.data_ptr(), None,
+                                    o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
+                                    o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr(), goal)
         self._bufs_ref = C.byref(self._bufs)
         # set_goals always hands the items record over: an env that has no use for it is refused by the library with the reason (not a manual env)
-        self._bufs_with_items = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), None,
-                                              o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
-                                              o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr())
+        self._bufs_with_items = K.make_buffers(self.state.data_ptr(), self.items.data_ptr(), self.aux.data_ptr(), None,
+                                               o['obs'].data_ptr(), o['reward'].data_ptr(), o['done'].data_ptr(),
+                                               o['info'].data_ptr(), o['final_obs'].data_ptr(), o['truncated'].data_ptr(), goal)
 
     def _device_out(self, name):
         """Output tensor `name` on the device.  step_host() leaves the step's outputs in pinned host memory only (that is its point: one
@@ -81,6 +87,8 @@ class BatchedEnv:
                 self._out['final_obs'][d.to(self.device)] = h['final_obs'][d].to(self.device)
                 self._host_ended[:] = False
             self._out['truncated'].copy_(h['trunc'], non_blocking=True)
+            if 'goal' in h:
+                self._out['goal'].copy_(h['goal'], non_blocking=True)
         return self._out[name]
 
     def _before_device_launch(self):
@@ -95,6 +103,16 @@ class BatchedEnv:
     info = property(lambda self: self._device_out('info'))
     final_obs = property(lambda self: self._device_out('final_obs'))
     truncated = property(lambda self: self._device_out('truncated'))
+    goal = property(lambda self: self._device_out('goal'))  # AntFlagrun only: [N, 4] = goal x, y | switched to it in the last step | steps since the goal changed
+
+    def count_solver_rows(self, on=True):
+        """Diagnostic: from now on every step ADDS to `self.solver_rows` [N] (int32, zeroed here) the constraint rows each env's solver held
+        -- joint limits + 3 per contact over the step's substeps (hrl_buffers.solver_rows).  What a launch costs depends on it."""
+        self.solver_rows = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device) if on else None
+        p = self.solver_rows.data_ptr() if on else None
+        self._bufs.solver_rows = p
+        self._bufs_with_items.solver_rows = p
+        return self.solver_rows
 
     def close(self):
         if getattr(self, '_h', None):
@@ -157,12 +175,14 @@ class BatchedEnv:
                  'info': torch.zeros(self.num_envs, K.HRL_INFO_STRIDE, dtype=f32).pin_memory(),
                  'final_obs': torch.zeros(self.num_envs, self.obs_dim, dtype=f32).pin_memory(),
                  'trunc': torch.zeros(self.num_envs, dtype=torch.uint8).pin_memory()}
+            if 'goal' in self._out:
+                t['goal'] = torch.zeros(self.num_envs, K.HRL_GOAL_STRIDE, dtype=f32).pin_memory()
             self._host = t
             self._host_np = {k: v.numpy() for k, v in t.items()}
             self._host_ended = np.zeros(self.num_envs, bool)  # envs whose episode ended in a host step since the device tensors were refreshed
-            self._hbufs = K.hrl_buffers(self.state.data_ptr(), self.items.data_ptr() if self._uses_items else None, self.aux.data_ptr(), t['act'].data_ptr(),
-                                        t['obs'].data_ptr(), t['rew'].data_ptr(), t['done'].data_ptr(), t['info'].data_ptr(),
-                                        t['final_obs'].data_ptr(), t['trunc'].data_ptr())
+            self._hbufs = K.make_buffers(self.state.data_ptr(), self.items.data_ptr() if self._uses_items else None, self.aux.data_ptr(), t['act'].data_ptr(),
+                                         t['obs'].data_ptr(), t['rew'].data_ptr(), t['done'].data_ptr(), t['info'].data_ptr(),
+                                         t['final_obs'].data_ptr(), t['trunc'].data_ptr(), t['goal'].data_ptr() if 'goal' in t else None)
         h = self._host_np
         h['act'][...] = actions
         with torch.cuda.device(self.device):
@@ -171,6 +191,10 @@ class BatchedEnv:
         self._host_fresh = True
         self._host_ended |= h['done'] != 0
         return h['obs'], h['rew'], h['done'], h['info']
+
+    def host_goal(self):
+        """AntFlagrun: [N, 4] numpy view of the last step_host(): goal x, y | 1 if that step switched to it | steps since the goal changed."""
+        return self._host_np['goal']
 
     def host_final_obs(self):
         """(final_obs [N, obs_dim], truncated [N] uint8) numpy views of the last step_host(): valid where its `done` was set."""
@@ -204,7 +228,7 @@ class BatchedEnv:
     # random streams) -- plus the config (seed, env_id_offset, constructor arguments).  torch.save()-able; resuming continues bit for bit.
     def state_dict(self):
         self._before_device_launch()
-        out = {k: getattr(self, k).detach().cpu().clone() for k in ('state', 'items', 'aux', 'obs', 'reward', 'done', 'info', 'final_obs', 'truncated')}
+        out = {k: getattr(self, k).detach().cpu().clone() for k in ('state', 'items', 'aux', 'obs', 'reward', 'done', 'info', 'final_obs', 'truncated') + (('goal',) if 'goal' in self._out else ())}
         out['config'] = bytes(self.cfg)
         out['abi_version'] = K.HRL_ABI_VERSION
         return out
@@ -222,8 +246,8 @@ class BatchedEnv:
         self._before_device_launch()
         for k in ('state', 'items', 'aux'):
             getattr(self, k).copy_(sd[k])
-        for k in ('obs', 'reward', 'done', 'info', 'final_obs', 'truncated'):
-            if k in sd and tuple(sd[k].shape) == tuple(self._out[k].shape):
+        for k in ('obs', 'reward', 'done', 'info', 'final_obs', 'truncated', 'goal'):
+            if k in sd and k in self._out and tuple(sd[k].shape) == tuple(self._out[k].shape):
                 self._out[k].copy_(sd[k])
         return self.obs
 
@@ -243,9 +267,25 @@ class BatchedEnv:
             _lib.check(_lib.lib().hrl_get_state(self._h, C.byref(self._bufs), qpos.data_ptr(), qvel.data_ptr(), self._stream()))
         return qpos, qvel
 
-    def set_state(self, qpos, qvel):
+    def set_state(self, qpos, qvel, observe=True):
+        """Teleport: writes qpos [N, 15] / qvel [N, 14] into the state records and -- as the reference does after
+        `resetBasePositionAndOrientation` (ant_maze_bullet_env.py:117-121: calc_state(), _get_obs()) -- recomputes the observations of the new
+        state (hrl_observe).  Returns them."""
         qpos = qpos.to(device=self.device, dtype=torch.float32).contiguous()
         qvel = qvel.to(device=self.device, dtype=torch.float32).contiguous()
+        self._before_device_launch()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hrl_set_state(self._h, C.byref(self._bufs), qpos.data_ptr(), qvel.data_ptr(), self._stream()))
+            if observe:
+                _lib.check(_lib.lib().hrl_observe(self._h, C.byref(self._bufs), None, self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
+        return self.obs
+
+    def observe(self, mask=None):
+        """The observations of the state / items / aux tensors AS THEY ARE (after writing into them: a teleport, moved items, another target):
+        hrl_observe.  Nothing else changes.  Rows with mask == 0 keep their observation."""
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._before_device_launch()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hrl_observe(self._h, C.byref(self._bufs), None if m is None else m.data_ptr(), self._stream()))
+        return self.obs

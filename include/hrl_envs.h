@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HRL_ABI_VERSION 6
+#define HRL_ABI_VERSION 7
 
 /* env kinds */
 #define HRL_ANT_FLAT 0     /* AntMjEnv: flat ground, obs 29 (envs/MjAnt.py:31-97)                        */
@@ -54,7 +54,14 @@ extern "C" {
 #define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
 #define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
 #define HRL_MAX_TARGETS 64  /* maze kinds: `targets` of the constructor (ant_maze_bullet_env.py:23) */
-#define HRL_MAX_GOALS 63    /* flagrun manual goals (flag_goal_capacity): items[0..1] current, items[2..] the pending list in list order */
+#define HRL_MAX_GOALS 61    /* flagrun manual goals (flag_goal_capacity) */
+/* flagrun items record (the modes that keep one): current goal | where the robot stood when it got that goal | squared distance to it then
+ * (ant_flagrun_env.py:100-103 `_goal_start_pos`, `_sq_dist_goal`: the path reward of :174-176) | spare | the pending list in list order */
+#define HRL_FLAG_GOAL_OFF 0
+#define HRL_FLAG_START_OFF 2
+#define HRL_FLAG_SQDIST_OFF 4
+#define HRL_FLAG_PENDING_OFF 6
+#define HRL_GOAL_STRIDE 4   /* optional flagrun output `goal`: current goal x, y | 1 if this step switched to it (info['target']) | steps since the goal changed */
 
 /* status codes */
 #define HRL_OK 0
@@ -95,6 +102,19 @@ typedef struct hrl_model {
      * articulated-body phases and the contact phase of the four envs lane-packed on one wave each.  1: one 64-thread workgroup per env,
      * every phase on the env's own wave (the measurement reference of DESIGN.md 4; same arithmetic, bit for bit). */
     int32_t step_group;
+    /* ---- ABI v7: model choices nothing in the reference tree decides (the arithmetic lives in the absent pybullet wheel), as parameters, so
+     * that fitting recorded pybullet steps (tools/make_pybullet_golden.py) is a config change.  The defaults are the build's specification
+     *  and cost nothing: each feature is skipped by a wave-uniform test when its parameter is at the default. ---- */
+    /* base damping (Bullet's multibodies have a small built-in linear / angular damping of the base): per substep the torso's
+     * linear / angular velocity of the unconstrained update is scaled by max(0, 1 - timestep * damping).  Default 0 (none). */
+    float linear_damping, angular_damping;
+    /* restitution of a contact whose bodies approach faster than restitution_threshold along the normal: the normal row then asks for a
+     * separating velocity of restitution * (approach speed) (Bullet combines the two bodies' restitutions by their product, SURVEY A.3:
+     * ground / walls 0.5 (sizeable_enclosed_scene.py:60) x robot 0 = 0).  Default 0: every contact is plastic. */
+    float restitution, restitution_threshold; /* 0, 0.2 m/s */
+    /* contacts kept per substep, 1..12 (candidates beyond it are dropped in candidate order: ground, walls, boxes, cubes, capsule pairs).
+     * Default 12, the most the solver's 44 rows hold. */
+    int32_t max_contacts;
 } hrl_model;
 
 typedef struct hrl_config {
@@ -135,20 +155,30 @@ typedef struct hrl_config {
     float flag_max_target_dist;
     /* manual_goal_creation (ant_flagrun_env.py:27,150-153): reset neither draws goals nor changes the current one; goals
      * come from outside: hrl_set_goals() (`env.goals = [...]; env.next_target()`) and hrl_next_target().  The current goal
-     * lives in items[0..1], the pending list behind it, so `items` must be provided.  As in the reference, next_target()
+     * lives in items[0..1], the pending list from items[HRL_FLAG_PENDING_OFF] on, so `items` must be provided.  As in the reference, next_target()
      * pops the list when flag_max_targets > 0 and draws a goal near the robot (ignoring the list) when flag_max_targets < 1
      * (flag_max_target_dist > 0), :113-116; the constructor's either-or rule (:17-18) holds for manual envs too. */
     int32_t flag_manual_goals;
-    /* manual_goal_creation: the longest list `env.goals = [...]` / hrl_set_goals() may hold, 1..HRL_MAX_GOALS (default 15: the
-     * pending list then fits the default 32-float items record; a larger capacity lengthens the record, hrl_items_stride()). */
+    /* manual_goal_creation: the longest list `env.goals = [...]` / hrl_set_goals() may hold, 1..HRL_MAX_GOALS (default 15; the record is
+     * hrl_items_stride() floats long). */
     int32_t flag_goal_capacity;
+    /* ABI v7: the class-level reward weights of AntFlagrunBulletEnv (ant_flagrun_env.py:157-160), read by step() as
+     * r = ant_env_rew_weight * r_upstream + path_rew_weight * path_rew - dist_rew_weight * walk_target_dist (:169-178), + goal_reach_rew once per
+     * goal (:184-186).  path_rew (:174-176) needs where the robot stood and how far the goal was when the goal was set (:100-103): kept in the
+     * items record (HRL_FLAG_START_OFF, HRL_FLAG_SQDIST_OFF), so a config with path_rew_weight != 0 must be given `items`. */
+    float flag_ant_env_rew_weight, flag_path_rew_weight, flag_dist_rew_weight, flag_goal_reach_rew; /* 1, 0, 0, 5000 */
     hrl_model model;
 } hrl_config;
 
-/* Caller-owned buffers of one shard.  Unused pointers may be NULL (items for non-gather kinds). */
+/* Caller-owned buffers of one shard.  Unused pointers may be NULL (items for non-gather kinds).
+ * INITIALISE IT: `hrl_buffers b; hrl_buffers_init(&b);` (or `hrl_buffers b = {sizeof b};`), then assign the pointers you have.  The library
+ * reads the optional output pointers of its own ABI version only within `struct_size` bytes and treats the rest as NULL, and refuses a record
+ * whose struct_size is not that of a known layout (HRL_ERR_BAD_ARG: what a record left uninitialised on the stack almost surely holds) --
+ * a host rebuilt against a newer header never hands the kernels stack garbage as an output address. */
 typedef struct hrl_buffers {
+    uint64_t struct_size; /* sizeof(hrl_buffers) of the header the CALLER was compiled against (hrl_buffers_init sets it) */
     float *state;         /* [N][HRL_STATE_STRIDE]  in/out */
-    float *items;         /* [N][hrl_items_stride()] in/out (gather kinds; flagrun with max_target_dist or manual goals); the other kinds keep nothing in it: pass NULL and the record is neither read nor written */
+    float *items;         /* [N][hrl_items_stride()] in/out (gather kinds; flagrun with max_target_dist, manual goals or a path reward); the other kinds keep nothing in it: pass NULL and the record is neither read nor written */
     int32_t *aux;         /* [N][HRL_AUX_STRIDE]    in/out */
     const float *actions; /* [N][act_dim]           in  (step only) */
     float *obs;           /* [N][obs_dim]           out */
@@ -163,7 +193,17 @@ typedef struct hrl_buffers {
     /* gym TimeLimit (`max_episode_steps=2000`, hrl_pybullet_envs/__init__.py:15): 1 when the episode was ended by the step limit ALONE
      * (gym.wrappers.TimeLimit: info['TimeLimit.truncated'] = not done), else 0; written for every env in every step.  May be NULL. */
     uint8_t *truncated;   /* [N]                    out (step only, optional) */
+    /* AntFlagrun (ABI v7): the goal being chased after this step, and whether this step switched to it -- the reference's
+     * `info['target'] = self.goal`, set on the steps in which next_target() ran (ant_flagrun_env.py:191,199):
+     * goal[i] = {x, y, 1.0 if retargeted in this step else 0.0, steps_since_goal_change}.  Written before an auto-reset.  May be NULL; the other
+     * kinds never write it. */
+    float *goal;          /* [N][HRL_GOAL_STRIDE]   out (step only, optional) */
+    /* Diagnostic (ABI v7): hrl_step ADDS to solver_rows[i] the number of constraint rows env i's solver held in this step -- joint limits + 3 per
+     * contact, summed over the step's substeps.  What a launch costs depends on it (the sweeps are serial in the rows), so a measurement reports
+     * it next to the time (bench.py: solver_rows_per_env_step).  The caller zeroes it when it wants to.  May be NULL. */
+    int32_t *solver_rows; /* [N]                    in/out (step only, optional) */
 } hrl_buffers;
+#define HRL_BUFFERS_SIZE_V7_BASE ((uint64_t)(sizeof(uint64_t) + 8 * sizeof(void *))) /* through `info`: the least a v7 caller hands over */
 
 typedef struct hrl_handle hrl_handle;
 
@@ -175,8 +215,9 @@ int hrl_default_config(int32_t env_kind, hrl_config *cfg);
  * ant_maze_bullet_env.py:54-57, MjAnt.py:15, point_bot.py:15-16). */
 int hrl_obs_dim(const hrl_config *cfg);
 int hrl_act_dim(const hrl_config *cfg);
-/* floats per env of the `items` buffer: HRL_ITEMS_STRIDE (32) for up to 16 items / 15 manual goals -- every default config --, else the
- * next multiple of 32 that holds 2 * (n_food + n_poison) (gather_scene.py:33) or 2 * (1 + flag_goal_capacity) floats; at most 128. */
+/* floats per env of the `items` buffer: HRL_ITEMS_STRIDE (32) for up to 16 items -- every default config --, else the next multiple of 32 that
+ * holds 2 * (n_food + n_poison) floats (gather_scene.py:33); a manual_goal_creation flagrun env: HRL_FLAG_PENDING_OFF + 2 * flag_goal_capacity
+ * floats rounded up likewise (64 at the default capacity of 15); at most 128. */
 int hrl_items_stride(const hrl_config *cfg);
 
 /* Replaces env construction (gym.make / Env.__init__ + first BulletClient): validates and copies cfg. */
@@ -192,6 +233,16 @@ int hrl_reset(hrl_handle *h, const hrl_buffers *bufs, const uint8_t *mask, void 
  * robot.calc_state + task logic (ant_gather_env.py:76-119, gather_base.py:74-109,
  * ant_maze_bullet_env.py:77-97, MjAnt.py:36-97).  One call steps all N envs once. */
 int hrl_step(hrl_handle *h, const hrl_buffers *bufs, void *stream);
+
+/* Zeroes `b` and sets b->struct_size. */
+int hrl_buffers_init(hrl_buffers *b);
+
+/* The observation of the state AS IT IS in bufs (state, items, aux) into bufs->obs, without stepping: what the reference does after a
+ * teleport -- `resetBasePositionAndOrientation(...)`, `robot.calc_state()`, `_get_obs()` (ant_maze_bullet_env.py:117-121; upstream
+ * calc_state + ant_gather_env.py:121-125 get_food_obs, sizeable_enclosed_scene.py:63-97 sense_walls, point_bot.py:48-67).  Nothing but `obs`
+ * is written (no pickups, no counters, no reward; feet-contact entries 0 as after a reset).  Envs with mask[i] == 0 keep their row
+ * (mask == NULL: all).  hrl_set_state() + hrl_observe() is how identical-state parity tests replay the reference's fixtures on the device. */
+int hrl_observe(hrl_handle *h, const hrl_buffers *bufs, const uint8_t *mask, void *stream);
 
 /* State access for identical-state parity tests (replaces pybullet get/resetBasePositionAndOrientation,
  * get/resetJointState): copies between the packed state record and split qpos[N][15] / qvel[N][14]. */
@@ -212,7 +263,7 @@ int hrl_set_goals(hrl_handle *h, const hrl_buffers *bufs, const float *goals_xy,
  * _rewarded, refreshes bufs->obs.
  * ok (device, [N], may be NULL): 1, or 0 for an env whose list is empty -- the reference raises IndexError there; such an
  * env is left unchanged.  (The pending list itself is plain data in the caller's `items` / `aux` tensors: `env.goals = [...]`
- * without next_target() is items[2 + 2k..] = goals[k], aux[3] low 16 bits = len(goals) <= flag_goal_capacity.) */
+ * without next_target() is items[HRL_FLAG_PENDING_OFF + 2k..] = goals[k], aux[3] low 16 bits = len(goals) <= flag_goal_capacity.) */
 int hrl_next_target(hrl_handle *h, const hrl_buffers *bufs, const uint8_t *mask, uint8_t *ok, void *stream);
 
 /* Last error text of the calling thread ("" if none). */

@@ -527,16 +527,30 @@ int FN(orc_flag_create_close_target)(REAL size, REAL tol, REAL mtd, const REAL *
     return -1;
 }
 
-/* ant_flagrun_env.py:162-204 `step` after `super().step(a)`: goal reward, retargeting, timeout, running out of goals.
+/* ant_flagrun_env.py:174-176 `path_rew`: np.dot(body_real_xyz[:2] - _goal_start_pos, goal - _goal_start_pos) / _sq_dist_goal */
+REAL FN(orc_flag_path_rew)(const REAL *robot_xy, const REAL *goal, const REAL *goal_start, REAL sq_dist_goal) {
+    return ((robot_xy[0] - goal_start[0]) * (goal[0] - goal_start[0]) + (robot_xy[1] - goal_start[1]) * (goal[1] - goal_start[1])) / sq_dist_goal;
+}
+/* ant_flagrun_env.py:98-103 `set_target`: `_goal_start_pos` = where the robot stands, `_sq_dist_goal` = np.linalg.norm(goal - pos) ** 2 (the
+ * norm squared, not the sum of squares); out3 = start x, start y, squared distance */
+void FN(orc_flag_set_target_state)(const REAL *goal, const REAL *robot_xy, REAL *out3) {
+    REAL dx = goal[0] - robot_xy[0], dy = goal[1] - robot_xy[1], nrm = RSQRT(dx * dx + dy * dy);
+    out3[0] = robot_xy[0]; out3[1] = robot_xy[1]; out3[2] = nrm * nrm;
+}
+/* ant_flagrun_env.py:162-204 `step` after `super().step(a)`: the class-level reward weights (:157-160, hrl_config.flag_*: r *= ant_env_rew_weight,
+ * += path_rew * path_rew_weight, += -walk_target_dist * dist_rew_weight; `with_path` = 0 leaves the path term out: envs that keep no
+ * `_goal_start_pos`), goal reward, retargeting, timeout, running out of goals.
  * io: steps (steps_since_goal_change), rewarded, goals_left.  *retarget = 1 when next_target() succeeded. */
-void FN(orc_flagrun_task)(const hrl_config *cfg, REAL inner_rew, int inner_done, REAL walk_target_dist, int *steps,
-                          int *rewarded, int *goals_left, REAL *rew, int *done, int *retarget) {
-    REAL r = inner_rew * 1; /* ant_env_rew_weight = 1; path_rew_weight = dist_rew_weight = 0 (:157-159) */
+void FN(orc_flagrun_task_w)(const hrl_config *cfg, REAL inner_rew, int inner_done, REAL walk_target_dist, int with_path, REAL path_rew, int *steps,
+                            int *rewarded, int *goals_left, REAL *rew, int *done, int *retarget) {
+    REAL r = inner_rew * R_(cfg->flag_ant_env_rew_weight); /* :169 */
     int d = inner_done;
     *retarget = 0;
     *steps += 1; /* :171 */
+    if (with_path) r = r + path_rew * R_(cfg->flag_path_rew_weight); /* :176 */
+    r = r + (-walk_target_dist) * R_(cfg->flag_dist_rew_weight);     /* :178 */
     if (walk_target_dist < R_(cfg->tol)) { /* :183 */
-        if (!*rewarded) { r += 5000; *rewarded = 1; } /* :184-186, goal_reach_rew :160 */
+        if (!*rewarded) { r += R_(cfg->flag_goal_reach_rew); *rewarded = 1; } /* :184-186, goal_reach_rew :160 */
         if (cfg->flag_switch_on_collision) {
             if (*goals_left > 0) { *goals_left -= 1; *rewarded = 0; *steps = 0; *retarget = 1; } /* next_target :110-118 */
             else d = 1; /* goals.pop() raises IndexError :193-194 */
@@ -547,6 +561,11 @@ void FN(orc_flagrun_task)(const hrl_config *cfg, REAL inner_rew, int inner_done,
         else d = 1;
     }
     *rew = r; *done = d;
+}
+/* the same without a path term (the golden fixtures of the default weights call this one) */
+void FN(orc_flagrun_task)(const hrl_config *cfg, REAL inner_rew, int inner_done, REAL walk_target_dist, int *steps,
+                          int *rewarded, int *goals_left, REAL *rew, int *done, int *retarget) {
+    FN(orc_flagrun_task_w)(cfg, inner_rew, inner_done, walk_target_dist, 0, 0, steps, rewarded, goals_left, rew, done, retarget);
 }
 
 /* =================================================================================================================
@@ -570,6 +589,9 @@ typedef struct FN(orc_consts) {
     REAL lo[NJ], hi[NJ];  /* joint ranges, assets/ant.xml:18-54                                          */
     REAL mu_self;         /* friction between two ant links = friction_robot^2 (Bullet combines by product)       */
     int iters, nsub, self_collision, item_collision;
+    int max_contacts, damping_on;   /* hrl_model.max_contacts; base damping switched on */
+    REAL damp_lin, damp_ang;        /* max(0, 1 - h * damping): factor on the torso's unconstrained linear / angular velocity per substep */
+    REAL restitution, rest_thr;     /* hrl_model.restitution / restitution_threshold */
 } FN(orc_consts);
 
 /* static collision world: ground plane + lateral half-spaces + axis-aligned boxes
@@ -609,6 +631,9 @@ void FN(orc_consts_init)(const hrl_model *M, FN(orc_consts) * K) {
     K->vmax = R_(M->max_joint_vel); K->limp_max = R_(M->limit_max_impulse); K->ground_z = R_(M->ground_z);
     K->iters = M->solver_iters; K->nsub = M->frame_skip;
     K->mu_self = R_(M->friction_robot * M->friction_robot); K->self_collision = M->self_collision; K->item_collision = M->item_collision;
+    K->max_contacts = M->max_contacts; K->damping_on = M->linear_damping != 0 || M->angular_damping != 0;
+    { REAL sl = R_(1) - K->h * R_(M->linear_damping), sa = R_(1) - K->h * R_(M->angular_damping); K->damp_lin = sl > 0 ? sl : 0; K->damp_ang = sa > 0 ? sa : 0; }
+    K->restitution = R_(M->restitution); K->rest_thr = R_(M->restitution_threshold);
     const double d2r = pi / 180.0;
     const double lo[NJ] = {-40, 30, -40, -100, -40, -100, -40, 30}, hi[NJ] = {40, 100, 40, -30, 40, -30, 40, 100};
     for (int j = 0; j < NJ; ++j) { K->lo[j] = R_(lo[j] * d2r); K->hi[j] = R_(hi[j] * d2r); }
@@ -1076,7 +1101,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
             if (dist < K->cdist) {
                 if (f == 0) ground_touch[s] = 1;
                 ++ncand;
-                if (nc < MAXC) {
+                if (nc < K->max_contacts) {
                     FN(orc_contact) *cc = &C[nc++];
                     cc->level = level; cc->leg = leg; cc->level2 = -1; cc->leg2 = 0; cc->sphere = s; cc->dist = dist; cc->surface = surface; cc->mu = K->mu;
                     for (int k = 0; k < 3; ++k) { cc->n[k] = n[k]; cc->r[k] = FMA_(-rad, n[k], c[k]); }
@@ -1102,7 +1127,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                         const int id = pair++;
                         if (!(d2n < thr * thr)) continue;
                         ++ncand;
-                        if (nc >= MAXC) continue;
+                        if (nc >= K->max_contacts) continue;
                         FN(orc_contact) *cc = &C[nc++];
                         const REAL len = RSQRT(d2n);
                         cc->level = a; cc->leg = i; cc->level2 = b; cc->leg2 = j; cc->sphere = -1; cc->surface = ORC_SURF_SELF + id; cc->mu = K->mu_self;
@@ -1130,6 +1155,10 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
     for (int k = 0; k < 3; ++k) { un[k] = FMA_(h, D.a0[k], u[k]); un[3 + k] = FMA_(h, D.a0[3 + k] + wxv[k], u[3 + k]); }
     for (int j = 0; j < NJ; ++j) un[6 + j] = FMA_(h, D.qdd[j], u[6 + j]);
     un[14] = un[15] = 0;
+    if (K->damping_on) for (int k = 0; k < 3; ++k) { un[k] = un[k] * K->damp_ang; un[3 + k] = un[3 + k] * K->damp_lin; } /* hrl_model.angular_damping / linear_damping */
+    REAL u16[16]; /* the velocity at the start of the substep, dof order: approach speeds of the restitution rows */
+    for (int k = 0; k < NDOF; ++k) u16[k] = u[k];
+    u16[14] = u16[15] = 0;
     /* (2) constraint rows: joint limits, contact normals, friction pairs */
     REAL J[MAXR][16], B[MAXR][16], bias[MAXR], hi[MAXR], lam[MAXR], mu_row[MAXR]; /* hi: bound of non-friction rows */
     int fr_normal[MAXR];
@@ -1176,6 +1205,11 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
         }
         if (which == 0) {
             bias[nr] = (C[c].dist > 0 ? C[c].dist : K->erp_c * C[c].dist) * K->inv_h;
+            if (K->restitution > 0) { /* hrl_model.restitution: approaching faster than the threshold -> ask for restitution * (approach speed) of separation */
+                REAL vn = J[nr][0] * u16[0];
+                for (int d = 1; d < 16; ++d) vn = FMA_(J[nr][d], u16[d], vn);
+                if (vn < -K->rest_thr) bias[nr] = FMA_(K->restitution, vn, bias[nr]);
+            }
             hi[nr] = R_(1e30); fr_normal[nr] = -1; mu_row[nr] = 0;
         } else { bias[nr] = 0; hi[nr] = 0; fr_normal[nr] = nl + c; mu_row[nr] = C[c].mu; }
         ++nr;
@@ -1202,6 +1236,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
     REAL un[6];
     for (int k = 0; k < 3; ++k) un[k] = u[k];
     un[3] = FMA_(h, force[0] / m, u[3]); un[4] = FMA_(h, force[1] / m, u[4]); un[5] = FMA_(h, force[2] / m - K->g, u[5]);
+    if (K->damping_on) for (int k = 0; k < 3; ++k) { un[k] = un[k] * K->damp_ang; un[3 + k] = un[3 + k] * K->damp_lin; }
     /* contacts: 8 corners vs ground, lateral planes and item cubes in surface-major order, then every cube's 8 corners vs the
      * player's oriented box -- the half that catches a cube under the middle of a face --, at most MAXC in all */
     REAL Jr[3 * MAXC][16], Br[3 * MAXC][16], bias[3 * MAXC], hic[3 * MAXC], lam[3 * MAXC], mu_row[3 * MAXC];
@@ -1229,7 +1264,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
             }
             if (dist < K->cdist) {
                 ++ncand;
-                if (nc < MAXC) {
+                if (nc < K->max_contacts) {
                     for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
                     cd[nc] = dist; csurf[nc] = surface; ++nc;
                 }
@@ -1253,7 +1288,7 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
             }
             if (dist < K->cdist) {
                 ++ncand;
-                if (nc < MAXC) {
+                if (nc < K->max_contacts) {
                     for (int k = 0; k < 3; ++k) { cr[nc][k] = c[k]; cn[nc][k] = n[k]; }
                     cd[nc] = dist; csurf[nc] = ORC_SURF_OF_ITEM(f); ++nc;
                 }
@@ -1269,6 +1304,12 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
         FN(v3cross)(Jr[nr], cr[c], d);
         for (int k = 0; k < 3; ++k) { Jr[nr][3 + k] = d[k]; Br[nr][k] = Jr[nr][k] / I; Br[nr][3 + k] = d[k] / m; }
         bias[nr] = which == 0 ? (cd[c] > 0 ? cd[c] : K->erp_c * cd[c]) * K->inv_h : R_(0);
+        if (which == 0 && K->restitution > 0) {
+            REAL vn = Jr[nr][0] * u[0];
+            for (int d = 1; d < 6; ++d) vn = FMA_(Jr[nr][d], u[d], vn);
+            vn = vn + 0; /* the joint slots of a free body hold exact zeros (the device's row product ends in this addition) */
+            if (vn < -K->rest_thr) bias[nr] = FMA_(K->restitution, vn, bias[nr]);
+        }
         hic[nr] = which == 0 ? R_(1e30) : R_(0);
         frn[nr] = which == 0 ? -1 : c; mu_row[nr] = which == 0 ? R_(0) : K->mu;
         ++nr;
@@ -1440,6 +1481,8 @@ void FN(orc_env_init)(const hrl_config *cfg, FN(orc_env) * E) {
     FN(orc_world_init)(cfg, &E->W);
 }
 
+/* the env keeps `_goal_start_pos` / `_sq_dist_goal` in its items record (HRL_FLAG_START_OFF, HRL_FLAG_SQDIST_OFF) */
+static int FN(flag_path_on)(const hrl_config *cfg) { return cfg->flag_manual_goals || cfg->flag_max_target_dist > 0 || cfg->flag_path_rew_weight != 0; }
 /* the goal a flagrun env is chasing: kept in items[0..1] (max_target_dist and manual modes) or the k-th of the shared list */
 static void FN(flag_current_goal)(const hrl_config *cfg, const REAL *items, const int32_t *aux, REAL *g) {
     if (cfg->flag_max_target_dist > 0 || cfg->flag_manual_goals) { g[0] = items[0]; g[1] = items[1]; }
@@ -1530,14 +1573,17 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
         for (int i = 0; i < cfg->n_food + cfg->n_poison; ++i) FN(respawn_item)(cfg, env, ep, 1, i, origin, items + 2 * i);
     }
     aux[0] = 0; aux[2] = (int32_t)(ep + 1); /* NB: the flagrun goal stream is keyed by the NEW episode index */
-    if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_manual_goals) { /* the walk target survives the reset (:149-152), pending goals do not */
-        for (int i = 0; i < orc_items_stride(cfg); ++i) items[i] = 0;
-        items[0] = prev_target[0]; items[1] = prev_target[1];
-    } else if (cfg->env_kind == HRL_ANT_FLAGRUN && cfg->flag_max_target_dist > 0) { /* reset -> next_target -> create_close_target (:153, :111-112) */
-        REAL g2[2];
-        for (int i = 0; i < orc_items_stride(cfg); ++i) items[i] = 0;
-        FN(flag_close_goal)(cfg, env, ep + 1, 1, st, g2);
-        items[0] = g2[0]; items[1] = g2[1];
+    if (cfg->env_kind == HRL_ANT_FLAGRUN && items && FN(flag_path_on)(cfg)) { /* an env of the shared goal list without a path reward keeps nothing in the record */
+        if (cfg->flag_manual_goals) { /* the walk target and the path-reward state survive the reset (:149-152), pending goals do not */
+            for (int i = HRL_FLAG_PENDING_OFF; i < orc_items_stride(cfg); ++i) items[i] = 0;
+            items[0] = prev_target[0]; items[1] = prev_target[1];
+        } else { /* reset -> next_target -> set_target(first goal of the new episode) at the start pose (:144-153): create_close_target (:111-112) or the shared list */
+            REAL g2[2];
+            for (int i = 0; i < orc_items_stride(cfg); ++i) items[i] = 0;
+            if (cfg->flag_max_target_dist > 0) { FN(flag_close_goal)(cfg, env, ep + 1, 1, st, g2); items[0] = g2[0]; items[1] = g2[1]; }
+            else FN(flag_goal)(cfg, ep + 1, 1, g2);
+            FN(orc_flag_set_target_state)(g2, st, items + HRL_FLAG_START_OFF);
+        }
     }
     REAL feet[4] = {0, 0, 0, 0}, wtd = 0, cen[2] = {0, 0};
     FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0, cen);
@@ -1551,10 +1597,10 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
 }
 
 /* `env.goals = [...]` of a manual_goal_creation flagrun env (ant_flagrun_env.py:45,96,150): the pending list, in list order,
- * behind the current goal in the items record (items[2 + 2k..] = goals[k]); its length in the low 16 bits of aux[3]. */
+ * behind the current goal and the path-reward state in the items record (items[HRL_FLAG_PENDING_OFF + 2k..] = goals[k]); its length in the low 16 bits of aux[3]. */
 void FN(orc_flag_goals_assign)(const hrl_config *cfg, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals) {
-    for (int k = 0; k < n_goals; ++k) { items[2 + 2 * k] = goals_xy[2 * k]; items[3 + 2 * k] = goals_xy[2 * k + 1]; }
-    for (int i = 2 + 2 * n_goals; i < orc_items_stride(cfg); ++i) items[i] = 0;
+    for (int k = 0; k < n_goals; ++k) { items[HRL_FLAG_PENDING_OFF + 2 * k] = goals_xy[2 * k]; items[HRL_FLAG_PENDING_OFF + 1 + 2 * k] = goals_xy[2 * k + 1]; }
+    for (int i = HRL_FLAG_PENDING_OFF + 2 * n_goals; i < orc_items_stride(cfg); ++i) items[i] = 0;
     aux[3] = (int32_t)(((uint32_t)n_goals & 0xffffu) | ((uint32_t)aux[3] & 0xffff0000u));
 }
 
@@ -1565,19 +1611,22 @@ void FN(orc_flag_goals_assign)(const hrl_config *cfg, REAL *items, int32_t *aux,
  * computed from).  Returns 1 on success. */
 int FN(orc_flag_next_target)(const hrl_config *cfg, int64_t env, const REAL *st, REAL *items, int32_t *aux) {
     uint32_t a3 = (uint32_t)aux[3], cur = a3 & 0xffffu;
+    REAL g2[2];
     if (cfg->flag_max_target_dist > 0) { /* max_targets < 1 (:17-18): the goal counter of the episode keys the draw */
-        REAL g2[2];
         cur = (cur + 1) & 0xffffu;
         FN(flag_close_goal)(cfg, env, (uint32_t)aux[2], cur, st, g2);
         items[0] = g2[0]; items[1] = g2[1];
     } else if (!cfg->flag_manual_goals) { /* the shared list reset() made (:91-96,150-153): `cur` of its max_targets goals are used up */
         if (cur >= (uint32_t)cfg->flag_max_targets) return 0; /* goals.pop() on an empty list */
         cur += 1;
+        FN(flag_goal)(cfg, (uint32_t)aux[2], cur, g2);
     } else {
         if (cur == 0) return 0;
         cur -= 1;
-        items[0] = items[2 + 2 * cur]; items[1] = items[3 + 2 * cur];
+        g2[0] = items[HRL_FLAG_PENDING_OFF + 2 * cur]; g2[1] = items[HRL_FLAG_PENDING_OFF + 1 + 2 * cur];
+        items[0] = g2[0]; items[1] = g2[1];
     }
+    if (items && FN(flag_path_on)(cfg)) FN(orc_flag_set_target_state)(g2, st, items + HRL_FLAG_START_OFF); /* set_target (:98-103) with the robot where it is */
     aux[3] = (int32_t)(cur | (a3 & 0x7fff0000u));
     return 1;
 }
@@ -1600,7 +1649,7 @@ void FN(orc_env_next_target_one)(const FN(orc_env) * E, int64_t env, REAL *st, R
 
 /* One env step on the packed record.  Mirrors hrl_step() of include/hrl_envs.h. */
 void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, const REAL *act,
-                          REAL *obs, REAL *rew_out, uint8_t *done_out, REAL *info, REAL *final_obs, uint8_t *truncated) {
+                          REAL *obs, REAL *rew_out, uint8_t *done_out, REAL *info, REAL *final_obs, uint8_t *truncated, REAL *goal_out, int32_t *rows_out) {
     const hrl_config *cfg = &E->cfg;
     const FN(orc_consts) *K = &E->K;
     REAL q[15], u[14], feet[4] = {0, 0, 0, 0};
@@ -1608,18 +1657,19 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
     const int gather = cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER;
     const int n_items = gather ? cfg->n_food + cfg->n_poison : 0;
     FN(orc_substep_dbg) dbg;
+    int n_rows_step = 0; /* solver rows over the step's substeps (hrl_buffers.solver_rows) */
     memset(&dbg, 0, sizeof(dbg));
     for (int i = 0; i < 15; ++i) q[i] = st[i];
     for (int k = 0; k < 3; ++k) { u[k] = st[HRL_QVEL_OFF + 3 + k]; u[3 + k] = st[HRL_QVEL_OFF + k]; }
     for (int j = 0; j < NJ; ++j) u[6 + j] = st[HRL_QVEL_OFF + 6 + j];
     if (cfg->env_kind == HRL_POINT_GATHER) { /* point_bot.py:28-31: a/|a|*500 N in the world xy plane */
         REAL n = RSQRT(act[0] * act[0] + act[1] * act[1]), f[3] = {act[0] / n * R_(cfg->model.point_force), act[1] / n * R_(cfg->model.point_force), 0};
-        for (int s = 0; s < K->nsub; ++s) FN(orc_point_substep)(K, &E->W, q, u, f, items, n_items, &dbg);
+        for (int s = 0; s < K->nsub; ++s) { FN(orc_point_substep)(K, &E->W, q, u, f, items, n_items, &dbg); n_rows_step += dbg.n_rows; }
     } else {
         REAL tau[NJ];
         for (int j = 0; j < NJ; ++j) tau[j] = R_(cfg->model.torque_scale) * FN(clampr)(act[j], -1, 1);
         int gt[13];
-        for (int s = 0; s < K->nsub; ++s) FN(orc_ant_substep)(K, &E->W, q, u, tau, gather ? items : 0, n_items, gt, &dbg);
+        for (int s = 0; s < K->nsub; ++s) { FN(orc_ant_substep)(K, &E->W, q, u, tau, gather ? items : 0, n_items, gt, &dbg); n_rows_step += dbg.n_rows; }
         for (int l = 0; l < 4; ++l) feet[l] = (gt[2 + 3 * l] || gt[3 + 3 * l]) ? R_(1) : R_(0);
     }
     for (int i = 0; i < 15; ++i) st[i] = q[i];
@@ -1660,14 +1710,21 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         st[HRL_POTENTIAL_OFF] = pot; /* next_target() re-reads the same stale potential (:116), i.e. leaves it unchanged */
         const int budget = close_mode ? (1 << 20) : cfg->flag_max_targets; /* max_target_dist mode never runs out (:113-114) */
         int goals_left = manual ? cur : budget - cur; /* manual: `cur` counts the pending goals */
-        FN(orc_flagrun_task)(cfg, alive + progress, idone, wtd, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
+        const int with_path = FN(flag_path_on)(cfg);
+        const REAL path = with_path ? FN(orc_flag_path_rew)(st, tgt, items + HRL_FLAG_START_OFF, items[HRL_FLAG_SQDIST_OFF]) : 0;
+        FN(orc_flagrun_task_w)(cfg, alive + progress, idone, wtd, with_path, path, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
         if (steps > 0x7fff) steps = 0x7fff; /* steps_since_goal_change saturates in its 15-bit field (only reachable with the timeout off) */
-        if (retarget && (manual || close_mode)) { /* the next_target() of :190 / :198: goals.pop() (:116) or create_close_target around the robot's xy (:113-114) */
+        if (retarget) { /* the next_target() of :190 / :198: goals.pop() (:116), create_close_target around the robot's xy (:113-114) or the shared list's next goal; set_target (:98-103) */
             FN(orc_flag_next_target)(cfg, env, st, items, aux);
             cur = aux[3] & 0xffff;
         } else cur = manual ? goals_left : budget - goals_left;
         aux[3] = (int32_t)(((uint32_t)cur & 0xffffu) | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
         FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0); /* calc_state w.r.t. the (possibly new) goal */
+        if (goal_out) { /* info['target'] = self.goal on the steps that switched goals (:191,199) */
+            REAL g2[2];
+            FN(flag_current_goal)(cfg, items, aux, g2);
+            goal_out[0] = g2[0]; goal_out[1] = g2[1]; goal_out[2] = retarget ? R_(1) : R_(0); goal_out[3] = R_(steps);
+        }
     } else if (cfg->env_kind == HRL_ANT_MAZE_MJ) { /* MjAnt.py:36-97 then ant_maze_mj_env.py:66-78 */
         REAL wtd, s28[28], rpy[3], inner, tgt[2] = {R_(cfg->targets[aux[3]][0]), R_(cfg->targets[aux[3]][1])};
         int nlim, idone;
@@ -1697,6 +1754,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
     st[HRL_EPRET_OFF] += rew;
     *rew_out = rew; *done_out = (uint8_t)done;
     if (truncated) *truncated = (uint8_t)trunc;
+    if (rows_out) *rows_out += n_rows_step;
     info[0] = food_rew; info[1] = dead_rew; info[2] = st[HRL_EPRET_OFF]; info[3] = R_(aux[0]);
     /* what step() returns in the reference is the state of THIS step (ant_gather_env.py:96,118-119, ant_maze_bullet_env.py:82,97): kept in
      * final_obs when the episode ends, because the in-place reset below overwrites obs with the next episode's first observation */
@@ -1716,8 +1774,20 @@ void FN(orc_reset_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_
                               items ? items + (size_t)i * orc_items_stride(cfg) : 0, aux + (size_t)i * HRL_AUX_STRIDE, obs + (size_t)i * od);
     }
 }
-void FN(orc_step_batch_v6)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
-                           REAL *reward, uint8_t *done, REAL *info, REAL *final_obs, uint8_t *truncated) {
+/* hrl_observe of include/hrl_envs.h: the observation of the records as they stand, nothing else written (feet-contact entries 0) */
+void FN(orc_observe_batch)(const hrl_config *cfg, const REAL *state, const REAL *items, const int32_t *aux, const uint8_t *mask, REAL *obs) {
+    FN(orc_env) E;
+    FN(orc_env_init)(cfg, &E);
+    int od = orc_obs_dim(cfg);
+    REAL zero_items[2 * HRL_MAX_ITEMS] = {0};
+    for (int i = 0; i < cfg->num_envs; ++i) {
+        if (mask && !mask[i]) continue;
+        REAL feet[4] = {0, 0, 0, 0};
+        FN(make_obs)(&E, state + (size_t)i * HRL_STATE_STRIDE, items ? items + (size_t)i * orc_items_stride(cfg) : zero_items, aux + (size_t)i * HRL_AUX_STRIDE, feet, obs + (size_t)i * od, 0, 0, 0, 0);
+    }
+}
+void FN(orc_step_batch_v7)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
+                           REAL *reward, uint8_t *done, REAL *info, REAL *final_obs, uint8_t *truncated, REAL *goal, int32_t *solver_rows) {
     FN(orc_env) E;
     FN(orc_env_init)(cfg, &E);
     int od = orc_obs_dim(cfg), ad = orc_act_dim(cfg);
@@ -1726,7 +1796,11 @@ void FN(orc_step_batch_v6)(const hrl_config *cfg, REAL *state, REAL *items, int3
         FN(orc_env_step_one)(&E, cfg->env_id_offset + i, state + (size_t)i * HRL_STATE_STRIDE,
                              items ? items + (size_t)i * orc_items_stride(cfg) : 0, aux + (size_t)i * HRL_AUX_STRIDE,
                              actions + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, info + (size_t)i * HRL_INFO_STRIDE,
-                             final_obs ? final_obs + (size_t)i * od : 0, truncated ? truncated + i : 0);
+                             final_obs ? final_obs + (size_t)i * od : 0, truncated ? truncated + i : 0, goal ? goal + (size_t)i * HRL_GOAL_STRIDE : 0, solver_rows ? solver_rows + i : 0);
+}
+void FN(orc_step_batch_v6)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
+                           REAL *reward, uint8_t *done, REAL *info, REAL *final_obs, uint8_t *truncated) {
+    FN(orc_step_batch_v7)(cfg, state, items, aux, actions, obs, reward, done, info, final_obs, truncated, 0, 0);
 }
 void FN(orc_step_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_t *aux, const REAL *actions, REAL *obs,
                         REAL *reward, uint8_t *done, REAL *info) {

@@ -36,8 +36,9 @@
  *   item cubes) through the point of their axis closest to the box; candidate contacts in the order ground, lateral planes, boxes, self
  *   pairs; at most 12 kept; rows = limits, normals, friction pairs.
  *
- * Frozen = never touched by a performance change.  It changes with the MODEL only; so far once: round 5 replaced the end-point spheres
- * against boxes by the capsules of the asset (a cube fits between the ankle and tip spheres of a foot capsule).
+ * Frozen = never touched by a performance change.  It changes with the MODEL only; so far in round 5: the end-point spheres against boxes
+ * became the capsules of the asset (a cube fits between the ankle and tip spheres of a foot capsule), and the parameters hrl_model gained
+ * (base damping, restitution, the contact cap; all off / unchanged at their defaults) were added.
  */
 #include <math.h>
 #include <stdint.h>
@@ -56,6 +57,10 @@ typedef struct tb_params {
     int32_t n_planes, n_boxes;
     double plane_n[4][3], plane_d[4]; /* inside: n.p - d > 0 */
     double box_lo[TB_MAXBOX][3], box_hi[TB_MAXBOX][3];
+    /* model parameters of hrl_model added in ABI v7 (defaults: 0, 0, 0, 0.2, 12) */
+    double linear_damping, angular_damping; /* the free velocity of the base is scaled by max(0, 1 - h * damping) every substep */
+    double restitution, restitution_threshold; /* normal rows of approaches faster than the threshold ask for restitution * speed of separation */
+    int32_t max_contacts; /* contacts kept per substep, <= TB_MAXC */
 } tb_params;
 
 typedef struct tb_out {
@@ -424,6 +429,11 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
     chol_solve(TB_NV, Lc, rhs);
     double un[TB_NV];
     for (int k = 0; k < TB_NV; ++k) un[k] = u[k] + h * rhs[k];
+    { /* base damping */
+        double sa = 1 - h * P->angular_damping, sl = 1 - h * P->linear_damping;
+        for (int k = 0; k < 3; ++k) { un[k] *= sa > 0 ? sa : 0; un[3 + k] *= sl > 0 ? sl : 0; }
+    }
+    const int cap = P->max_contacts > 0 && P->max_contacts < TB_MAXC ? P->max_contacts : TB_MAXC;
 
     /* ---- rows */
     static _Thread_local double J[TB_MAXR][TB_NV], B[TB_MAXR][TB_NV];
@@ -470,7 +480,7 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
             }
             if (!(dist < P->cdist)) continue;
             ++ncand;
-            if (nc >= TB_MAXC) continue;
+            if (nc >= cap) continue;
             tb_contact *c = &C[nc++];
             c->bodyA = sbody[s]; c->bodyB = -1; c->dist = dist; c->mu = P->mu;
             c->surface = f <= P->n_planes ? f : 100 + (f - 1 - P->n_planes);
@@ -492,7 +502,7 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
                         int id = pair++;
                         if (!(dist < P->cdist)) continue;
                         ++ncand;
-                        if (nc >= TB_MAXC) continue;
+                        if (nc >= cap) continue;
                         tb_contact *c = &C[nc++];
                         c->bodyA = a == 0 ? 0 : (a == 1 ? 1 + 2 * i : 2 + 2 * i);
                         c->bodyB = b == 0 ? 0 : (b == 1 ? 1 + 2 * j : 2 + 2 * j);
@@ -512,7 +522,14 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
             tb_point_row(&K, C[ci].bodyB, C[ci].p, d, jb);
             for (int k = 0; k < TB_NV; ++k) J[nr][k] -= jb[k];
         }
-        if (which == 0) { bias[nr] = (C[ci].dist > 0 ? C[ci].dist : P->erp_c * C[ci].dist) / h; lo[nr] = 0; hi[nr] = 1e30; normal_of[nr] = -1; mu_of[nr] = 0; kind[nr] = 1; }
+        if (which == 0) {
+            bias[nr] = (C[ci].dist > 0 ? C[ci].dist : P->erp_c * C[ci].dist) / h; lo[nr] = 0; hi[nr] = 1e30; normal_of[nr] = -1; mu_of[nr] = 0; kind[nr] = 1;
+            if (P->restitution > 0) { /* Newton restitution on the approach speed at the start of the substep */
+                double vn = 0;
+                for (int k = 0; k < TB_NV; ++k) vn += J[nr][k] * u[k];
+                if (vn < -P->restitution_threshold) bias[nr] += P->restitution * vn;
+            }
+        }
         else { bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; normal_of[nr] = nl + ci; mu_of[nr] = C[ci].mu; kind[nr] = 2; }
         ++nr;
     }
@@ -559,6 +576,11 @@ void tb_point_substep(const tb_params *P, double *q, double *u, const double *fo
     m3_from_quat(R, q + 3);
     /* an isotropic inertia tensor has no gyroscopic torque: omega is unchanged by the free motion */
     for (int k = 0; k < 3; ++k) { un[k] = u[k]; un[3 + k] = u[3 + k] + h * (force[k] / m - (k == 2 ? P->gravity : 0.0)); }
+    { /* base damping */
+        double sa = 1 - h * P->angular_damping, sl = 1 - h * P->linear_damping;
+        for (int k = 0; k < 3; ++k) { un[k] *= sa > 0 ? sa : 0; un[3 + k] *= sl > 0 ? sl : 0; }
+    }
+    const int cap = P->max_contacts > 0 && P->max_contacts < TB_MAXC ? P->max_contacts : TB_MAXC;
     static _Thread_local double J[TB_MAXR][TB_NV], B[TB_MAXR][TB_NV];
     double bias[TB_MAXR], lo[TB_MAXR], hi[TB_MAXR], mu_of[TB_MAXR], lam[TB_MAXR], cp[TB_MAXC][3], cn[TB_MAXC][3], cd[TB_MAXC];
     int normal_of[TB_MAXR], kind[TB_MAXR], csurf[TB_MAXC], nc = 0, ncand = 0;
@@ -573,7 +595,7 @@ void tb_point_substep(const tb_params *P, double *q, double *u, const double *fo
             else dist = tb_sphere_box(p, 0.0, P->box_lo[f - 1 - P->n_planes], P->box_hi[f - 1 - P->n_planes], n);
             if (!(dist < P->cdist)) continue;
             ++ncand;
-            if (nc >= TB_MAXC) continue;
+            if (nc >= cap) continue;
             for (int k = 0; k < 3; ++k) { cp[nc][k] = c[k]; cn[nc][k] = n[k]; }
             cd[nc] = dist; csurf[nc] = f <= P->n_planes ? f : 100 + (f - 1 - P->n_planes); ++nc;
         }
@@ -586,7 +608,14 @@ void tb_point_substep(const tb_params *P, double *q, double *u, const double *fo
         v3_cross(rxd, cp[ci], d);
         memset(J[nr], 0, sizeof(J[nr])); memset(B[nr], 0, sizeof(B[nr]));
         for (int k = 0; k < 3; ++k) { J[nr][k] = rxd[k]; J[nr][3 + k] = d[k]; B[nr][k] = rxd[k] / I; B[nr][3 + k] = d[k] / m; }
-        if (which == 0) { bias[nr] = (cd[ci] > 0 ? cd[ci] : P->erp_c * cd[ci]) / h; lo[nr] = 0; hi[nr] = 1e30; normal_of[nr] = -1; mu_of[nr] = 0; kind[nr] = 1; }
+        if (which == 0) {
+            bias[nr] = (cd[ci] > 0 ? cd[ci] : P->erp_c * cd[ci]) / h; lo[nr] = 0; hi[nr] = 1e30; normal_of[nr] = -1; mu_of[nr] = 0; kind[nr] = 1;
+            if (P->restitution > 0) {
+                double vn = 0;
+                for (int k = 0; k < 6; ++k) vn += J[nr][k] * u[k];
+                if (vn < -P->restitution_threshold) bias[nr] += P->restitution * vn;
+            }
+        }
         else { bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; normal_of[nr] = ci; mu_of[nr] = P->mu; kind[nr] = 2; }
         ++nr;
     }

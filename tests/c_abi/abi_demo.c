@@ -5,7 +5,7 @@
  *   device buffers from hipMalloc, hrl_create / hrl_reset / hrl_step on a stream, results copied back when wanted.
  *
  *   build:  gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I../../include abi_demo.c -L../../hrl_pybullet_envs_amd -lhrl_envs_hip -L/opt/rocm/lib -lamdhip64 -o abi_demo   (tests/c_abi/Makefile)
- *   run:    abi_demo <kind> <n_envs> <steps> <seed> <out.bin>
+ *   run:    abi_demo <kind> <n_envs> <steps> <seed> <out.bin>            (a sixth argument: only show that an uninitialised hrl_buffers is refused)
  * Actions are U(-1, 1) from a 64-bit LCG (the one oracle/orc_impl.h::orc_bench uses), generated on the host and copied per step.
  * out.bin: state[N][32] | items[N][stride] | aux[N][4] (as int32) | obs[N][D] | reward[N] | done[N] (u8) | final_obs[N][D] | truncated[N] (u8), raw.
  */
@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "hrl_envs.h"
 
@@ -29,6 +30,15 @@ int main(int argc, char **argv) {
     hrl_handle *h = NULL;
     CHECK_HRL(hrl_create(&cfg, &h));
     hrl_buffers b;
+    CHECK_HRL(hrl_buffers_init(&b)); /* zeroes the record and sets struct_size: pointers this host does not know about stay NULL, and the library
+                                        refuses a record that was left as the stack held it (`abi_demo ... uninit` below shows that) */
+    if (argc > 6) { /* what a host rebuilt against a newer header without initialising the record would hand over */
+        hrl_buffers junk;
+        memset(&junk, 0x5a, sizeof junk);
+        const int rc = hrl_reset(h, &junk, NULL, NULL);
+        printf("uninitialised record: rc %d (%s)\n", rc, hrl_last_error());
+        return rc == HRL_ERR_BAD_ARG ? 0 : 5;
+    }
     float *d_act = NULL;
     CHECK_HIP(hipMalloc((void **)&b.state, sizeof(float) * n * HRL_STATE_STRIDE));
     CHECK_HIP(hipMalloc((void **)&b.items, sizeof(float) * n * S));

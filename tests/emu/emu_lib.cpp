@@ -99,7 +99,7 @@ static DevBufs to_dev(const hrl_buffers *b, const uint8_t *mask) {
     DevBufs d;
     d.state = b->state; d.items = b->items; d.aux = b->aux; d.actions = b->actions; d.obs = b->obs;
     d.reward = b->reward; d.done = b->done; d.info = b->info; d.mask = mask; d.stamps = nullptr;
-    d.final_obs = b->final_obs; d.truncated = b->truncated;
+    d.final_obs = b->final_obs; d.truncated = b->truncated; d.goal = b->goal; d.rows = b->solver_rows;
     return d;
 }
 
@@ -114,6 +114,13 @@ int emu_reset(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, 
     DevCfg c; build_devcfg(*cfg, c);
     DevBufs d = to_dev(b, mask);
     for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; reset_dispatch(x, d, c, e); }
+    return HRL_OK;
+}
+int emu_observe(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, int reverse) {
+    if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
+    DevCfg c; build_devcfg(*cfg, c);
+    DevBufs d = to_dev(b, mask);
+    for (int e = 0; e < cfg->num_envs; ++e) { CpuGroup g(1); CpuExec x(g, 0); x.reverse = reverse != 0; observe_dispatch(x, d, c, e); }
     return HRL_OK;
 }
 /* group = envs per workgroup: 4 = the product's launch for the ant kinds (four host threads per group), 1 = one wave per env */

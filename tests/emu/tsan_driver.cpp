@@ -24,7 +24,7 @@ int main() {
         std::vector<float> state(n * 32), items((size_t)n * is), obs((size_t)n * od), rew(n), info(n * 4), act((size_t)n * ad), fin((size_t)n * od);
         std::vector<int32_t> aux(n * 4);
         std::vector<uint8_t> done(n), trunc(n);
-        hrl_buffers b{state.data(), items.data(), aux.data(), act.data(), obs.data(), rew.data(), done.data(), info.data(), fin.data(), trunc.data()};
+        hrl_buffers b{sizeof(hrl_buffers), state.data(), items.data(), aux.data(), act.data(), obs.data(), rew.data(), done.data(), info.data(), fin.data(), trunc.data(), nullptr, nullptr};
         if (emu_reset(&cfg, &b, nullptr, 0) != 0) return 3;
         std::mt19937 rng(1);
         std::uniform_real_distribution<float> u(-1.f, 1.f);

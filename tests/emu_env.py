@@ -43,16 +43,25 @@ class EmuEnv:
         self.act = np.zeros((n, self.ad), f)
         self.final_obs = np.zeros((n, self.od), f)
         self.truncated = np.zeros(n, np.uint8)
+        self.goal = np.zeros((n, K.HRL_GOAL_STRIDE), f)
+        self.solver_rows = np.zeros(n, np.int32)
 
     def _bufs(self):
-        return K.hrl_buffers(ptr(self.state), ptr(self.items), ptr(self.aux), ptr(self.act), ptr(self.obs),
-                             ptr(self.rew), ptr(self.done), ptr(self.info), ptr(self.final_obs), ptr(self.truncated))
+        return K.make_buffers(ptr(self.state), ptr(self.items), ptr(self.aux), ptr(self.act), ptr(self.obs),
+                              ptr(self.rew), ptr(self.done), ptr(self.info), ptr(self.final_obs), ptr(self.truncated), ptr(self.goal), ptr(self.solver_rows))
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         b = self._bufs()
         rc = lib(self.asan).emu_reset(C.byref(self.cfg), C.byref(b), ptr(m), self.reverse)
         assert rc == 0, lib(self.asan).emu_validate(C.byref(self.cfg))
+        return self.obs
+
+    def observe(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        b = self._bufs()
+        rc = lib(self.asan).emu_observe(C.byref(self.cfg), C.byref(b), ptr(m), self.reverse)
+        assert rc == 0
         return self.obs
 
     def step(self, actions):

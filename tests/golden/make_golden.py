@@ -544,6 +544,54 @@ def main():
                    'obs_is_new_state': bool(np.array_equal(obs, s_new)),
                    'target_after': [float(self.walk_target_x), float(self.walk_target_y)]})
     G['flagrun_step'] = fr
+
+    # the same step() with the CLASS-LEVEL reward weights moved off their defaults (ant_flagrun_env.py:157-160, read off the class in :169-186), the
+    # path reward's state (`_goal_start_pos`, `_sq_dist_goal`, :100-103) drawn at random -- including the constructor's 0 / (0, 0) of an env that
+    # never got a goal (:47-49: 0 / 0 -> NaN) -- and what set_target() leaves behind when the step switches goals; info['target'] (:191,199)
+    fw = []
+    defaults = {k: getattr(AntFlagrunBulletEnv, k) for k in ('ant_env_rew_weight', 'path_rew_weight', 'dist_rew_weight', 'goal_reach_rew')}
+    for k in range(90):
+        lrs = np.random.RandomState(13500 + k)
+        w = {'ant_env_rew_weight': float(lrs.choice([1, 0, 0.5, -2])), 'path_rew_weight': float(lrs.choice([0, 1, 0.3, -4])),
+             'dist_rew_weight': float(lrs.choice([0, 1, 0.05])), 'goal_reach_rew': float(lrs.choice([5000, 0, 10, -1]))}
+        if k % 9 == 0: w = dict(defaults)
+        n_goals = int(lrs.randint(0, 4))
+        goals = [tuple(lrs.uniform(-5, 5, 2)) for _ in range(n_goals)]
+        tol, timeout = float(lrs.choice([0.5, 1.0])), int(lrs.choice([5, 200]))
+        switch = bool(lrs.randint(0, 2)) if k % 4 == 0 else True
+        steps0 = int(lrs.randint(0, 7)); rewarded0 = bool(lrs.randint(0, 2)) if not switch else False
+        pos = lrs.uniform(-4, 4, 3)
+        goal0 = lrs.uniform(-5, 5, 2)
+        if k % 2 == 0: goal0 = pos[:2] + lrs.uniform(-1, 1, 2) * 0.6 * tol     # near the goal: rewards and switches
+        wtd = float(np.linalg.norm(goal0 - pos[:2]))
+        start = lrs.uniform(-4, 4, 2); sq = float(np.linalg.norm(goal0 - start) ** 2)
+        if k % 10 == 3: start, sq = np.array([0, 0]), 0                          # as constructed: no goal received yet
+        inner_r = float(lrs.uniform(-2, 2)); inner_d = bool(lrs.randint(0, 8) == 0)
+        s_old = lrs.uniform(-1, 1, 28).astype(np.float32); s_new = lrs.uniform(-1, 1, 28).astype(np.float32)
+        robot = NS(walk_target_dist=wtd, walk_target_x=float(goal0[0]), walk_target_y=float(goal0[1]), body_real_xyz=pos,
+                   robot_body=NS(get_position=lambda: pos), calc_potential=lambda: -wtd / 0.0165, calc_state=lambda: s_new.copy())
+        self = AntFlagrunBulletEnv.__new__(AntFlagrunBulletEnv)
+        self.__dict__.update(dict(robot=robot, tol=tol, timeout=timeout, switch_flag_on_collision=switch, max_targets=100,
+                                  goals=list(goals), steps_since_goal_change=steps0, _rewarded=rewarded0, debug=False,
+                                  use_sensor=False, isRender=False, flag=None, walk_target_x=float(goal0[0]), walk_target_y=float(goal0[1]),
+                                  _sq_dist_goal=sq, _goal_start_pos=np.array(start), potential=-77.0,
+                                  _super_step_result=(s_old.copy(), inner_r, inner_d, {})))
+        for name, v in w.items(): setattr(AntFlagrunBulletEnv, name, v)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                with np.errstate(all='ignore'):
+                    obs, r, d, info = AntFlagrunBulletEnv.step(self, np.zeros(8))
+        finally:
+            for name, v in defaults.items(): setattr(AntFlagrunBulletEnv, name, v)
+        fw.append({'weights': w, 'n_goals': n_goals, 'goals': [list(map(float, g)) for g in goals], 'tol': tol, 'timeout': timeout, 'switch': switch,
+                   'steps_before': steps0, 'rewarded_before': rewarded0, 'robot_xy': [float(pos[0]), float(pos[1])], 'goal': [float(goal0[0]), float(goal0[1])],
+                   'goal_start_pos': [float(start[0]), float(start[1])], 'sq_dist_goal': float(sq), 'walk_target_dist': wtd,
+                   'inner_rew': inner_r, 'inner_done': inner_d, 'rew': float(r), 'done': bool(d),
+                   'steps_after': int(self.steps_since_goal_change), 'rewarded_after': bool(self._rewarded), 'goals_left': len(self.goals),
+                   'info_target': [float(info['target'][0]), float(info['target'][1])] if 'target' in info else None,
+                   'goal_start_pos_after': [float(self._goal_start_pos[0]), float(self._goal_start_pos[1])], 'sq_dist_goal_after': float(self._sq_dist_goal)})
+    G['flagrun_weights_step'] = fw
     # create_target rejection logic (ant_flagrun_env.py:71-78) with the uniforms it consumed
     class LogU:
         def __init__(self, seed): self.rs = np.random.RandomState(seed); self.log = []

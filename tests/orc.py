@@ -95,6 +95,8 @@ class OracleEnv:
         self.info = np.zeros((n, K.HRL_INFO_STRIDE), self.dtype)
         self.final_obs = np.zeros((n, self.od), self.dtype)
         self.truncated = np.zeros(n, np.uint8)
+        self.goal = np.zeros((n, K.HRL_GOAL_STRIDE), self.dtype)
+        self.solver_rows = np.zeros(n, np.int32)
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
@@ -104,10 +106,15 @@ class OracleEnv:
 
     def step(self, actions):
         a = np.ascontiguousarray(actions, self.dtype).reshape(self.N, self.ad)
-        fn('orc_step_batch_v6', self.dtype)(C.byref(self.cfg), ptr(self.state), ptr(self.items), ptr(self.aux), ptr(a),
+        fn('orc_step_batch_v7', self.dtype)(C.byref(self.cfg), ptr(self.state), ptr(self.items), ptr(self.aux), ptr(a),
                                             ptr(self.obs), ptr(self.rew), ptr(self.done), ptr(self.info), ptr(self.final_obs),
-                                            ptr(self.truncated))
+                                            ptr(self.truncated), ptr(self.goal), ptr(self.solver_rows))
         return self.obs, self.rew, self.done, self.info
+
+    def observe(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        fn('orc_observe_batch', self.dtype)(C.byref(self.cfg), ptr(self.state), ptr(self.items), ptr(self.aux), ptr(m), ptr(self.obs))
+        return self.obs
 
     @property
     def qpos(self):

@@ -23,7 +23,7 @@ for kind, kw in CASES:
         rng = np.random.RandomState(1)
         for t in range(60):
             e.step(rng.uniform(-1, 1, (6, e.ad)).astype(np.float32))
-# random legal configs (tests/tools/fuzz_configs.py: capacity edges -- 64 items, 64 bins, 256-wide observations, 64 targets, 63 goals --, parked waves,
+# random legal configs (tests/tools/fuzz_configs.py: capacity edges -- 64 items, 64 bins, 256-wide observations, 64 targets, 61 goals --, parked waves,
 # teleports, masked resets, manual goals): the records are sized for exactly these
 import os, sys
 os.environ['HRL_EMU_ASAN'] = '1'

@@ -408,7 +408,8 @@ def test_flagrun_manual_goals():
     assert emu_env.lib().emu_set_goals(C.byref(cfg), C.byref(b), orc.ptr(goals), G, None, 0) == 0
     same(o, e, 'set_goals')
     assert np.array_equal(o.items[:, 0:2], goals[:, G - 1]) and np.all((o.aux[:, 3] & 0xffff) == G - 1)  # the LAST goal first
-    assert np.array_equal(o.items[:, 2:2 + 2 * (G - 1)], goals[:, :G - 1].reshape(n, -1))                # the rest, in list order
+    P0 = K.HRL_FLAG_PENDING_OFF
+    assert np.array_equal(o.items[:, P0:P0 + 2 * (G - 1)], goals[:, :G - 1].reshape(n, -1))                # the rest, in list order
     rng = np.random.RandomState(1)
     visited = np.zeros(n, int); done_at = np.full(n, -1)
     for t in range(12):
@@ -434,7 +435,7 @@ def test_flagrun_manual_goals():
     ok_o = np.full(n, 7, np.uint8); ok_e = np.full(n, 7, np.uint8)
     mask = np.ones(n, np.uint8); mask[5] = 0
     for env in (o, e):
-        env.items[:, 2:4] = extra; env.aux[:, 3] = (env.aux[:, 3] & ~0xffff) | 1
+        env.items[:, K.HRL_FLAG_PENDING_OFF:K.HRL_FLAG_PENDING_OFF + 2] = extra; env.aux[:, 3] = (env.aux[:, 3] & ~0xffff) | 1
     for rep, want in ((0, 1), (1, 0)):
         orc.lib().orc_next_target_batch_f32(C.byref(cfg), orc.ptr(o.state), orc.ptr(o.items), orc.ptr(o.aux), orc.ptr(mask), orc.ptr(o.obs), orc.ptr(ok_o))
         b = e._bufs()

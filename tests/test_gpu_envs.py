@@ -126,10 +126,10 @@ def test_c_abi_error_paths():
         st = torch.zeros(n, 32, device='cuda'); it = torch.zeros(n, 32, device='cuda'); aux = torch.zeros(n, 4, dtype=torch.int32, device='cuda')
         obs = torch.zeros(n, od, device='cuda'); act = torch.zeros(n, ad, device='cuda'); rew = torch.zeros(n, device='cuda')
         done = torch.zeros(n, dtype=torch.uint8, device='cuda'); info = torch.zeros(n, 4, device='cuda')
-        no_items = K.hrl_buffers(st.data_ptr(), None, aux.data_ptr(), act.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr())
+        no_items = K.make_buffers(st.data_ptr(), None, aux.data_ptr(), act.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr())
         assert L.hrl_reset(h, C.byref(no_items), None, None) == K.HRL_ERR_BAD_ARG and b'items' in L.hrl_last_error()
         assert L.hrl_step(h, C.byref(no_items), None) == K.HRL_ERR_BAD_ARG and b'items' in L.hrl_last_error()
-        ok = K.hrl_buffers(st.data_ptr(), it.data_ptr(), aux.data_ptr(), None, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr())
+        ok = K.make_buffers(st.data_ptr(), it.data_ptr(), aux.data_ptr(), None, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr())
         assert L.hrl_reset(h, C.byref(ok), None, None) == K.HRL_OK
         assert L.hrl_step(h, C.byref(ok), None) == K.HRL_ERR_BAD_ARG  # no actions
         torch.cuda.synchronize()
@@ -137,6 +137,104 @@ def test_c_abi_error_paths():
     bad = _lib.default_config(K.HRL_ANT_FLAGRUN, flag_max_targets=5, flag_max_target_dist=2.0)
     h = C.c_void_p()
     assert L.hrl_create(C.byref(bad), C.byref(h)) == K.HRL_ERR_BAD_ARG and b'exactly one' in L.hrl_last_error()
+    # a buffer record that was never initialised (ABI v7: hrl_buffers.struct_size): refused at every entry point, before any launch
+    cfg = _lib.default_config(K.HRL_ANT_FLAT, num_envs=n, seed=0)
+    assert L.hrl_create(C.byref(cfg), C.byref(h)) == K.HRL_OK
+    junk = K.hrl_buffers()
+    C.memset(C.byref(junk), 0x5a, C.sizeof(junk))
+    zero = K.hrl_buffers(); zero.struct_size = 0
+    for rec in (junk, zero):
+        assert L.hrl_reset(h, C.byref(rec), None, None) == K.HRL_ERR_BAD_ARG and b'hrl_buffers_init' in L.hrl_last_error()
+        assert L.hrl_step(h, C.byref(rec), None) == K.HRL_ERR_BAD_ARG and b'struct_size' in L.hrl_last_error()
+        assert L.hrl_observe(h, C.byref(rec), None, None) == K.HRL_ERR_BAD_ARG
+        assert L.hrl_get_state(h, C.byref(rec), st.data_ptr(), st.data_ptr(), None) == K.HRL_ERR_BAD_ARG
+    fresh = K.hrl_buffers()
+    C.memset(C.byref(fresh), 0x5a, C.sizeof(fresh))
+    assert L.hrl_buffers_init(C.byref(fresh)) == K.HRL_OK and fresh.struct_size == C.sizeof(K.hrl_buffers) and fresh.goal is None and fresh.state is None
+    # a caller compiled against a shorter record of this ABI version (no `goal` field): accepted, what lies beyond its struct_size is not read
+    od = L.hrl_obs_dim(C.byref(cfg))
+    obs = torch.zeros(n, od, device='cuda'); act = torch.zeros(n, 8, device='cuda')
+    short = K.make_buffers(st.data_ptr(), None, aux.data_ptr(), act.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr())
+    short.goal = 0x5a5a5a5a5a5a          # garbage beyond the declared size
+    short.struct_size = K.hrl_buffers.goal.offset
+    assert L.hrl_reset(h, C.byref(short), None, None) == K.HRL_OK and L.hrl_step(h, C.byref(short), None) == K.HRL_OK
+    torch.cuda.synchronize()
+    assert L.hrl_destroy(h) == K.HRL_OK
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs in one process')
+def test_c_abi_refuses_a_launch_from_another_device():
+    """A handle belongs to the device that was current at hrl_create(): called with another device current, every entry point returns
+    HRL_ERR_BAD_ARG and says which device to set (a launch there would hand the kernel a constants pointer of another GPU)."""
+    import ctypes as C
+    from hrl_pybullet_envs_amd import _lib
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+    g = BatchedEnv(_lib.default_config(K.HRL_ANT_FLAT, num_envs=8, seed=0), 'cuda:0')
+    g.reset()
+    with torch.cuda.device(1):
+        assert _lib.lib().hrl_reset(g._h, C.byref(g._bufs), None, None) == K.HRL_ERR_BAD_ARG
+        assert b'hipSetDevice(0)' in _lib.lib().hrl_last_error()
+    g.step(torch.zeros(8, 8, device='cuda:0'))   # BatchedEnv switches to its device itself
+    g.close()
+
+
+def test_flagrun_info_target_and_class_level_reward_weights():
+    """ant_flagrun_env.py:191,199: `info['target'] = self.goal` on exactly the steps in which next_target() ran; :157-178: the class-level reward
+    weights, read off the class when the env is built.  One env (the reference's object) and a batch; rewards against the oracle configured alike."""
+    import hrl_pybullet_envs_amd as H
+    import orc
+    env = H.AntFlagrunBulletEnv(timeout=7, num_envs=1, seed=4)
+    env.reset()
+    g0, switched = env.goal, []
+    for t in range(30):
+        ob, r, d, info = env.step(np.zeros(8))
+        if 'target' in info:
+            switched.append(t)
+            assert info['target'] == pytest.approx(env.goal) and info['target'] != pytest.approx(g0)
+            g0 = env.goal
+        else:
+            assert env.goal == pytest.approx(g0)
+    assert len(switched) >= 4 and switched[0] <= 6 and all(b - a <= 7 for a, b in zip(switched, switched[1:]))   # the 7-step timeout at the latest
+    env.close()
+    cls = H.AntFlagrunBulletEnv
+    saved = (cls.ant_env_rew_weight, cls.path_rew_weight, cls.dist_rew_weight, cls.goal_reach_rew)
+    try:
+        cls.ant_env_rew_weight, cls.path_rew_weight, cls.dist_rew_weight, cls.goal_reach_rew = 0.5, 2.0, 0.25, 77
+        n = 128
+        env = H.AntFlagrunBulletEnv(timeout=9, tolerance=1.0, num_envs=n, seed=6)
+    finally:
+        cls.ant_env_rew_weight, cls.path_rew_weight, cls.dist_rew_weight, cls.goal_reach_rew = saved
+    assert env.reward_weights == dict(ant_env_rew_weight=0.5, path_rew_weight=2.0, dist_rew_weight=0.25, goal_reach_rew=77.0)
+    ocfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=6, auto_reset=1, flag_timeout=9, tol=1.0, max_episode_steps=2000,
+                              flag_ant_env_rew_weight=0.5, flag_path_rew_weight=2.0, flag_dist_rew_weight=0.25, flag_goal_reach_rew=77.0)
+    assert bytes(ocfg) == bytes(env._cfg)
+    o = orc.OracleEnv(ocfg, np.float32)
+    ob = env.reset(); o.reset()
+    assert np.array_equal(ob.cpu().numpy(), o.obs) and np.array_equal(env._backend().items.cpu().numpy(), o.items)
+    rng = np.random.RandomState(0)
+    n_sw = 0
+    for t in range(40):
+        if t == 20:   # some ants put next to their goals: the goal reward (77) and a switch on reaching it
+            gl = env.goal
+            o.state[::2, 0:2] = gl[::2].astype(np.float32) + np.float32(0.2)
+            env._backend().state.copy_(torch.from_numpy(o.state))
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        ob, r, d, info = env.step(torch.from_numpy(a).cuda()); o.step(a)
+        assert np.array_equal(r.cpu().numpy(), o.rew, equal_nan=True) and np.array_equal(ob.cpu().numpy(), o.obs, equal_nan=True), t
+        assert np.array_equal(env._backend().goal.cpu().numpy(), o.goal) and np.array_equal(env._backend().items.cpu().numpy(), o.items)
+        sw = info['retargeted'].cpu().numpy() != 0
+        n_sw += int(sw.sum())
+        assert np.allclose(info['target'].cpu().numpy()[~o.done.astype(bool)], env.goal[~o.done.astype(bool)], atol=1e-6)
+        if t == 20:
+            assert (o.rew[::2] > 60).sum() > 40   # reached: + goal_reach_rew
+    assert n_sw > 4 * n   # every 9 steps at the latest
+    assert np.all(np.isfinite(env._sq_dist_goal.cpu().numpy())) and env._goal_start_pos.shape == (n, 2)
+    env.set_reward_weights(path_rew_weight=0.0, goal_reach_rew=5000)   # a live env: new handle, same simulation
+    o.cfg.flag_path_rew_weight = 0.0; o.cfg.flag_goal_reach_rew = 5000.0
+    a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+    ob, r, d, info = env.step(torch.from_numpy(a).cuda()); o.step(a)
+    assert np.array_equal(r.cpu().numpy(), o.rew, equal_nan=True) and np.array_equal(env._backend().state.cpu().numpy(), o.state, equal_nan=True)
+    env.close()
 
 
 def test_flagrun_close_goal_class():
@@ -582,6 +680,9 @@ def test_c_abi_from_plain_c(tmp_path):
         assert np.array_equal(st, o.state) and np.array_equal(it, o.items) and np.array_equal(aux, o.aux), kind
         assert np.array_equal(ob, o.obs, equal_nan=True) and np.array_equal(rew, o.rew) and np.array_equal(done, o.done), kind
         assert np.array_equal(fin, o.final_obs, equal_nan=True) and np.array_equal(trunc, o.truncated) and np.any(fin != 0), kind
+    # a record left as the stack held it is refused with the reason, not handed to a kernel (hrl_buffers.struct_size, hrl_buffers_init)
+    p = subprocess.run([os.path.join(d, 'abi_demo'), '1', '8', '1', '1', str(tmp_path / 'x.bin'), 'uninit'], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and 'rc 1' in p.stdout and 'hrl_buffers_init' in p.stdout, (p.stdout, p.stderr)
 
 
 def test_checkpoint_and_resume_continue_bit_for_bit():

@@ -314,6 +314,44 @@ def test_flagrun_close_targets():
 
 
 
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-6), (np.float32, 2e-3)])  # hrl_config holds the weights as float: 0.3 and 0.05 are good to 3e-8 relative
+def test_flagrun_class_level_reward_weights(dtype, tol):
+    """`flagrun_weights_step.json`: the reference's own step() (ant_flagrun_env.py:162-204) with the class-level weights moved off their defaults
+    (:157-160), random path-reward state (:100-103) -- including an env that never received a goal (0 / 0 -> NaN or +-inf rewards) -- and what
+    set_target() leaves behind when the step switches goals; info['target'] (:191,199).  Replayed on the oracle's record functions."""
+    L, cr = orc.lib(), orc.creal(dtype)
+    pr = orc.fn('orc_flag_path_rew', dtype); pr.restype = cr
+    n_target = n_nonfinite = 0
+    for c in load('flagrun_weights_step'):
+        w = c['weights']
+        cfg = orc.default_config(K.HRL_ANT_FLAGRUN, tol=c['tol'], flag_timeout=c['timeout'], flag_switch_on_collision=int(c['switch']),
+                                 flag_ant_env_rew_weight=w['ant_env_rew_weight'], flag_path_rew_weight=w['path_rew_weight'],
+                                 flag_dist_rew_weight=w['dist_rew_weight'], flag_goal_reach_rew=w['goal_reach_rew'])
+        xy, goal, start = arr(c['robot_xy'], dtype), arr(c['goal'], dtype), arr(c['goal_start_pos'], dtype)
+        with np.errstate(all='ignore'):
+            path = pr(orc.ptr(xy), orc.ptr(goal), orc.ptr(start), cr(c['sq_dist_goal']))
+        steps = C.c_int(c['steps_before']); rewarded = C.c_int(int(c['rewarded_before'])); left = C.c_int(c['n_goals'])
+        rew = cr(); done = C.c_int(); retarget = C.c_int()
+        orc.fn('orc_flagrun_task_w', dtype)(C.byref(cfg), cr(c['inner_rew']), int(c['inner_done']), cr(c['walk_target_dist']), 1, cr(path),
+                                            C.byref(steps), C.byref(rewarded), C.byref(left), C.byref(rew), C.byref(done), C.byref(retarget))
+        if np.isfinite(c['rew']):
+            assert rew.value == pytest.approx(c['rew'], abs=tol * max(1.0, abs(c['rew']))), c
+        else:
+            n_nonfinite += 1
+            assert (np.isnan(c['rew']) and np.isnan(rew.value)) or rew.value == c['rew'], (c['rew'], rew.value)
+        assert bool(done.value) == c['done'] and steps.value == c['steps_after'] and bool(rewarded.value) == c['rewarded_after'] and left.value == c['goals_left']
+        assert bool(retarget.value) == (c['info_target'] is not None)
+        st3 = np.array(c['goal_start_pos'] + [c['sq_dist_goal']], dtype)
+        if retarget.value:   # next_target() -> set_target(goals.pop()): the LAST goal; `_goal_start_pos` / `_sq_dist_goal` from where the robot stands
+            n_target += 1
+            new_goal = arr(c['goals'][-1], dtype)
+            np.testing.assert_allclose(new_goal, c['info_target'], atol=1e-6)
+            orc.fn('orc_flag_set_target_state', dtype)(orc.ptr(new_goal), orc.ptr(xy), orc.ptr(st3))
+        np.testing.assert_allclose(st3[:2], c['goal_start_pos_after'], atol=1e-6)
+        assert st3[2] == pytest.approx(c['sq_dist_goal_after'], rel=1e-12 if dtype == np.float64 else 1e-5)
+    assert n_target >= 20 and n_nonfinite >= 5
+
+
 def test_flagrun_manual_goal_sequences():
     """manual_goal_creation sequences run on the reference itself (make_golden.py `flagrun_manual_seq`): `env.goals = [...];
     env.next_target()` takes the LAST goal of the list (goals.pop(), ant_flagrun_env.py:116), the list is consumed back to front,
@@ -335,7 +373,7 @@ def test_flagrun_manual_goal_sequences():
             if e['op'] == 'reset':
                 before = items[0:2].copy(); steps_before = (aux[3] >> 16) & 0x7fff
                 o.reset()
-                assert np.array_equal(items[0:2], before) and np.all(items[2:] == 0) and (aux[3] & 0xffff) == 0   # target kept, list dropped
+                assert np.array_equal(items[0:2], before) and np.all(items[K.HRL_FLAG_PENDING_OFF:] == 0) and (aux[3] & 0xffff) == 0   # target kept, list dropped
                 assert ((aux[3] >> 16) & 0x7fff) == steps_before == e['steps'] and not (aux[3] >> 31) & 1
                 np.testing.assert_allclose(items[0:2], e['target'], atol=1e-12)
             elif e['op'] in ('set_goals', 'next_target'):
@@ -349,7 +387,7 @@ def test_flagrun_manual_goal_sequences():
                     np.testing.assert_allclose(items[0:2], gl[-1], atol=1e-12)   # goals.pop(): the LAST goal
                     assert not (aux[3] >> 31) & 1
                 assert (aux[3] & 0xffff) == len(e['goals_left']) and ((aux[3] >> 16) & 0x7fff) == e['steps']
-                np.testing.assert_allclose(items[2:2 + 2 * len(e['goals_left'])].reshape(-1, 2), arr(e['goals_left']).reshape(-1, 2), atol=1e-12)
+                np.testing.assert_allclose(items[K.HRL_FLAG_PENDING_OFF:K.HRL_FLAG_PENDING_OFF + 2 * len(e['goals_left'])].reshape(-1, 2), arr(e['goals_left']).reshape(-1, 2), atol=1e-12)
             else:
                 wtd = float(np.linalg.norm(arr(e['pos'][:2]) - items[0:2]))
                 base = 1.0 + (e['potential'] - prev['potential'])

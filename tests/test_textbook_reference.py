@@ -246,7 +246,7 @@ def test_lcp_residual_five_sweeps_against_converged():
 def test_optimised_spec_equals_textbook_over_the_model_parameters():
     """The engine parameters of `hrl_model` are part of the C-ABI: 400 random contact states, each with its OWN model -- density, gravity, time
     step, both ERPs, both friction coefficients, contact distance, limit margin, rate clamp, limit impulse cap, ground height, 1..13 sweeps,
-    self collision on / off, arena size -- one substep of the optimised specification against the frozen textbook reference: the two derivations
+    self collision on / off, arena size, base damping, restitution and its threshold, the contact cap -- one substep of the optimised specification against the frozen textbook reference: the two derivations
     agree to rounding everywhere in the parameter space, not only at the defaults."""
     rng = np.random.RandomState(77)
     worst, rows, selfc = 0.0, [], 0
@@ -259,7 +259,11 @@ def test_optimised_spec_equals_textbook_over_the_model_parameters():
                   model_contact_dist=f32(rng.choice([0.0, 0.005, 0.02, 0.08])), model_limit_margin=f32(rng.choice([0.0, 0.05, 0.25, 1.0])),
                   model_max_joint_vel=f32(rng.choice([5.0, 30.0, 100.0, 1000.0])), model_limit_max_impulse=f32(rng.choice([0.5, 10.0, 100.0, 1e6])),
                   model_ground_z=f32(rng.choice([0.0, 0.005, 0.05])), model_solver_iters=int(rng.choice([1, 2, 3, 5, 8, 13])),
-                  model_self_collision=int(rng.rand() < 0.5))
+                  model_self_collision=int(rng.rand() < 0.5),
+                  # ABI v7: base damping, restitution, the contact cap
+                  model_linear_damping=f32(rng.choice([0.0, 0.0, 0.04, 1.0, 50.0])), model_angular_damping=f32(rng.choice([0.0, 0.0, 0.04, 2.0, 400.0])),
+                  model_restitution=f32(rng.choice([0.0, 0.0, 0.3, 1.0])), model_restitution_threshold=f32(rng.choice([0.0, 0.2, 1.5])),
+                  model_max_contacts=int(rng.choice([12, 12, 1, 3, 8])))
         cfg = orc.default_config(K.HRL_ANT_GATHER, **kw)
         p = tb.params(cfg)
         q, u, tau = rand_state(rng, xy=(-wx / 2 - 0.1, wx / 2 + 0.1, -wy / 2 - 0.1, wy / 2 + 0.1), joint_slack=0.3 if i % 3 == 0 else 0.1)
@@ -286,7 +290,10 @@ def test_pointbot_spec_equals_textbook_over_states_and_parameters():
         cfg = orc.default_config(K.HRL_POINT_GATHER, world_size=(wx, wy), model_gravity=f32(rng.choice([1.6, 9.8, 20.0])), model_timestep=f32(rng.uniform(0.001, 0.008)),
                                  model_contact_erp=f32(rng.uniform(0, 1)), model_friction_ground=f32(rng.choice([0.0, 0.3, 0.8, 3.0])),
                                  model_friction_robot=f32(rng.choice([0.0, 0.1, 1.0])), model_contact_dist=f32(rng.choice([0.0, 0.005, 0.02, 0.08])),
-                                 model_ground_z=f32(rng.choice([0.0, 0.005, 0.05])), model_solver_iters=int(rng.choice([1, 2, 5, 13])))
+                                 model_ground_z=f32(rng.choice([0.0, 0.005, 0.05])), model_solver_iters=int(rng.choice([1, 2, 5, 13])),
+                                 model_linear_damping=f32(rng.choice([0.0, 0.0, 0.04, 30.0])), model_angular_damping=f32(rng.choice([0.0, 0.0, 0.04, 30.0])),
+                                 model_restitution=f32(rng.choice([0.0, 0.0, 0.5, 1.0])), model_restitution_threshold=f32(rng.choice([0.0, 0.2])),
+                                 model_max_contacts=int(rng.choice([12, 12, 2, 5])))
         p = tb.params(cfg)
         q = np.zeros(7)
         q[0], q[1] = rng.uniform(-wx / 2, wx / 2), rng.uniform(-wy / 2, wy / 2)
@@ -304,6 +311,40 @@ def test_pointbot_spec_equals_textbook_over_states_and_parameters():
         worst = max(worst, err); contacts.append(out.n_contacts)
     assert np.mean(contacts) > 1.5 and max(contacts) >= 6
     print(f'point bot, random states and parameters: worst |diff| {worst:.2e}, contacts mean {np.mean(contacts):.1f} max {max(contacts)}')
+
+
+def test_model_parameters_of_abi_v7_do_what_they_say():
+    """hrl_model.linear_damping / angular_damping / restitution / max_contacts (defaults 0 / 0 / 0 / 12: the build's specification):
+    a free-flying ant's base velocity decays by (1 - h d) per substep; a cube dropped flat on the ground leaves it at restitution x its impact
+    speed (and stays down at the default 0); the cap keeps the first candidates.  Optimised specification and textbook reference alike."""
+    h = 0.0165 / 4
+    # damping: no gravity, no contacts, only the base moving (every joint rate 0: the legs ride along)
+    cfg = orc.default_config(K.HRL_ANT_FLAT, model_gravity=0.0, model_linear_damping=2.0, model_angular_damping=5.0)
+    q = np.zeros(15); q[2] = 3.0; q[6] = 1.0; q[7:] = 0.5 * (LO + HI)
+    u = np.zeros(14); u[3:6] = [1.0, -2.0, 0.5]
+    q2, u2, _ = orc_substeps(cfg, q, u, np.zeros(8), 10)
+    np.testing.assert_allclose(u2[3:6], u[3:6] * (1 - h * 2.0) ** 10, rtol=1e-6)
+    u = np.zeros(14); u[2] = 1.5   # spinning about the vertical: the symmetric ant keeps its axis
+    q2, u2, _ = orc_substeps(cfg, q, u, np.zeros(8), 10)
+    assert u2[2] == pytest.approx(1.5 * (1 - h * 5.0) ** 10, rel=1e-3) and abs(u2[0]) < 1e-6 and abs(u2[1]) < 1e-6
+    # restitution: the PointBot's cube, flat, 1 mm above the ground, coming down at 2 m/s
+    for e, thr in ((0.0, 0.2), (0.5, 0.2), (1.0, 0.2), (0.5, 5.0)):
+        cfg = orc.default_config(K.HRL_POINT_GATHER, model_restitution=e, model_restitution_threshold=thr, model_gravity=0.0)
+        qq = np.array([0, 0, 0.35 + 0.005 + 0.001, 0, 0, 0, 1.0]); uu = np.zeros(6); uu[5] = -2.0
+        p = tb.params(cfg)
+        q1, u1, out = tb.point_substep(p, qq, uu, np.zeros(3))
+        q2, u2 = qq.copy(), uu.copy()
+        orc.lib().orc_point_substeps_f64(C.byref(cfg), orc.ptr(q2), orc.ptr(u2), orc.ptr(np.zeros(3)), 1)
+        assert out.n_contacts == 4 and np.abs(u1 - u2).max() < 1e-9
+        want = (e * 2.0 if 2.0 > thr else 0.0) - 0.001 / h   # the speculative row lets it close the 1 mm gap (-gap / h); restitution adds e x the impact speed
+        assert u2[5] == pytest.approx(want, abs=0.01), (e, thr, u2[5])   # (four coupled corner rows, five sweeps: converged to a percent)
+    # the cap: an ant lying flat touches with more than three spheres; max_contacts = 3 keeps the first three candidates
+    cfg12, cfg3 = orc.default_config(K.HRL_ANT_FLAT), orc.default_config(K.HRL_ANT_FLAT, model_max_contacts=3)
+    q = np.zeros(15); q[2] = 0.09; q[6] = 1.0; q[7:] = np.radians([0, 30, 0, -30, 0, -30, 0, 30])
+    a12, a3 = orc_substeps(cfg12, q, np.zeros(14), np.zeros(8))[2], orc_substeps(cfg3, q, np.zeros(14), np.zeros(8))[2]
+    assert a12[2] > 3 and a3[2] == 3
+    out3 = tb.ant_substep(tb.params(cfg3), q, np.zeros(14), np.zeros(8))[2]
+    assert out3.n_contacts == 3 and out3.n_candidates == tb.ant_substep(tb.params(cfg12), q, np.zeros(14), np.zeros(8))[2].n_candidates
 
 
 # ----------------------------------------------------------------------------------------------- capsules against boxes

@@ -16,7 +16,9 @@ class tb_params(C.Structure):
                 ('limp_max', C.c_double), ('ground_z', C.c_double),
                 ('iters', C.c_int32), ('self_collision', C.c_int32), ('n_planes', C.c_int32), ('n_boxes', C.c_int32),
                 ('plane_n', (C.c_double * 3) * 4), ('plane_d', C.c_double * 4),
-                ('box_lo', (C.c_double * 3) * MAXBOX), ('box_hi', (C.c_double * 3) * MAXBOX)]
+                ('box_lo', (C.c_double * 3) * MAXBOX), ('box_hi', (C.c_double * 3) * MAXBOX),
+                ('linear_damping', C.c_double), ('angular_damping', C.c_double), ('restitution', C.c_double), ('restitution_threshold', C.c_double),
+                ('max_contacts', C.c_int32)]
 
 
 class tb_out(C.Structure):
@@ -46,6 +48,8 @@ def params(cfg, items=None, self_collision=None):
     p.mu, p.mu_self = float(np.float32(m.friction_ground) * np.float32(m.friction_robot)), float(np.float32(m.friction_robot) * np.float32(m.friction_robot))
     p.cdist, p.lmargin, p.vmax, p.limp_max, p.ground_z = m.contact_dist, m.limit_margin, m.max_joint_vel, m.limit_max_impulse, m.ground_z
     p.iters = m.solver_iters
+    p.linear_damping, p.angular_damping, p.restitution, p.restitution_threshold = m.linear_damping, m.angular_damping, m.restitution, m.restitution_threshold
+    p.max_contacts = m.max_contacts
     p.self_collision = int(getattr(m, 'self_collision', 0)) if self_collision is None else int(self_collision)
     kind = cfg.env_kind
     hx = hy = 0.0

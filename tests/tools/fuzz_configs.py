@@ -55,6 +55,10 @@ def draw_model(rng, kw, kind):
     if rng.rand() < 0.3: kw['model_density'] = f32(pick(rng, [5.0, 200.0, 1000.0, 3000.0]))
     if rng.rand() < 0.3: kw['model_point_force'] = f32(pick(rng, [0.0, 100.0, 500.0, 2500.0]))
     if rng.rand() < 0.3: kw['model_ground_z'] = f32(pick(rng, [0.0, 0.005, 0.05]))
+    if rng.rand() < 0.2: kw['model_linear_damping'] = f32(pick(rng, [0.0, 0.04, 1.0, 300.0]))
+    if rng.rand() < 0.2: kw['model_angular_damping'] = f32(pick(rng, [0.0, 0.04, 2.0, 300.0]))
+    if rng.rand() < 0.2: kw['model_restitution'] = f32(pick(rng, [0.0, 0.25, 0.5, 1.0])); kw['model_restitution_threshold'] = f32(pick(rng, [0.0, 0.2, 1.0]))
+    if rng.rand() < 0.2: kw['model_max_contacts'] = int(pick(rng, [1, 2, 4, 7, 11, 12]))
     if kind != K.HRL_POINT_GATHER and rng.rand() < 0.3: kw['model_self_collision'] = int(rng.randint(2))
     if rng.rand() < 0.15: kw['model_step_group'] = 1
 
@@ -123,8 +127,13 @@ def draw_config(rng, kind):
         kw['flag_enclosed'] = int(rng.rand() < 0.7)
         if not kw['flag_enclosed'] and not kw['use_sensor']:
             kw['centroid_n_static'] = 1; kw['centroid_static_sum'] = (0.0, 0.0)
+        if rng.rand() < 0.4:   # the class-level reward weights (ant_flagrun_env.py:157-160)
+            kw['flag_ant_env_rew_weight'] = f32(pick(rng, [1.0, 0.0, 0.5, -2.0]))
+            kw['flag_path_rew_weight'] = f32(pick(rng, [0.0, 0.0, 1.0, 0.3, -4.0]))
+            kw['flag_dist_rew_weight'] = f32(pick(rng, [0.0, 1.0, 0.05]))
+            kw['flag_goal_reach_rew'] = f32(pick(rng, [5000.0, 0.0, 10.0, -1.0]))
         if rng.rand() < 0.35:
-            kw['flag_manual_goals'] = 1; kw['flag_goal_capacity'] = int(pick(rng, [1, 2, 15, 16, 17, 40, 63]))
+            kw['flag_manual_goals'] = 1; kw['flag_goal_capacity'] = int(pick(rng, [1, 2, 13, 14, 15, 16, 17, 29, 30, 40, 61]))
     if kind == K.HRL_ANT_FLAT and rng.rand() < 0.5:
         kw['walk_target'] = (f32(rng.uniform(-50, 1000)), f32(rng.uniform(-50, 50)))
     draw_model(rng, kw, kind)
@@ -154,6 +163,7 @@ class GpuSide:
         import torch
         from hrl_pybullet_envs_amd.vec_env import BatchedEnv
         self.t, self.g = torch, BatchedEnv(cfg, 'cuda:0')
+        self.g.count_solver_rows()
 
     def reset(self, mask=None): self.g.reset(None if mask is None else self.t.from_numpy(mask).cuda())
     def step(self, a): self.g.step(self.t.from_numpy(a).cuda())
@@ -162,13 +172,16 @@ class GpuSide:
         t, g = self.t, self.g
         g.state.copy_(t.from_numpy(o.state)); g.items.copy_(t.from_numpy(o.items)); g.aux.copy_(t.from_numpy(o.aux))
 
+    def observe(self, mask): self.g.observe(None if mask is None else self.t.from_numpy(mask).cuda())
     def set_goals(self, goals, mask): self.g.set_goals(self.t.from_numpy(goals).cuda(), None if mask is None else self.t.from_numpy(mask).cuda())
     def next_target(self, mask): return self.g.next_target(None if mask is None else self.t.from_numpy(mask).cuda())[1].cpu().numpy()
 
     def outputs(self):
         g = self.g
-        return {k: v.cpu().numpy() for k, v in dict(state=g.state, items=g.items, aux=g.aux, obs=g.obs, rew=g.reward, done=g.done, info=g.info,
-                                                     final_obs=g.final_obs, truncated=g.truncated).items()}
+        d = dict(state=g.state, items=g.items, aux=g.aux, obs=g.obs, rew=g.reward, done=g.done, info=g.info, final_obs=g.final_obs, truncated=g.truncated)
+        if g.cfg.env_kind == K.HRL_ANT_FLAGRUN: d['goal'] = g.goal
+        d['solver_rows'] = g.solver_rows
+        return {k: v.cpu().numpy() for k, v in d.items()}
 
     def close(self): self.g.close()
 
@@ -189,6 +202,8 @@ class EmuSide:
         e = self.e
         e.state[...] = o.state; e.items[...] = o.items; e.aux[...] = o.aux
 
+    def observe(self, mask): self.e.observe(mask)
+
     def set_goals(self, goals, mask):
         import emu_env
         assert emu_env.lib(self.ASAN).emu_set_goals(orc.C.byref(self.e.cfg), orc.C.byref(self.e._bufs()), orc.ptr(goals), goals.shape[1], orc.ptr(mask), 0) == 0
@@ -201,7 +216,7 @@ class EmuSide:
 
     def outputs(self):
         e = self.e
-        return dict(state=e.state, items=e.items, aux=e.aux, obs=e.obs, rew=e.rew, done=e.done, info=e.info, final_obs=e.final_obs, truncated=e.truncated)
+        return dict(state=e.state, items=e.items, aux=e.aux, obs=e.obs, rew=e.rew, done=e.done, info=e.info, final_obs=e.final_obs, truncated=e.truncated, goal=e.goal, solver_rows=e.solver_rows)
 
     def close(self): pass
 
@@ -220,7 +235,7 @@ def run(Side, kind, seed, T):
     o.reset(); s.reset()
     CLOCK['create'] += time.time() - t0
     ended = 0
-    names = ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info', 'final_obs', 'truncated')
+    names = ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info', 'final_obs', 'truncated') + (('goal',) if kind == K.HRL_ANT_FLAGRUN else ()) + ('solver_rows',)
     manual = kind == K.HRL_ANT_FLAGRUN and cfg.flag_manual_goals and cfg.flag_max_targets >= 1   # goals near the robot ignore the list: hrl_set_goals refuses
     L = orc.lib()
 
@@ -268,6 +283,9 @@ def run(Side, kind, seed, T):
                 elif kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) and cfg.n_food + cfg.n_poison > 0:
                     o.items[r, rng.randint(0, 2 * (cfg.n_food + cfg.n_poison))] = v
             s.push(o)
+        if what == 5:      # the observation recomputed from the records as they stand (hrl_observe)
+            m = some(0.6)
+            o.observe(m); s.observe(m)
         if what == 1:      # masked reset from outside
             m = some(0.3)
             o.reset(m); s.reset(m)

@@ -40,7 +40,7 @@ def main():
         t = dict(state=torch.zeros(n, 32, device='cuda'), items=torch.zeros(n, 32, device='cuda'), aux=torch.zeros(n, 4, dtype=torch.int32, device='cuda'),
                  obs=torch.zeros(n, obs_dim + 2, device='cuda'), rew=torch.zeros(n, device='cuda'), done=torch.zeros(n, dtype=torch.uint8, device='cuda'),
                  info=torch.zeros(n, 4, device='cuda'))
-        b = K.hrl_buffers(t['state'].data_ptr(), t['items'].data_ptr(), t['aux'].data_ptr(), None, t['obs'].data_ptr(), t['rew'].data_ptr(),
+        b = K.make_buffers(t['state'].data_ptr(), t['items'].data_ptr(), t['aux'].data_ptr(), None, t['obs'].data_ptr(), t['rew'].data_ptr(),
                           t['done'].data_ptr(), t['info'].data_ptr())
         if name.endswith('+final'):
             t['final'] = torch.zeros(n, obs_dim, device='cuda'); t['trunc'] = torch.zeros(n, dtype=torch.uint8, device='cuda')
