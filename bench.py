@@ -52,30 +52,49 @@ def parse_args():
     ap.add_argument('--gather-every', type=int, default=100, help='all-gather episode returns every K steps (N>1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo only to rehearse N>1 on a box with fewer GPUs')
-    ap.add_argument('--watchdog', type=float, default=900.0, help='seconds a rank may take in total before it reports the stage it hangs in and exits 3 (0 = off)')
+    ap.add_argument('--settle', type=int, default=300, help='untimed steps before --warmup, whatever the caller passes for --warmup: the timed window then '
+                    'sees ants that stand (the first ~50 steps after a reset have fewer contacts and shorter launches); 0 = time the post-reset transient')
+    ap.add_argument('--watchdog', type=float, default=900.0, help='seconds a rank may go WITHOUT PROGRESS (a new stage, or another 64 launches queued) before '
+                    'it reports the stage it hangs in and exits 3 (0 = off)')
+    ap.add_argument('--stall-in', default=None, help=argparse.SUPPRESS)  # test hook: sleep forever on entering this stage (tests/test_gpu_envs.py)
     return ap.parse_args()
 
 
 class Watchdog:
     """A rank that stops making progress (a collective some rank never joined, a rendezvous that never completes) would otherwise sit until the
-    driver's limit with nothing on its output.  A daemon thread: after `seconds` it prints which stage the rank was in and ends THIS process
-    with status 3 (os._exit: no interpreter teardown that could block on the GPU; never a re-exec).  torch.distributed.run then ends the others."""
+    driver's limit with nothing on its output.  A STALL detector, not a budget: every new stage (`at`) and every heartbeat of the stepping loop
+    (`beat`) moves the deadline `seconds` ahead, so a long run that keeps going is never cut short; a daemon thread that finds the deadline passed
+    prints which stage the rank was in and ends THIS process with status 3 (os._exit: no interpreter teardown that could block on the GPU; never
+    a re-exec).  torch.distributed.run then ends the others."""
 
-    def __init__(self, seconds, rank):
+    def __init__(self, seconds, rank, stall_in=None):
         import threading
-        self.stage, self.rank, self.seconds = 'start', rank, seconds
+        self.stage, self.rank, self.seconds, self.stall_in = 'start', rank, seconds, stall_in
         self._done = threading.Event()
+        self._deadline = time.monotonic() + seconds
         if seconds > 0:
             threading.Thread(target=self._watch, daemon=True).start()
 
     def _watch(self):
-        if not self._done.wait(self.seconds):
-            sys.stderr.write(f'bench.py watchdog: rank {self.rank} still in stage "{self.stage}" after {self.seconds:.0f} s, exiting 3\n')
-            sys.stderr.flush()
-            os._exit(3)
+        while True:
+            left = self._deadline - time.monotonic()
+            if left <= 0:
+                break
+            if self._done.wait(min(left, 1.0)):
+                return
+        sys.stderr.write(f'bench.py watchdog: rank {self.rank} made no progress in stage "{self.stage}" for {self.seconds:.0f} s, exiting 3\n')
+        sys.stderr.flush()
+        os._exit(3)
+
+    def beat(self):
+        self._deadline = time.monotonic() + self.seconds
 
     def at(self, stage):
         self.stage = stage
+        self.beat()
+        if self.stall_in == stage:   # test hook: a rank that hangs here
+            while True:
+                time.sleep(1.0)
 
     def done(self):
         self._done.set()
@@ -221,7 +240,7 @@ def main():
     kinds = {'flat': K.HRL_ANT_FLAT, 'gather': K.HRL_ANT_GATHER, 'maze': K.HRL_ANT_MAZE, 'point': K.HRL_POINT_GATHER,
              'maze_mj': K.HRL_ANT_MAZE_MJ, 'flagrun': K.HRL_ANT_FLAGRUN}
 
-    wd = Watchdog(args.watchdog, int(os.environ.get('RANK', '0')))
+    wd = Watchdog(args.watchdog, int(os.environ.get('RANK', '0')), args.stall_in)
     wd.at('init_process_group')
     rank, world, local_rank = init_distributed(args.gpus, backend=args.backend)
     wd.at('build envs')
@@ -256,16 +275,22 @@ def main():
                     env.step(acts[t % T])
             if gatherer is not None and (t + 1) % gather_every == 0:
                 gatherer.launch()
+            if (t & 63) == 63:
+                wd.beat()   # the launch queue is bounded: the host gets here only as fast as the GPU works the launches off
 
     ranks_seen = None
     if world > 1:  # every rank reports in before anything is timed: the line shows the job really was `world` ranks on `world` devices
         wd.at('all_gather of (rank, device)')
         ranks_seen = [None] * world
         torch.distributed.all_gather_object(ranks_seen, (rank, local_rank, torch.cuda.get_device_name(dev)))
+    wd.at('settle')
+    run(0, args.settle)   # untimed, before the caller's warmup: the ants come to stand (the driver passes --warmup 5)
     wd.at('warmup')
-    run(0, args.warmup)
+    run(args.settle, args.warmup)
     torch.cuda.synchronize(dev)
     n_warm_gathers = gatherer.k if gatherer is not None else 0
+    for _, env, _, _ in envs:   # solver rows per env over the timed window: the regime the launch time belongs to, in the line itself
+        env.count_solver_rows()
     if world > 1:
         wd.at('barrier before the timed region')
         torch.distributed.barrier()
@@ -276,7 +301,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         ev.append((e0, e1))
-    run(args.warmup, args.steps)
+    run(args.settle + args.warmup, args.steps)
     for (e0, e1), (_, _, _, stream) in zip(ev, envs):
         e1.record(stream)
     torch.cuda.synchronize(dev)
@@ -297,7 +322,9 @@ def main():
     if gatherer is not None:
         g = gatherer.latest()
         gathered_ok = bool(g is not None and g.numel() == world * n and torch.isfinite(g).all())
-        times = gatherer.gather_times_us()[n_warm_gathers:]   # the collectives of the timed region, HIP events on the side stream
+        times = gatherer.gather_times_us(first=n_warm_gathers)   # the collectives of the timed region (launch index >= the warmup's count), HIP events on the side stream
+        expected = (args.settle + args.warmup + args.steps) // gather_every - n_warm_gathers
+        assert len(times) == min(expected, gatherer.KEEP), (len(times), expected)
         tmax = torch.tensor([max(times) if times else 0.0], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         rccl = {'backend': torch.distributed.get_backend(), 'world_size': torch.distributed.get_world_size(),
@@ -331,8 +358,12 @@ def main():
             'value': total_steps / wall, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            # False: the timed window starts less than 50 steps after the reset, ants still settling (launches are ~5 % shorter there)
-            'steady_state': args.warmup >= 50,
+            # True: at least 200 untimed steps (settle + warmup) lie between the reset and the timed window -- the ants stand, the contact count and
+            # with it the launch time have levelled off (launches are ~5 % shorter in the first 50 steps after a reset)
+            'steady_state': args.settle + args.warmup >= 200, 'settle_steps': args.settle,
+            # mean constraint rows per env and env step in the timed window (joint limits + 3 per contact, summed over the 4 substeps): the sweeps
+            # are serial in the rows, so this is the regime the launch time belongs to (hrl_buffers.solver_rows)
+            'solver_rows_per_env_step': {k: float(env.solver_rows.sum().item()) / (env.num_envs * args.steps) for k, env, _, _ in envs},
             'config': {'workload': f'{shard}, U(-1,1) actions pre-generated on device, auto-reset, max_episode_steps 2000',
                        'envs_per_gpu': n, 'global_envs': world * n,
                        'substeps_per_step': 4,

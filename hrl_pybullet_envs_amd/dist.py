@@ -96,6 +96,8 @@ class ReturnGatherer:
     `counts` = every rank's shard size (e.g. from `shard_range`); None = equal shards.  Uneven shards without `counts`
     would make `all_gather_into_tensor` hang on RCCL, so the sizes are exchanged once here when a group exists."""
 
+    KEEP = 4096   # collectives whose timing events are kept
+
     def __init__(self, envs, world, counts=None):
         if not isinstance(envs, (list, tuple)):
             envs = [(envs, None)]
@@ -116,17 +118,29 @@ class ReturnGatherer:
                 raise ValueError(f'counts {counts} do not describe a world of {world} with {n} envs on this rank')
         self.counts = counts
         total = sum(counts) if counts is not None else world * n
-        self.stream = torch.cuda.Stream(device=dev)
+        self.cpu = torch.device(dev).type == 'cpu'   # host tensors (the gloo tests on a box without a GPU): no streams, the collective runs in place
+        self.stream = None if self.cpu else torch.cuda.Stream(device=dev)
         self.local = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2)]
         self.out = [torch.empty(total, dtype=torch.float32, device=dev) for _ in range(2)]
         self.done_event = [None, None]
         self.k = 0          # launches so far
         self.last = None    # buffer index of the latest launch
-        self._timed = collections.deque(maxlen=4096)  # (start, end) HIP events around the latest collectives on the side stream: `gather_times_us()`
+        self._timed = collections.deque(maxlen=self.KEEP)  # (launch index, start, end) HIP events around the latest collectives on the side stream: `gather_times_us()`
 
     def launch(self):
         b = self.k & 1
         self.k += 1
+        if self.cpu:
+            import time
+            off = 0
+            for env, _ in self.parts:
+                self.local[b][off:off + env.num_envs].copy_(env.info[:, 2])
+                off += env.num_envs
+            t0 = time.perf_counter()
+            all_gather_returns(self.local[b], self.world, self.out[b], counts=self.counts)
+            self._timed.append((self.k - 1, t0, time.perf_counter()))
+            self.last = b
+            return
         if self.done_event[b] is not None:  # the collective of two launches ago read self.local[b]: order the new snapshot after it
             for env, st in self.parts:
                 (st or torch.cuda.current_stream(env.device)).wait_event(self.done_event[b])
@@ -147,13 +161,19 @@ class ReturnGatherer:
             all_gather_returns(self.local[b], self.world, self.out[b], counts=self.counts)
             self.done_event[b] = torch.cuda.Event(enable_timing=True)
             self.done_event[b].record(self.stream)
-            self._timed.append((t0, self.done_event[b]))
+            self._timed.append((self.k - 1, t0, self.done_event[b]))
         self.last = b
 
-    def gather_times_us(self):
-        """Duration of the collectives launched so far (the latest 4096), in microseconds, from HIP events on the side stream (waits for them)."""
+    def gather_times_us(self, first=0):
+        """Duration in microseconds of the collectives with launch index >= `first` (0-based; of the latest KEEP launches -- older ones are
+        forgotten, which an index, unlike a slice of this list, does not get wrong), from HIP events on the side stream (waits for those)."""
         out = []
-        for t0, t1 in self._timed:
+        for k, t0, t1 in self._timed:
+            if k < first:
+                continue
+            if self.cpu:
+                out.append((t1 - t0) * 1e6)
+                continue
             t1.synchronize()
             out.append(t0.elapsed_time(t1) * 1e3)
         return out
@@ -162,5 +182,6 @@ class ReturnGatherer:
         """The result of the most recent launch (waits for it); None before the first launch."""
         if self.last is None:
             return None
-        self.done_event[self.last].synchronize()
+        if not self.cpu:
+            self.done_event[self.last].synchronize()
         return self.out[self.last]

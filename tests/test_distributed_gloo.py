@@ -45,6 +45,84 @@ def _worker(rank, world, port, total, steps, out_dir):
 import pytest
 
 
+class _HostShard:
+    """What ReturnGatherer needs of an env, over the host executor: num_envs, device, info [N, 4] as a tensor"""
+
+    def __init__(self, e):
+        self.e, self.num_envs, self.device = e, e.N, torch.device('cpu')
+        self.info = torch.from_numpy(e.info)
+
+
+def _worker8(rank, world, port, total, steps, out_dir):
+    """A rank of the config-5 shape (BASELINE.json configs[4]): its shard half AntGather, half PointGather, stepped side by side; the running
+    episode returns of BOTH halves gathered every 5 steps by ReturnGatherer (the class bench.py uses), uneven shards."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    torch.set_num_threads(1)
+    import emu_env
+    import orc
+    from hrl_pybullet_envs_amd import _capi as K
+    from hrl_pybullet_envs_amd.dist import ReturnGatherer, init_distributed, shard_range
+    r, w, _ = init_distributed(world, backend='gloo')
+    off, cnt = shard_range(total, r, w)
+    na = cnt // 2   # ants first, points behind them, global ids contiguous over the rank's shard
+    ant = emu_env.EmuEnv(orc.default_config(K.HRL_ANT_GATHER, num_envs=max(na, 1), seed=4, auto_reset=1, env_id_offset=off, max_episode_steps=12))
+    pt = emu_env.EmuEnv(orc.default_config(K.HRL_POINT_GATHER, num_envs=cnt - na, seed=4, auto_reset=1, env_id_offset=off + na, max_episode_steps=12))
+    parts = ([(_HostShard(ant), None)] if na else []) + [(_HostShard(pt), None)]
+    g = ReturnGatherer(parts, w)   # shard sizes exchanged inside (uneven: 37 envs over 8 ranks)
+    assert g.counts == [shard_range(total, k, w)[1] for k in range(w)]
+    if na:
+        ant.reset()
+    pt.reset()
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-1, 1, (steps, total, 8)).astype(np.float32)
+    snaps = []
+    for t in range(steps):
+        if na:
+            ant.step(acts[t, off:off + na])
+        pt.step(acts[t, off + na:off + cnt, :2])
+        if (t + 1) % 5 == 0:
+            g.launch()
+            snaps.append(g.latest().numpy().copy())
+    assert len(g.gather_times_us(first=1)) == len(snaps) - 1
+    dist.barrier()
+    if r == 0:
+        np.save(os.path.join(out_dir, 'snaps.npy'), np.array(snaps))
+    np.save(os.path.join(out_dir, f'ret{r}.npy'), np.concatenate(([ant.info[:, 2]] if na else []) + [pt.info[:, 2]]))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_mixed_shards_gather_through_the_benchs_gatherer(tmp_path):
+    """The N = 8 shape of BASELINE.json configs[4] rehearsed on the CPU: 8 gloo ranks, 37 envs (shards of 5, 5, 5, 5, 5, 4, 4, 4), every shard half
+    AntGather half PointGather on the host executor, `ReturnGatherer` -- the class bench.py drives on a side stream -- exchanging the shard sizes
+    and gathering both halves' running returns.  Every snapshot is the single-process result in global-id order."""
+    total, steps, world = 37, 15, 8
+    mp.spawn(_worker8, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from hrl_pybullet_envs_amd.dist import shard_range
+    rets = np.concatenate([np.load(tmp_path / f'ret{r}.npy') for r in range(world)])
+    snaps = np.load(tmp_path / 'snaps.npy')
+    assert snaps.shape == (3, total) and np.array_equal(snaps[-1], rets) and np.all(np.isfinite(snaps))
+    # rank invariance: the same envs (same global ids, same actions) in one process
+    import emu_env
+    import orc
+    from hrl_pybullet_envs_amd import _capi as K
+    acts = np.random.RandomState(0).uniform(-1, 1, (steps, total, 8)).astype(np.float32)
+    want = np.zeros(total, np.float32)
+    for r in range(world):
+        off, cnt = shard_range(total, r, world)
+        na = cnt // 2
+        for kind, o, n, ad in ((K.HRL_ANT_GATHER, off, na, 8), (K.HRL_POINT_GATHER, off + na, cnt - na, 2)):
+            if n == 0:
+                continue
+            e = emu_env.EmuEnv(orc.default_config(kind, num_envs=n, seed=4, auto_reset=1, env_id_offset=o, max_episode_steps=12))
+            e.reset()
+            for t in range(steps):
+                e.step(acts[t, o:o + n, :ad])
+            want[o:o + n] = e.info[:, 2]
+    assert np.array_equal(rets, want)
+
+
 @pytest.mark.parametrize('total', [12, 13])  # 13: uneven shards (7 + 6), the gather pads to the largest
 def test_two_rank_sharding_matches_single_process(tmp_path, total):
     steps, world = 30, 2

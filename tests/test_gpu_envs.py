@@ -293,15 +293,44 @@ def test_bench_starts_two_ranks_from_a_bare_shell():
     assert 'rccl' not in one and one['config']['parallelism'] == 'one GPU, one process, no collective'   # nothing claimed that did not run
 
 
+def test_bench_four_ranks_of_the_config5_shape():
+    """The shape of the driver's N = 8 run of BASELINE.json configs[4], as far as a one-GPU box may go (at most six processes on the card: four
+    ranks + this one): `--gpus 4 --kind mixed` over gloo, every rank half AntGather half PointGather on two streams, the ReturnGatherer
+    gathering both halves of all four shards.  The line proves what ran: world size, every rank seen, the collectives of the timed region."""
+    out = _bench_line(['--gpus', '4', '--backend', 'gloo', '--kind', 'mixed', '--envs', '64', '--steps', '20', '--warmup', '5', '--settle', '20',
+                       '--gather-every', '5', '--no-cpu-baseline'])
+    assert out['n_gpus'] == 4 and out['config']['global_envs'] == 256 and 'mixed batch' in out['metric']
+    r = out['rccl']
+    assert r['world_size'] == 4 and r['ranks_seen'] == [0, 1, 2, 3] and len(r['devices']) == 4 and r['gather_count'] == 4 and r['gather_bytes_per_rank'] == 4 * 64
+    assert out['config']['returns_gathered_ok'] is True and set(out['solver_rows_per_env_step']) == {'gather', 'point'}
+
+
+def test_bench_default_line_is_a_steady_state_line():
+    """Whatever the driver passes for --warmup, the timed window starts 300 untimed steps after the reset (--settle): `steady_state` is true, and
+    the line carries the regime it was measured in -- the mean solver rows per env step (a standing ant: four feet on the ground and a few joints
+    near their stops: ~50 rows over four substeps; just after a reset: fewer)."""
+    out = _bench_line(['--steps', '20', '--warmup', '5', '--no-cpu-baseline'])   # the driver's flags
+    assert out['steady_state'] is True and out['settle_steps'] == 300 and out['warmup'] == 5 and out['steps'] == 20
+    rows = out['solver_rows_per_env_step']['gather']
+    assert 30 < rows < 120, rows
+    cold = _bench_line(['--steps', '20', '--warmup', '5', '--settle', '0', '--no-cpu-baseline'])
+    assert cold['steady_state'] is False and cold['solver_rows_per_env_step']['gather'] < rows
+
+
 def test_bench_watchdog_names_the_stage_a_rank_hangs_in():
-    """A rank that stops making progress exits 3 with the stage it hung in (here: a one-second limit that the run cannot meet)."""
+    """A rank that stops making progress exits 3 with the stage it hung in (a test hook makes it hang); a long run that keeps going is left alone."""
+    import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs', '4096', '--steps', '200000', '--warmup', '5', '--no-cpu-baseline',
-                        '--watchdog', '8'], capture_output=True, text=True, timeout=300)
-    assert p.returncode == 3 and 'watchdog: rank 0 still in stage "timed region"' in p.stderr, (p.returncode, p.stderr[-500:])
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs', '512', '--steps', '50', '--warmup', '5', '--no-cpu-baseline',
+                        '--watchdog', '6', '--stall-in', 'warmup'], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3 and 'watchdog: rank 0 made no progress in stage "warmup" for 6 s' in p.stderr, (p.returncode, p.stderr[-500:])
+    # a stall detector, not a budget: a run that takes several times the limit but keeps going is left alone
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs', '4096', '--steps', '150000', '--warmup', '5', '--no-cpu-baseline',
+                        '--watchdog', '3'], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])['steps'] == 150000, (p.returncode, p.stderr[-500:])
 
 
 def test_gymnasium_adapter_on_a_real_batched_env():
