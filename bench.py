@@ -295,12 +295,10 @@ def main():
         wd.at('barrier before the timed region')
         torch.distributed.barrier()
     wd.at('timed region')
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in envs]  # made before the clock starts (hipEventCreate is host time, not step time)
     t0 = time.perf_counter()
-    ev = []
-    for _, _, _, stream in envs:  # HIP events on the stream each kernel is launched on
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for (e0, _), (_, _, _, stream) in zip(ev, envs):  # HIP events on the stream each kernel is launched on
         e0.record(stream)
-        ev.append((e0, e1))
     run(args.settle + args.warmup, args.steps)
     for (e0, e1), (_, _, _, stream) in zip(ev, envs):
         e1.record(stream)

@@ -11,7 +11,7 @@ _lib = None
 
 # every symbol include/hrl_envs.h declares
 SYMBOLS = ['hrl_default_config', 'hrl_obs_dim', 'hrl_act_dim', 'hrl_items_stride', 'hrl_create', 'hrl_destroy', 'hrl_reset', 'hrl_step',
-           'hrl_get_state', 'hrl_set_state', 'hrl_set_goals', 'hrl_next_target', 'hrl_last_error', 'hrl_backend', 'hrl_buffers_init', 'hrl_observe']
+           'hrl_get_state', 'hrl_set_state', 'hrl_set_goals', 'hrl_next_target', 'hrl_last_error', 'hrl_backend', 'hrl_buffers_init', 'hrl_observe', 'hrl_update_config']
 
 
 class HrlError(RuntimeError):
@@ -31,6 +31,7 @@ def lib():
         L.hrl_backend.restype = C.c_char_p
         L.hrl_create.argtypes = [C.POINTER(K.hrl_config), C.POINTER(C.c_void_p)]
         L.hrl_destroy.argtypes = [C.c_void_p]
+        L.hrl_update_config.argtypes = [C.c_void_p, C.POINTER(K.hrl_config), C.c_void_p]
         L.hrl_reset.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p]
         L.hrl_step.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p]
         L.hrl_observe.argtypes = [C.c_void_p, C.POINTER(K.hrl_buffers), C.c_void_p, C.c_void_p]

@@ -63,7 +63,12 @@ class GymnasiumVectorEnv:
             info['final_observation'][i] (alias 'final_obs')   the observation its episode ended with,
             info['_final_observation'][i] (alias '_final_obs') True,
             info['final_info'] = {'episode_return', 'episode_length', 'food_rew', 'dead_rew', '_mask'}   per-env values of the finished episodes.
-    Tensors stay on the GPU (`numpy=True`: host numpy arrays instead, one synchronisation per step)."""
+    Tensors stay on the GPU (`numpy=True`: host numpy arrays instead, one synchronisation per step).
+
+    ALIASING: `obs`, `reward` and the entries of `final_info` are the env's own output tensors, OVERWRITTEN IN PLACE by the next step -- a trainer that
+    keeps them across steps (a rollout buffer) must `.clone()` them (with `numpy=True` every array is a fresh host copy).  `final_observation` is
+    a new tensor every step: the rows of the envs that finished, zeros elsewhere (gymnasium hands out None / zeros for those rows; the kernel's
+    persistent buffer would show the terminal observation of some EARLIER episode there)."""
 
     metadata = {'autoreset_mode': 'same_step', 'render_modes': ['rgb_array']}
     spec = None
@@ -102,7 +107,8 @@ class GymnasiumVectorEnv:
         obs, rew, done, info = self.env.step(actions)
         d = done.bool()
         truncated = info['TimeLimit.truncated'].bool()
-        out = {'final_observation': self._out(info['final_observation']), '_final_observation': self._out(d),
+        final = torch.where(d[:, None], info['final_observation'], torch.zeros((), dtype=obs.dtype, device=obs.device))   # fresh, rows that did not finish zeroed
+        out = {'final_observation': self._out(final), '_final_observation': self._out(d),
                'final_info': {'episode_return': self._out(info['episode_return']), 'episode_length': self._out(info['episode_length']),
                               'food_rew': self._out(info['food_rew']), 'dead_rew': self._out(info['dead_rew']), '_mask': self._out(d)}}
         out['final_obs'], out['_final_obs'] = out['final_observation'], out['_final_observation']

@@ -356,6 +356,25 @@ int hrl_destroy(hrl_handle *h) {
     return HRL_OK;
 }
 
+int hrl_update_config(hrl_handle *h, const hrl_config *cfg, void *stream) {
+    if (!h) return fail(HRL_ERR_BAD_ARG, "hrl_update_config: null handle");
+    const std::string why = validate(cfg);
+    if (!why.empty()) return fail(HRL_ERR_BAD_ARG, "hrl_update_config: " + why);
+    if (cfg->env_kind != h->cfg.env_kind || cfg->num_envs != h->cfg.num_envs || obs_dim(cfg) != obs_dim(&h->cfg) || act_dim(cfg) != act_dim(&h->cfg) ||
+        items_stride(cfg) != items_stride(&h->cfg))
+        return fail(HRL_ERR_BAD_ARG, "hrl_update_config: env_kind, num_envs, the observation / action width and the items stride belong to the buffers and cannot change on a live handle");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device)
+        return fail(HRL_ERR_BAD_ARG, "hrl_update_config: the handle was created on HIP device " + std::to_string(h->device) + ", the current device is " + std::to_string(cur));
+    DevCfg dc;
+    build_devcfg(*cfg, dc);
+    const hipError_t e = hipMemcpyAsync(h->d_dc, &dc, sizeof(DevCfg), hipMemcpyHostToDevice, (hipStream_t)stream); /* pageable source: staged before the call returns */
+    if (e != hipSuccess) return hip_fail(e, "hrl_update_config: device constants");
+    h->cfg = *cfg; h->dc = dc;
+    h->group = cfg->env_kind == HRL_POINT_GATHER || cfg->model.step_group == 1 ? 1 : 4;
+    return HRL_OK;
+}
+
 static bool needs_items(const DevCfg &dc) {
     return dc.kind == HRL_ANT_GATHER || dc.kind == HRL_POINT_GATHER || (dc.kind == HRL_ANT_FLAGRUN && dc.flag_path_on);
 }

@@ -1905,9 +1905,10 @@ HRL_DEV void phase_calc_state(const DevCfg &c, WaveLds &L, int lane, bool use_fe
     mine = (lane == 5) ? 0.3f * vz : mine;
     mine = (lane == 6) ? rpy[0] : mine;
     mine = (lane == 7) ? rpy[1] : mine;
-    if (lane >= 24 && lane < 28) {
+    if (lane >= 24 && lane < 28) { /* robot.feet_contact as the LAST step left it (aux[1] bits 28..31): upstream's step() calls calc_state() before it
+                                      refreshes the flags from the step's contacts, so the observation shows the previous step's (step_entry) */
         const int l = lane - 24;
-        mine = (use_feet && (L.gtouch[2 + 3 * l] || L.gtouch[3 + 3 * l])) ? 1.f : 0.f;
+        mine = (use_feet && ((L.aux[1] >> (28 + l)) & 1)) ? 1.f : 0.f;
     }
     if (lane < 28) L.s28[lane] = clampf(mine, -5.f, 5.f);
     L.scal[3] = wtd; L.scal[4] = rpy[2]; L.scal[5] = (float)nlim; L.scal[6] = cx; L.scal[7] = cy;
@@ -2097,7 +2098,7 @@ HRL_DEV void compute_obs(X &x, const DevCfg &c, long long env, bool step_mode, i
     x.each([&](int lane) { if (lane < 4) L.flags[lane] = 0; });
     if (KIND == 3) x.each([&](int lane) { phase_point_state(c, L, lane); });
     else {
-        const bool feet = step_mode && (KIND == 2 || KIND == 5); /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather */
+        const bool feet = KIND == 2 || KIND == 5; /* ant_gather_env.py:105-111: feet flags stay 0 in AntGather; a reset clears them (upstream robot_specific_reset) */
         x.each([&](int lane) { phase_calc_state<KIND>(c, L, lane, feet, centroid, mtx, mty); });
     }
     x.stamp(21);
@@ -2194,7 +2195,11 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
                 L.items[2 * i] = px; L.items[2 * i + 1] = py;
             }
         });
-    x.each([&](int lane) { if (lane == 0) L.aux[0] = 0; if (lane == 2) L.aux[2] = L.aux[2] + 1; });
+    x.each([&](int lane) {
+        if (lane == 0) L.aux[0] = 0;
+        if (lane == 1 && (KIND == 2 || KIND == 5)) L.aux[1] = L.aux[1] & 0x0fffffff; /* feet_contact = 0 (upstream robot_specific_reset) */
+        if (lane == 2) L.aux[2] = L.aux[2] + 1;
+    });
     compute_obs<KIND>(x, c, env, false);
     x.each([&](int lane) {
         if (lane != 31) return;
@@ -2498,7 +2503,17 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             if (b.truncated) b.truncated[eo] = (uint8_t)L.flags[2];
             if (b.rows) b.rows[eo] += rows_acc;
         }
-        if (lane == 1) L.aux[1] = L.aux[1] + 1;
+        if (lane == 1) {
+            int a1 = L.aux[1] + 1;
+            if (KIND == 2 || KIND == 5) { /* the kinds whose observation carries feet contacts: the step's flags (feet against the floor in its last collision pass,
+                                             upstream WalkerBaseBulletEnv.step AFTER calc_state) ride in the top four bits for the next step's observation */
+                int bits = 0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) bits |= ((L.gtouch[2 + 3 * l] | L.gtouch[3 + 3 * l]) & 1) << l;
+                a1 = (a1 & 0x0fffffff) | (bits << 28);
+            }
+            L.aux[1] = a1;
+        }
         if (lane == 2 && (KIND == 0 || KIND == 2 || KIND == 4 || KIND == 5)) L.st[31] = L.red[0];
         if (lane == 3) L.st[29] = L.red[1];
         if (lane == 8 && KIND == 5) L.aux[3] = L.flags[4];

@@ -50,20 +50,17 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         self._finish_init(cfg, num_envs, device, seed)
 
     def set_reward_weights(self, ant_env_rew_weight=None, path_rew_weight=None, dist_rew_weight=None, goal_reach_rew=None):
-        """Changes the reward weights of THIS env (None: keep).  They are constants of the library handle: a running env gets a new handle with
-        the same buffers' contents.  Switching a path reward on for an env built without one (shared goal list, no record of where the robot stood
-        when it got its goal) starts the path bookkeeping at the next goal / reset."""
+        """Changes the reward weights of THIS env (None: keep), in place on a running env (hrl_update_config) -- what assigning to the class
+        attribute does in the reference, whose step() reads it every time.  Switching a path reward on for an env built without one (shared goal
+        list, no record of where the robot stood when it got its goal) starts the path bookkeeping at the next goal / reset."""
         c = self._cfg
         new = [c.flag_ant_env_rew_weight if ant_env_rew_weight is None else float(ant_env_rew_weight),
                c.flag_path_rew_weight if path_rew_weight is None else float(path_rew_weight),
                c.flag_dist_rew_weight if dist_rew_weight is None else float(dist_rew_weight),
                c.flag_goal_reach_rew if goal_reach_rew is None else float(goal_reach_rew)]
-        sd = self._env.state_dict() if self._env is not None else None
         c.flag_ant_env_rew_weight, c.flag_path_rew_weight, c.flag_dist_rew_weight, c.flag_goal_reach_rew = new
-        if sd is not None:
-            self._env.close()
-            self._env = None
-            self._backend().load_state_dict(sd, strict=False)
+        if self._env is not None:
+            self._env.update_config(c)
 
     reward_weights = property(lambda self: dict(ant_env_rew_weight=self._cfg.flag_ant_env_rew_weight, path_rew_weight=self._cfg.flag_path_rew_weight,
                                                 dist_rew_weight=self._cfg.flag_dist_rew_weight, goal_reach_rew=self._cfg.flag_goal_reach_rew))

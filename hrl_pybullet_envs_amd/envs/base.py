@@ -64,18 +64,16 @@ class BatchedGymEnv:
 
     @max_episode_steps.setter
     def max_episode_steps(self, n):
-        """The step limit of gym's TimeLimit, applied inside the kernel (0: none).  On a running env the simulation carries over."""
+        """The step limit of gym's TimeLimit, applied inside the kernel (0: none).  On a running env it takes effect with the next step; the
+        simulation, the tensors handed out and the host buffers of step_host() stay as they are."""
         n = int(n)
         if n < 0:
             raise ValueError('max_episode_steps must be >= 0 (0: no limit)')
         if n == self._cfg.max_episode_steps:
             return
-        sd = self._env.state_dict() if self._env is not None else None
         self._cfg.max_episode_steps = n
-        if sd is not None:   # the limit is a constant of the library handle: a new handle, the same buffers' contents
-            self._env.close()
-            self._env = None
-            self._backend().load_state_dict(sd, strict=False)
+        if self._env is not None:   # a constant of the library handle: replaced in place (hrl_update_config), buffers and pinned host memory stay
+            self._env.update_config(self._cfg)
 
     def _finish_init(self, cfg, num_envs, device, seed):
         if num_envs < 1:

@@ -7,5 +7,5 @@ from enum import Enum
 
 
 class PositionEncoding(Enum):
-    normed_vec = 0  # normalized vector from robot position to target
-    angle = 1       # sin and cos of angle to target
+    normed_vec = 0  # the two target entries of the observation are the unit vector robot -> target (ant_maze_bullet_env.py:128-129)
+    angle = 1       # they are (sin, cos) of the target's bearing relative to the robot's heading (:130-131)

@@ -105,6 +105,21 @@ class BatchedEnv:
     truncated = property(lambda self: self._device_out('truncated'))
     goal = property(lambda self: self._device_out('goal'))  # AntFlagrun only: [N, 4] = goal x, y | switched to it in the last step | steps since the goal changed
 
+    def update_config(self, cfg):
+        """A changed copy of this env's config takes effect for the launches that follow on the current stream (hrl_update_config): the step limit,
+        reward weights, tolerances, engine parameters ... of a LIVE env -- the simulation, every tensor and the pinned host buffers stay as they
+        are.  What the tensors' shapes depend on cannot change (the library refuses and nothing happens)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hrl_update_config(self._h, C.byref(cfg), self._stream()))
+        self.cfg = cfg
+        uses = cfg.env_kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) or \
+            (cfg.env_kind == K.HRL_ANT_FLAGRUN and (bool(cfg.flag_manual_goals) or cfg.flag_max_target_dist > 0 or cfg.flag_path_rew_weight != 0))
+        if uses != self._uses_items:   # a flagrun env whose path reward was switched on / off: the items record joins / leaves the launches
+            self._uses_items = uses
+            self._bufs.items = self.items.data_ptr() if uses else None
+            if self._host is not None:
+                self._hbufs.items = self._bufs.items
+
     def count_solver_rows(self, on=True):
         """Diagnostic: from now on every step ADDS to `self.solver_rows` [N] (int32, zeroed here) the constraint rows each env's solver held
         -- joint limits + 3 per contact over the step's substeps (hrl_buffers.solver_rows).  What a launch costs depends on it."""

@@ -51,7 +51,8 @@ extern "C" {
 #define HRL_MAX_ITEMS 64    /* n_food + n_poison (ant_gather_env.py:16-17 takes any counts; an item is a lane of the wave here) */
 #define HRL_MAX_BINS 64     /* n_bins / sensor_bins */
 #define HRL_MAX_OBS 256     /* widest observation: AntMazeMj with 64 bins = 29 + 3 * 64 + 1 = 222 */
-#define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime, episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
+#define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime (AntMaze / AntFlagrun: low 28 bits; bits 28..31 = the feet contacts of the last step, what upstream's
+                               robot.feet_contact holds when the next step's calc_state() reads it), episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
 #define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
 #define HRL_MAX_TARGETS 64  /* maze kinds: `targets` of the constructor (ant_maze_bullet_env.py:23) */
 #define HRL_MAX_GOALS 61    /* flagrun manual goals (flag_goal_capacity) */
@@ -223,6 +224,13 @@ int hrl_items_stride(const hrl_config *cfg);
 /* Replaces env construction (gym.make / Env.__init__ + first BulletClient): validates and copies cfg. */
 int hrl_create(const hrl_config *cfg, hrl_handle **out);
 int hrl_destroy(hrl_handle *h);
+
+/* Replaces the handle's config by `cfg`, on `stream` (in order with the launches queued there): what changes on a LIVE env in the reference --
+ * `env.max_episode_steps` of gym's TimeLimit, AntFlagrunBulletEnv's class-level reward weights (ant_flagrun_env.py:157-160, read in every step),
+ * tolerances, timeouts, the engine parameters of hrl_model ... -- without a new handle: state, items, aux and every buffer of the caller stay as
+ * they are.  env_kind, num_envs and what the buffers' shapes depend on (observation / action width, items stride) must be what they were
+ * (HRL_ERR_BAD_ARG, nothing changed).  The constants are copied at the call (cfg may be freed on return). */
+int hrl_update_config(hrl_handle *h, const hrl_config *cfg, void *stream);
 
 /* Replaces Env.reset() (ant_gather_env.py:68-74, gather_base.py:67-72, ant_maze_bullet_env.py:104-121,
  * upstream WalkerBaseBulletEnv.reset): envs with mask[i] != 0 (all when mask == NULL) are put in the

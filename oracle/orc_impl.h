@@ -1095,6 +1095,11 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                 const int k = f - 1 - W->n_planes - W->n_boxes;
                 REAL lo[3], hi[3];
                 if (items_xy[2 * k] != items_xy[2 * k] || items_xy[2 * k + 1] != items_xy[2 * k + 1]) continue; /* a cube at a NaN place is nowhere (a clamp between NaN bounds would put it everywhere) */
+                { /* broad phase: every point of every shape lies within `reach` of the torso centre (hip 0.283 + aux 0.283 + foot 0.566 + radius + contact
+                     distance), so a cube farther than that (+ its half extent) along x or y touches nothing -- the same list as testing it */
+                    const REAL reach = R_(0.2) * R_(1.41421356237309504880) + K->L1 + K->L2 + K->r_caps + K->cdist + R_(0.02) + ORC_ITEM_HALF;
+                    if (!(RFABS(pos[0] - items_xy[2 * k]) < reach) || !(RFABS(pos[1] - items_xy[2 * k + 1]) < reach)) continue;
+                }
                 FN(item_box)(items_xy + 2 * k, lo, hi);
                 dist = FN(shape_vs_box)(D, pos, s, c, rad, lo, hi, c, n); surface = ORC_SURF_OF_ITEM(k);
             }
@@ -1489,6 +1494,13 @@ static void FN(flag_current_goal)(const hrl_config *cfg, const REAL *items, cons
     else FN(flag_goal)(cfg, (uint32_t)aux[2], (uint32_t)aux[3] & 0xffffu, g);
 }
 
+/* robot.feet_contact as the last step left it: bits 28..31 of aux[1] in the kinds whose observation carries the flags (AntMaze, AntFlagrun).
+ * Upstream WalkerBaseBulletEnv.step calls calc_state() BEFORE it refreshes the flags from the step's contacts, so an observation shows the
+ * flags of the step before; AntGather never refreshes them (ant_gather_env.py:105-111). */
+static void FN(stored_feet)(const hrl_config *cfg, const int32_t *aux, REAL *feet) {
+    const int on = cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_FLAGRUN;
+    for (int l = 0; l < 4; ++l) feet[l] = (on && (((uint32_t)aux[1] >> (28 + l)) & 1u)) ? R_(1) : R_(0);
+}
 /* observation of the CURRENT state (used by reset and by step) for ant kinds that do not need step-only data */
 static void FN(make_obs)(const FN(orc_env) * E, const REAL *st, const REAL *items, const int32_t *aux, const REAL *feet,
                          REAL *obs, REAL *wtd_out, int *nlim_out, REAL *s28_out, REAL *centroid_out) {
@@ -1573,6 +1585,7 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
         for (int i = 0; i < cfg->n_food + cfg->n_poison; ++i) FN(respawn_item)(cfg, env, ep, 1, i, origin, items + 2 * i);
     }
     aux[0] = 0; aux[2] = (int32_t)(ep + 1); /* NB: the flagrun goal stream is keyed by the NEW episode index */
+    if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_FLAGRUN) aux[1] &= 0x0fffffff; /* robot.feet_contact = 0 (upstream robot_specific_reset) */
     if (cfg->env_kind == HRL_ANT_FLAGRUN && items && FN(flag_path_on)(cfg)) { /* an env of the shared goal list without a path reward keeps nothing in the record */
         if (cfg->flag_manual_goals) { /* the walk target and the path-reward state survive the reset (:149-152), pending goals do not */
             for (int i = HRL_FLAG_PENDING_OFF; i < orc_items_stride(cfg); ++i) items[i] = 0;
@@ -1585,7 +1598,8 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
             FN(orc_flag_set_target_state)(g2, st, items + HRL_FLAG_START_OFF);
         }
     }
-    REAL feet[4] = {0, 0, 0, 0}, wtd = 0, cen[2] = {0, 0};
+    REAL feet[4], wtd = 0, cen[2] = {0, 0};
+    FN(stored_feet)(cfg, aux, feet); /* cleared above */
     FN(make_obs)(E, st, items, aux, feet, obs, &wtd, 0, 0, cen);
     const REAL dt = E->K.h * R_(E->K.nsub);
     if (cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER) st[HRL_POTENTIAL_OFF] = 0; /* never read */
@@ -1636,14 +1650,16 @@ int FN(orc_flag_next_target)(const hrl_config *cfg, int64_t env, const REAL *st,
 void FN(orc_env_set_goals_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, const REAL *goals_xy, int n_goals, REAL *obs) {
     FN(orc_flag_goals_assign)(&E->cfg, items, aux, goals_xy, n_goals);
     FN(orc_flag_next_target)(&E->cfg, env, st, items, aux);
-    REAL feet[4] = {0, 0, 0, 0};
+    REAL feet[4];
+    FN(stored_feet)(&E->cfg, aux, feet); /* next_target() -> robot.calc_state() with the flags as the last step left them */
     FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0);
 }
 /* hrl_next_target() of include/hrl_envs.h: `env.next_target()` alone; ok = 0 where the reference raises IndexError */
 void FN(orc_env_next_target_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *items, int32_t *aux, REAL *obs, uint8_t *ok) {
     const int r = FN(orc_flag_next_target)(&E->cfg, env, st, items, aux);
     if (ok) *ok = (uint8_t)r;
-    REAL feet[4] = {0, 0, 0, 0};
+    REAL feet[4];
+    FN(stored_feet)(&E->cfg, aux, feet);
     FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0);
 }
 
@@ -1652,7 +1668,8 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
                           REAL *obs, REAL *rew_out, uint8_t *done_out, REAL *info, REAL *final_obs, uint8_t *truncated, REAL *goal_out, int32_t *rows_out) {
     const hrl_config *cfg = &E->cfg;
     const FN(orc_consts) *K = &E->K;
-    REAL q[15], u[14], feet[4] = {0, 0, 0, 0};
+    REAL q[15], u[14], feet[4], feet_new[4] = {0, 0, 0, 0};
+    FN(stored_feet)(cfg, aux, feet); /* what calc_state() sees: the flags of the step BEFORE (upstream refreshes them after calc_state) */
     uint32_t t_life = (uint32_t)aux[1];
     const int gather = cfg->env_kind == HRL_ANT_GATHER || cfg->env_kind == HRL_POINT_GATHER;
     const int n_items = gather ? cfg->n_food + cfg->n_poison : 0;
@@ -1670,7 +1687,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         for (int j = 0; j < NJ; ++j) tau[j] = R_(cfg->model.torque_scale) * FN(clampr)(act[j], -1, 1);
         int gt[13];
         for (int s = 0; s < K->nsub; ++s) { FN(orc_ant_substep)(K, &E->W, q, u, tau, gather ? items : 0, n_items, gt, &dbg); n_rows_step += dbg.n_rows; }
-        for (int l = 0; l < 4; ++l) feet[l] = (gt[2 + 3 * l] || gt[3 + 3 * l]) ? R_(1) : R_(0);
+        for (int l = 0; l < 4; ++l) feet_new[l] = (gt[2 + 3 * l] || gt[3 + 3 * l]) ? R_(1) : R_(0); /* this step's: feet against the floor in its last collision pass */
     }
     for (int i = 0; i < 15; ++i) st[i] = q[i];
     for (int k = 0; k < 3; ++k) { st[HRL_QVEL_OFF + 3 + k] = u[k]; st[HRL_QVEL_OFF + k] = u[3 + k]; }
@@ -1719,7 +1736,8 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
             cur = aux[3] & 0xffff;
         } else cur = manual ? goals_left : budget - goals_left;
         aux[3] = (int32_t)(((uint32_t)cur & 0xffffu) | ((uint32_t)steps << 16) | ((uint32_t)rewarded << 31));
-        FN(make_obs)(E, st, items, aux, feet, obs, 0, 0, 0, 0); /* calc_state w.r.t. the (possibly new) goal */
+        FN(make_obs)(E, st, items, aux, retarget ? feet_new : feet, obs, 0, 0, 0, 0); /* the state of super().step(), or -- a switch -- next_target()'s calc_state()
+                                                                                        w.r.t. the new goal, which runs after the flags were refreshed */
         if (goal_out) { /* info['target'] = self.goal on the steps that switched goals (:191,199) */
             REAL g2[2];
             FN(flag_current_goal)(cfg, items, aux, g2);
@@ -1749,6 +1767,11 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         FN(orc_maze_task)(cfg, s28, inner, idone, st, rpy[2], tgt, wtd, aux[0] + 1, &FN(maze_lines)[0][0], 7, 3, obs, &rew, &done);
     }
     aux[0] += 1; aux[1] += 1;
+    if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_FLAGRUN) { /* robot.feet_contact for the next step's observation */
+        uint32_t bits = 0;
+        for (int l = 0; l < 4; ++l) bits |= (feet_new[l] != 0 ? 1u : 0u) << l;
+        aux[1] = (int32_t)(((uint32_t)aux[1] & 0x0fffffffu) | (bits << 28));
+    }
     int trunc = 0; /* gym TimeLimit, __init__.py:15 (gym.wrappers.TimeLimit: info['TimeLimit.truncated'] = not done; done = True) */
     if (cfg->max_episode_steps > 0 && aux[0] >= cfg->max_episode_steps) { trunc = !done; done = 1; }
     st[HRL_EPRET_OFF] += rew;
@@ -1774,7 +1797,8 @@ void FN(orc_reset_batch)(const hrl_config *cfg, REAL *state, REAL *items, int32_
                               items ? items + (size_t)i * orc_items_stride(cfg) : 0, aux + (size_t)i * HRL_AUX_STRIDE, obs + (size_t)i * od);
     }
 }
-/* hrl_observe of include/hrl_envs.h: the observation of the records as they stand, nothing else written (feet-contact entries 0) */
+/* hrl_observe of include/hrl_envs.h: the observation of the records as they stand, nothing else written (feet-contact entries: the flags the
+ * last step left, as robot.feet_contact holds them in the reference; 0 after a reset) */
 void FN(orc_observe_batch)(const hrl_config *cfg, const REAL *state, const REAL *items, const int32_t *aux, const uint8_t *mask, REAL *obs) {
     FN(orc_env) E;
     FN(orc_env_init)(cfg, &E);
@@ -1782,7 +1806,8 @@ void FN(orc_observe_batch)(const hrl_config *cfg, const REAL *state, const REAL 
     REAL zero_items[2 * HRL_MAX_ITEMS] = {0};
     for (int i = 0; i < cfg->num_envs; ++i) {
         if (mask && !mask[i]) continue;
-        REAL feet[4] = {0, 0, 0, 0};
+        REAL feet[4];
+        FN(stored_feet)(cfg, aux + (size_t)i * HRL_AUX_STRIDE, feet);
         FN(make_obs)(&E, state + (size_t)i * HRL_STATE_STRIDE, items ? items + (size_t)i * orc_items_stride(cfg) : zero_items, aux + (size_t)i * HRL_AUX_STRIDE, feet, obs + (size_t)i * od, 0, 0, 0, 0);
     }
 }

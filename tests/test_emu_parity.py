@@ -820,3 +820,33 @@ def test_capsule_mid_sections_against_cubes_and_the_maze_box(group):
             for name in ('state', 'aux', 'obs', 'rew', 'done', 'info'):
                 assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, k, name)
     assert mid >= 25, mid
+
+
+def test_feet_contact_flags_show_the_previous_step():
+    """Upstream WalkerBaseBulletEnv.step (recalled): `state = robot.calc_state()` comes BEFORE the loop that refreshes
+    `robot.feet_contact` from the step's contacts, so obs[22:26] of AntMaze / obs[24:28] of AntFlagrun are the flags of the step before
+    (zeros in the first step after a reset: robot_specific_reset); AntGather never refreshes them (ant_gather_env.py:105-111).  The flags of
+    a step ride in bits 28..31 of aux[1]."""
+    for kind, lo in ((K.HRL_ANT_MAZE, 22), (K.HRL_ANT_FLAGRUN, 24)):
+        cfg = orc.default_config(kind, num_envs=6, seed=2, auto_reset=1, max_episode_steps=30)
+        o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+        o.reset(); e.reset()
+        assert np.all(o.obs[:, lo:lo + 4] == 0) and np.all((o.aux[:, 1].view(np.uint32) >> 28) == 0)
+        seen = 0
+        for t in range(70):
+            before = (o.aux[:, 1].view(np.uint32) >> 28) & 0xf
+            a = np.zeros((6, 8), np.float32)
+            o.step(a); e.step(a)
+            assert np.array_equal(o.obs, e.obs, equal_nan=True) and np.array_equal(o.aux, e.aux)
+            cont = o.done == 0   # an env that ended was reset in place: its row is the next episode's first observation, flags 0
+            want = ((before[:, None] >> np.arange(4)) & 1).astype(np.float32)
+            assert np.array_equal(o.obs[cont, lo:lo + 4], want[cont]) and np.all(o.obs[~cont, lo:lo + 4] == 0)
+            assert np.all(((o.aux[~cont, 1].view(np.uint32) >> 28) & 0xf) == 0)
+            assert np.all((o.aux[:, 1] & 0x0fffffff) == t + 1)   # the lifetime count underneath
+            seen += int(want.sum())
+        assert seen > 200   # standing ants: feet on the floor most of the time
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=4, seed=2, auto_reset=1)
+    o = orc.OracleEnv(cfg, np.float32); o.reset()
+    for t in range(20):
+        o.step(np.zeros((4, 8), np.float32))
+    assert np.all(o.obs[:, 22:26] == 0) and np.all(o.aux[:, 1] == 20)

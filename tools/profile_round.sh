@@ -6,7 +6,7 @@ O=${1:?out dir}; mkdir -p $O
 # every kind is SETTLED before the window the counters are taken from (300 untimed steps: a PointBot has reached the walls, ants have
 # tumbled; round 3 profiled the first 60 steps after a reset, a different regime than the bench line's): tools/summarize_profile.py
 # condenses the LAST 50 launches of every pass.
-B="python3 bench.py --steps 50 --warmup 300 --no-cpu-baseline --kind ${2:-gather} --envs ${3:-4096}"
+B="python3 bench.py --steps 50 --warmup 300 --settle 0 --no-cpu-baseline --kind ${2:-gather} --envs ${3:-4096}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/bench_trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/f.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/w.log 2>&1 || exit 1
