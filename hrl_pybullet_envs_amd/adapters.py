@@ -112,6 +112,8 @@ class GymnasiumVectorEnv:
                'final_info': {'episode_return': self._out(info['episode_return']), 'episode_length': self._out(info['episode_length']),
                               'food_rew': self._out(info['food_rew']), 'dead_rew': self._out(info['dead_rew']), '_mask': self._out(d)}}
         out['final_obs'], out['_final_obs'] = out['final_observation'], out['_final_observation']
+        if 'retargeted' in info:   # AntFlagrun: info['target'] of the envs whose step switched goals (ant_flagrun_env.py:191,199), gymnasium's masked form
+            out['target'], out['_target'] = self._out(info['target'].clone()), self._out(info['retargeted'] != 0)
         return self._out(obs), self._out(rew), self._out(d & ~truncated), self._out(truncated), out
 
     def render(self):
@@ -157,6 +159,12 @@ class SB3VecEnv:
             infos = [{'food_rew': f, 'dead_rew': d} for f, d in zip(info['food_rew'].cpu().tolist(), info['dead_rew'].cpu().tolist())]
         else:
             infos = [{} for _ in range(self.num_envs)]
+        if 'retargeted' in info:   # AntFlagrun: `i['target'] = self.goal` on the steps in which the goal was switched (ant_flagrun_env.py:191,199)
+            sw = info['retargeted'].cpu().numpy() != 0
+            if sw.any():
+                tg = info['target'].cpu().numpy()
+                for i in np.nonzero(sw)[0]:
+                    infos[i]['target'] = (float(tg[i, 0]), float(tg[i, 1]))
         if dones.any():
             idx = np.nonzero(dones)[0]
             fin = info['final_observation'][done.bool()].cpu().numpy()
