@@ -50,6 +50,7 @@ class hrl_config(C.Structure):
                 ('flag_switch_on_collision', C.c_int32), ('flag_enclosed', C.c_int32), ('flag_max_target_dist', C.c_float),
                 ('flag_manual_goals', C.c_int32), ('flag_goal_capacity', C.c_int32),
                 ('flag_ant_env_rew_weight', C.c_float), ('flag_path_rew_weight', C.c_float), ('flag_dist_rew_weight', C.c_float), ('flag_goal_reach_rew', C.c_float),
+                ('walker_electricity_cost', C.c_float), ('walker_stall_torque_cost', C.c_float), ('walker_joints_at_limit_cost', C.c_float),
                 ('model', hrl_model)]
 
     def copy(self):

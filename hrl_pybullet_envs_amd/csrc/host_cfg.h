@@ -63,6 +63,8 @@ inline int default_config(int32_t kind, hrl_config *c) {
     c->flag_size = 10.f; c->flag_max_targets = 100; c->flag_timeout = 200; c->flag_switch_on_collision = 1; c->flag_enclosed = 1;
     c->flag_goal_capacity = 15;
     c->flag_ant_env_rew_weight = 1.f; c->flag_path_rew_weight = 0.f; c->flag_dist_rew_weight = 0.f; c->flag_goal_reach_rew = 5000.f; /* ant_flagrun_env.py:157-160 */
+    c->walker_electricity_cost = -2.0f; c->walker_stall_torque_cost = -0.1f; c->walker_joints_at_limit_cost = -0.1f; /* upstream WalkerBaseBulletEnv */
+    if (kind == HRL_ANT_FLAGRUN) { c->walker_electricity_cost = 0.f; c->walker_stall_torque_cost = 0.f; c->walker_joints_at_limit_cost = 0.f; } /* ant_flagrun_env.py:133-135 */
     if (kind == HRL_ANT_FLAGRUN) { /* ant_flagrun_env.py:14-16; arena (size+2)^2 :59-61; start (0,0,0.25) :144 */
         c->use_sensor = 0; c->n_bins = 8; c->sensor_span = 3.14159265358979323846f; c->sensor_range = 4.f; c->tol = 0.5f;
         c->world_size[0] = 12.f; c->world_size[1] = 12.f; c->start_pos[2] = 0.25f;
@@ -207,6 +209,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.flag_switch = c.flag_switch_on_collision; d.flag_mtd = c.flag_max_target_dist; d.flag_manual = c.flag_manual_goals;
     d.self_collision = m.self_collision; d.item_collision = m.item_collision; d.mu_self = m.friction_robot * m.friction_robot;
     d.flag_path_on = c.env_kind == HRL_ANT_FLAGRUN && (c.flag_manual_goals || c.flag_max_target_dist > 0.f || c.flag_path_rew_weight != 0.f);
+    d.w_elec = c.walker_electricity_cost; d.w_stall = c.walker_stall_torque_cost; d.w_jal = c.walker_joints_at_limit_cost;
     d.flag_w_env = c.flag_ant_env_rew_weight; d.flag_w_path = c.flag_path_rew_weight; d.flag_w_dist = c.flag_dist_rew_weight; d.flag_goal_rew = c.flag_goal_reach_rew;
     d.max_contacts = m.max_contacts;
     d.damping_on = (m.linear_damping != 0.f) || (m.angular_damping != 0.f);

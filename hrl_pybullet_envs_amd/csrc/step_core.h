@@ -85,6 +85,7 @@ struct DevCfg {
     float mu_self; /* friction between two ant links */
     int obs_dim, act_dim;
     float flag_w_env, flag_w_path, flag_w_dist, flag_goal_rew; /* ant_flagrun_env.py:157-160 */
+    float w_elec, w_stall, w_jal; /* upstream WalkerBaseBulletEnv.electricity_cost / stall_torque_cost / joints_at_limit_cost (AntMaze -2, -0.1, -0.1; AntFlagrun 0, 0, 0) */
     int flag_path_on;             /* the env keeps `_goal_start_pos` / `_sq_dist_goal` in its items record (manual goals, goals near the robot, or a path reward weight) */
     int max_contacts;             /* contacts kept per substep, <= MAXC */
     int damping_on;               /* base damping: the torso twist of the unconstrained update is scaled by damp_ang / damp_lin */
@@ -2443,7 +2444,10 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             const bool close = c.flag_mtd > 0.f, listed = c.flag_manual && !close; /* max_targets < 1: goals near the robot whoever made the env (:113-114) */
             const int step_cur = listed ? -1 : 1;
             auto more = [&]() { return close ? true : (listed ? cur > 0 : cur < c.flag_max_targets); };
-            rew = (alive + progress) * c.flag_w_env; /* r *= ant_env_rew_weight (:169) */
+            float e1 = 0.f, e2 = 0.f; /* upstream WalkerBaseBulletEnv.step: the reward of super().step() with the cost weights reset() set (0, 0, 0 unless the caller set others) */
+            for (int j = 0; j < NJ; ++j) { const float a = L.act[j]; e1 += fabsf(a * L.s28[9 + 2 * j]); e2 += a * a; }
+            const float electricity = c.w_elec * (e1 / NJ) + c.w_stall * (e2 / NJ);
+            rew = ((((alive + progress) + electricity) + c.w_jal * L.scal[5]) + 0.f) * c.flag_w_env; /* r *= ant_env_rew_weight (:169) */
             if (c.flag_path_on) { /* :174-176: how far along the straight line from where the goal was received to the goal, over the squared distance then
                                      (the record holds both; 0 / 0 before a manual env got its first goal: NaN, as in the reference) */
                 const float gsx = L.items[HRL_FLAG_START_OFF], gsy = L.items[HRL_FLAG_START_OFF + 1];
@@ -2481,8 +2485,8 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             const float wtd = L.scal[3], pot = -wtd / c.dt, progress = pot - L.st[31];
             float e1 = 0.f, e2 = 0.f;
             for (int j = 0; j < NJ; ++j) { const float a = L.act[j]; e1 += fabsf(a * L.s28[9 + 2 * j]); e2 += a * a; }
-            const float electricity = -2.0f * (e1 / NJ) + -0.1f * (e2 / NJ);
-            const float inner = (((alive + progress) + electricity) + -0.1f * L.scal[5]) + 0.f;
+            const float electricity = c.w_elec * (e1 / NJ) + c.w_stall * (e2 / NJ);
+            const float inner = (((alive + progress) + electricity) + c.w_jal * L.scal[5]) + 0.f;
             rew = inner * c.inner_rew_weight;
             done = idone;
             const int t = L.aux[0] + 1;

@@ -5,14 +5,15 @@ import numpy as np
 from ... import _capi as K
 from ... import _lib
 from ..base import BatchedGymEnv
+from ..upstream import WalkerBaseBulletEnv, walker_costs
 
 
 class AntFlagrunBulletEnv(BatchedGymEnv):
     """Class-level reward weights, as in the reference (ant_flagrun_env.py:157-160; `step` reads them off the CLASS, :169-186):
         r = ant_env_rew_weight * r_upstream + path_rew_weight * path_rew - dist_rew_weight * walk_target_dist (+ goal_reach_rew per goal reached).
-    Set them on the class before constructing an env -- `AntFlagrunBulletEnv.path_rew_weight = 0.5` -- : the constructor hands the values of
-    that moment to the kernel (hrl_config.flag_*_rew_weight, flag_goal_reach_rew); `env.set_reward_weights(...)` changes them on a live env
-    (the simulation carries over)."""
+    Set them on the class, before constructing an env or while it runs -- `AntFlagrunBulletEnv.path_rew_weight = 0.5` --: every step compares the
+    class attributes with what the kernel holds (hrl_config.flag_*_rew_weight, flag_goal_reach_rew) and hands a change over in place
+    (hrl_update_config); `env.set_reward_weights(...)` changes them for ONE env."""
     ant_env_rew_weight = 1
     path_rew_weight = 0
     dist_rew_weight = 0
@@ -47,7 +48,36 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         self.goal_capacity, self._create_calls = int(goal_capacity), 0
         self.switch_flag_on_collision = switch_flag_on_collision
         self.use_sensor, self.n_bins, self.sensor_span, self.sensor_range, self.debug = use_sensor, sensor_bins, sensor_span, sensor_range, debug
+        self._class_weights_seen = (float(type(self).ant_env_rew_weight), float(type(self).path_rew_weight), float(type(self).dist_rew_weight),
+                                    float(type(self).goal_reach_rew)) + walker_costs()
+        cfg.walker_electricity_cost, cfg.walker_stall_torque_cost, cfg.walker_joints_at_limit_cost = walker_costs()   # (reset() zeroes them on the class)
         self._finish_init(cfg, num_envs, device, seed)
+
+    def reset(self, mask=None):
+        """ant_flagrun_env.py:132-155.  Its first three lines assign 0 to upstream WalkerBaseBulletEnv's electricity / stall-torque / joints-at-limit
+        costs ON THE CLASS (:133-135): this env, and every other walker env of the process from now on, steps without them."""
+        WalkerBaseBulletEnv.electricity_cost = 0
+        WalkerBaseBulletEnv.stall_torque_cost = 0
+        WalkerBaseBulletEnv.joints_at_limit_cost = 0
+        self._sync_class_weights()
+        return super().reset(mask)
+
+    def _sync_class_weights(self):
+        """step() reads the four weights off AntFlagrunBulletEnv (:169-186) and super().step() the three costs off WalkerBaseBulletEnv, every time:
+        a change of a class attribute reaches the kernel with the next step (weights set through set_reward_weights() belong to this env alone
+        and stay until the CLASS attribute changes again)."""
+        cls, c = type(self), self._cfg
+        now = (float(cls.ant_env_rew_weight), float(cls.path_rew_weight), float(cls.dist_rew_weight), float(cls.goal_reach_rew)) + walker_costs()
+        if now != self._class_weights_seen:
+            changed = [a != b for a, b in zip(now, self._class_weights_seen)]
+            names = ('flag_ant_env_rew_weight', 'flag_path_rew_weight', 'flag_dist_rew_weight', 'flag_goal_reach_rew',
+                     'walker_electricity_cost', 'walker_stall_torque_cost', 'walker_joints_at_limit_cost')
+            for name, v, ch in zip(names, now, changed):
+                if ch:
+                    setattr(c, name, v)
+            self._class_weights_seen = now
+            if self._env is not None:
+                self._env.update_config(c)
 
     def set_reward_weights(self, ant_env_rew_weight=None, path_rew_weight=None, dist_rew_weight=None, goal_reach_rew=None):
         """Changes the reward weights of THIS env (None: keep), in place on a running env (hrl_update_config) -- what assigning to the class

@@ -5,6 +5,7 @@ from ... import _capi as K
 from ... import _lib
 from ...utils import PositionEncoding
 from ..base import BatchedGymEnv
+from ..upstream import walker_costs
 
 _eval_target = [-2, 4]
 _targets = ([2, -3], [2, 0], [2, 3], _eval_target)  # ant_maze_bullet_env.py:13-14
@@ -23,11 +24,21 @@ class AntMazeBulletEnv(BatchedGymEnv):
                                   sense_walls=int(bool(sense_walls)), done_at_target=int(bool(done_at_target)),
                                   max_steps=int(max_steps), tol=float(tol), inner_rew_weight=float(inner_rew_weight),
                                   targ_dist_rew=int(bool(targ_dist_rew)))
+        cfg.walker_electricity_cost, cfg.walker_stall_torque_cost, cfg.walker_joints_at_limit_cost = walker_costs()   # upstream's class attributes, as they are now
         self.n_bins, self.sensor_range, self.sensor_span = n_bins, float(sensor_range), sensor_span
         self.targets, self.sense_walls, self.sense_target = targets, sense_walls, sense_target
         self.done_at_target, self.max_steps, self.tol = done_at_target, max_steps, tol
         self.inner_rew_weight, self.targ_dist_rew, self.target_encoding, self.debug = inner_rew_weight, targ_dist_rew, target_encoding, debug
         self._finish_init(cfg, num_envs, device, seed)
+
+    def _sync_class_weights(self):
+        """super().step() reads WalkerBaseBulletEnv.electricity_cost / stall_torque_cost / joints_at_limit_cost off the class every step (and an
+        AntFlagrunBulletEnv.reset() anywhere in the process has set them to 0, ant_flagrun_env.py:133-135)."""
+        c, w = self._cfg, walker_costs()
+        if (c.walker_electricity_cost, c.walker_stall_torque_cost, c.walker_joints_at_limit_cost) != tuple(np.float32(x) for x in w):
+            c.walker_electricity_cost, c.walker_stall_torque_cost, c.walker_joints_at_limit_cost = w
+            if self._env is not None:
+                self._env.update_config(c)
 
     @property
     def stadium_scene(self):

@@ -130,7 +130,12 @@ class BatchedGymEnv:
     def _load_host_state(self, host):
         pass
 
+    def _sync_class_weights(self):
+        """The reference reads some reward weights off CLASS attributes in every step (upstream WalkerBaseBulletEnv's costs, AntFlagrunBulletEnv's
+        weights): subclasses compare them with what the kernel holds and hand over a change (hrl_update_config).  Nothing by default."""
+
     def step(self, a):
+        self._sync_class_weights()
         env = self._backend()
         if self.num_envs == 1:
             # numpy in / numpy out like the reference: one launch + one synchronisation, the kernel reads the action from and

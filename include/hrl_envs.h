@@ -168,6 +168,12 @@ typedef struct hrl_config {
      * goal (:184-186).  path_rew (:174-176) needs where the robot stood and how far the goal was when the goal was set (:100-103): kept in the
      * items record (HRL_FLAG_START_OFF, HRL_FLAG_SQDIST_OFF), so a config with path_rew_weight != 0 must be given `items`. */
     float flag_ant_env_rew_weight, flag_path_rew_weight, flag_dist_rew_weight, flag_goal_reach_rew; /* 1, 0, 0, 5000 */
+    /* ABI v7: the class-level cost weights of upstream WalkerBaseBulletEnv, which the reward of `super().step()` is made of in AntMazeBulletEnv
+     * and AntFlagrunBulletEnv (alive + progress + electricity_cost * mean|a * joint_speed| + stall_torque_cost * mean(a^2)
+     * + joints_at_limit_cost * joints_at_limit).  Upstream's values -2.0, -0.1, -0.1 are the default for AntMaze; AntFlagrunBulletEnv.reset()
+     * sets all three to 0 ON THE UPSTREAM CLASS (ant_flagrun_env.py:133-135), so a flagrun env has 0, 0, 0 -- and, in the reference, so has every
+     * other walker env of the process from then on; the Python classes mirror that through envs/upstream.py. */
+    float walker_electricity_cost, walker_stall_torque_cost, walker_joints_at_limit_cost;
     hrl_model model;
 } hrl_config;
 

@@ -1729,7 +1729,11 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         int goals_left = manual ? cur : budget - cur; /* manual: `cur` counts the pending goals */
         const int with_path = FN(flag_path_on)(cfg);
         const REAL path = with_path ? FN(orc_flag_path_rew)(st, tgt, items + HRL_FLAG_START_OFF, items[HRL_FLAG_SQDIST_OFF]) : 0;
-        FN(orc_flagrun_task_w)(cfg, alive + progress, idone, wtd, with_path, path, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
+        REAL fe1 = 0, fe2 = 0; /* upstream WalkerBaseBulletEnv.step with the cost weights AntFlagrunBulletEnv.reset() left on the class (hrl_config.walker_*: 0, 0, 0 unless set otherwise) */
+        for (int j = 0; j < NJ; ++j) { REAL a = act[j]; fe1 += RFABS(a * s28[9 + 2 * j]); fe2 += a * a; }
+        const REAL felec = R_(cfg->walker_electricity_cost) * (fe1 / NJ) + R_(cfg->walker_stall_torque_cost) * (fe2 / NJ);
+        const REAL finner = (((alive + progress) + felec) + R_(cfg->walker_joints_at_limit_cost) * R_(nlim)) + 0;
+        FN(orc_flagrun_task_w)(cfg, finner, idone, wtd, with_path, path, &steps, &rewarded, &goals_left, &rew, &done, &retarget);
         if (steps > 0x7fff) steps = 0x7fff; /* steps_since_goal_change saturates in its 15-bit field (only reachable with the timeout off) */
         if (retarget) { /* the next_target() of :190 / :198: goals.pop() (:116), create_close_target around the robot's xy (:113-114) or the shared list's next goal; set_target (:98-103) */
             FN(orc_flag_next_target)(cfg, env, st, items, aux);
@@ -1762,8 +1766,8 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         st[HRL_POTENTIAL_OFF] = pot;
         REAL e1 = 0, e2 = 0;
         for (int j = 0; j < NJ; ++j) { REAL a = act[j]; e1 += RFABS(a * s28[9 + 2 * j]); e2 += a * a; }
-        REAL electricity = R_(-2.0) * (e1 / NJ) + R_(-0.1) * (e2 / NJ);
-        REAL inner = (((alive + progress) + electricity) + R_(-0.1) * R_(nlim)) + 0;
+        REAL electricity = R_(cfg->walker_electricity_cost) * (e1 / NJ) + R_(cfg->walker_stall_torque_cost) * (e2 / NJ);
+        REAL inner = (((alive + progress) + electricity) + R_(cfg->walker_joints_at_limit_cost) * R_(nlim)) + 0;
         FN(orc_maze_task)(cfg, s28, inner, idone, st, rpy[2], tgt, wtd, aux[0] + 1, &FN(maze_lines)[0][0], 7, 3, obs, &rew, &done);
     }
     aux[0] += 1; aux[1] += 1;

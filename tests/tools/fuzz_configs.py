@@ -107,6 +107,9 @@ def draw_config(rng, kind):
         kw['done_at_target'] = int(rng.rand() < 0.6)
         kw['max_steps'] = int(pick(rng, [-1, -1, 0, 1, 2, 4, 25]))
         kw['targ_dist_rew'] = int(rng.rand() < 0.4)
+        if rng.rand() < 0.3:   # upstream WalkerBaseBulletEnv's class-level cost weights (0 after any flagrun reset in the reference's process)
+            kw['walker_electricity_cost'] = f32(pick(rng, [0.0, -2.0, -0.5])); kw['walker_stall_torque_cost'] = f32(pick(rng, [0.0, -0.1]))
+            kw['walker_joints_at_limit_cost'] = f32(pick(rng, [0.0, -0.1, -1.0]))
         kw['tol'] = f32(pick(rng, [1.5, 0.2, 0.8, 3.0, 12.0]))
         if rng.rand() < 0.4: kw['start_pos'] = (f32(rng.uniform(-4, 4)), f32(rng.uniform(-8, -3)), f32(pick(rng, [0.25, 0.4, 0.75])))
         if rng.rand() < 0.3: kw['centroid_n_static'] = int(rng.randint(0, 5)); kw['centroid_static_sum'] = (f32(rng.uniform(-9, 9)), f32(rng.uniform(-9, 9)))
@@ -127,6 +130,9 @@ def draw_config(rng, kind):
         kw['flag_enclosed'] = int(rng.rand() < 0.7)
         if not kw['flag_enclosed'] and not kw['use_sensor']:
             kw['centroid_n_static'] = 1; kw['centroid_static_sum'] = (0.0, 0.0)
+        if rng.rand() < 0.3:   # upstream WalkerBaseBulletEnv's cost weights set back after reset() zeroed them
+            kw['walker_electricity_cost'] = f32(pick(rng, [0.0, -2.0, -0.5])); kw['walker_stall_torque_cost'] = f32(pick(rng, [0.0, -0.1]))
+            kw['walker_joints_at_limit_cost'] = f32(pick(rng, [0.0, -0.1, -1.0]))
         if rng.rand() < 0.4:   # the class-level reward weights (ant_flagrun_env.py:157-160)
             kw['flag_ant_env_rew_weight'] = f32(pick(rng, [1.0, 0.0, 0.5, -2.0]))
             kw['flag_path_rew_weight'] = f32(pick(rng, [0.0, 0.0, 1.0, 0.3, -4.0]))
