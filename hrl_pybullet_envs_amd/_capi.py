@@ -26,7 +26,7 @@ class hrl_model(C.Structure):
                 ('max_joint_vel', C.c_float), ('limit_max_impulse', C.c_float), ('ground_z', C.c_float),
                 ('point_force', C.c_float), ('self_collision', C.c_int32), ('item_collision', C.c_int32), ('step_group', C.c_int32),
                 ('linear_damping', C.c_float), ('angular_damping', C.c_float), ('restitution', C.c_float), ('restitution_threshold', C.c_float),
-                ('max_contacts', C.c_int32)]
+                ('max_contacts', C.c_int32), ('joint_damping', C.c_float), ('joint_armature', C.c_float)]
 
 
 class hrl_config(C.Structure):

@@ -42,7 +42,7 @@ inline int default_config(int32_t kind, hrl_config *c) {
     m.point_force = 500.f; /* point_bot.py:29 */
     m.self_collision = kind != HRL_POINT_GATHER; /* URDF_USE_SELF_COLLISION | ..._EXCLUDE_ALL_PARENTS */
     m.item_collision = kind == HRL_ANT_GATHER || kind == HRL_POINT_GATHER; /* food.xml / poison.xml are collidable boxes */
-    m.linear_damping = 0.f; m.angular_damping = 0.f; m.restitution = 0.f; m.restitution_threshold = 0.2f; m.max_contacts = MAXC; /* DESIGN.md 3.9 */
+    m.linear_damping = 0.f; m.angular_damping = 0.f; m.restitution = 0.f; m.restitution_threshold = 0.2f; m.max_contacts = MAXC; m.joint_damping = 0.f; m.joint_armature = 0.f; /* DESIGN.md 3.9 */
     if (kind != HRL_ANT_GATHER && kind != HRL_POINT_GATHER) c->walk_target[0] = 1000.f; /* upstream WalkerBase default walk target (1e3, 0) until the env sets one */
     if (kind == HRL_ANT_MAZE) {
         static const float t[4][2] = {{2, -3}, {2, 0}, {2, 3}, {-2, 4}}; /* ant_maze_bullet_env.py:13-14 */
@@ -141,7 +141,8 @@ inline std::string validate(const hrl_config *c) {
     if (!(m.timestep > 0) || m.frame_skip < 1 || m.frame_skip > 64 || m.solver_iters < 1 || m.solver_iters > 64) return "bad timestep / frame_skip / solver_iters";
     if (!(m.density > 0)) return "density must be positive";
     if (m.max_contacts < 1 || m.max_contacts > MAXC) return "model.max_contacts must be within 1..12";
-    if (!(m.linear_damping >= 0) || !(m.angular_damping >= 0) || !(m.restitution >= 0) || !(m.restitution_threshold >= 0)) return "model damping / restitution parameters must be >= 0";
+    if (!(m.linear_damping >= 0) || !(m.angular_damping >= 0) || !(m.restitution >= 0) || !(m.restitution_threshold >= 0) || !(m.joint_damping >= 0) || !(m.joint_armature >= 0))
+        return "model damping / restitution / armature parameters must be >= 0";
     if (m.step_group != 0 && m.step_group != 1) return "model.step_group must be 0 (four env-waves per workgroup) or 1 (one wave per env)";
     return "";
 }
@@ -215,6 +216,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.damping_on = (m.linear_damping != 0.f) || (m.angular_damping != 0.f);
     { const float sl = 1.f - d.h * m.linear_damping, sa = 1.f - d.h * m.angular_damping; d.damp_lin = sl > 0.f ? sl : 0.f; d.damp_ang = sa > 0.f ? sa : 0.f; }
     d.restitution = m.restitution; d.rest_thr = m.restitution_threshold;
+    d.jdamp = m.joint_damping; d.armature = m.joint_armature;
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
     d.items_stride = items_stride(&c);
     d.item_shift = c.n_food + c.n_poison > 16 ? 6 : 4;

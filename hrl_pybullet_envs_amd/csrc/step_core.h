@@ -74,6 +74,7 @@ struct DevCfg {
     float h, inv_h, g, erp_c, erp_l, mu, cdist, lmargin, vmax, limp_max, ground_z, torque_scale, point_force, dt;
     int iters, nsub;
     float m0, a0, b0, m1, a1, b1, m2, a2, b2, L1, L2, r_torso, r_caps;
+    float jdamp, armature; /* hrl_model.joint_damping / joint_armature (assets/ant.xml:8; 0, 0: left out of the specification): tau_j - jdamp * rate_j, D_j + armature */
     float jlo[NJ], jhi[NJ], jmid[NJ], jscale[NJ]; /* limits; mid-point and 2/(hi-lo) for the scaled joint observation */
     int n_planes;
     float plane_n[4][3], plane_d[4];
@@ -476,8 +477,8 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
     for (int k = 0; k < 6; ++k) L.cb[ja][k] = cba[k];
     float Ua[6], Iac[6];
     sym6_matvec(Ua, If, Sa);
-    const float invDa = 1.f / dot6(Sa, Ua);
-    const float uta = L.tau[ja] - dot6(Sa, pAf);
+    const float invDa = 1.f / (dot6(Sa, Ua) + c.armature);             /* + 0 at the default: the same bits */
+    const float uta = fma_(-c.jdamp, qda, L.tau[ja]) - dot6(Sa, pAf);   /* - 0 * rate at the default: the same bits */
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -495,7 +496,7 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
 
 /* Phase K2 (body map, same lanes as K1): the aux lanes add what the ankle handed over to their rigid part and process
  * the hip joint (aux -> torso).  Every lane runs the stream on its own registers; only the aux lanes publish. */
-HRL_DEV void phase_hip(WaveLds &L, const LaneRegs &g, int lane) {
+HRL_DEV void phase_hip(const DevCfg &c, WaveLds &L, const LaneRegs &g, int lane) {
     const int grp = lane >> 2, type = grp >> 2, l = grp & 3, jh = 2 * l;
     float Sh[6], cbh[6];
 #pragma unroll
@@ -507,8 +508,8 @@ HRL_DEV void phase_hip(WaveLds &L, const LaneRegs &g, int lane) {
     for (int k = 0; k < 21; ++k) Ix[k] = g.rI[k] + L.Iaf[l][k];
     float Uh[6], Iac[6];
     sym6_matvec(Uh, Ix, Sh);
-    const float invDh = 1.f / dot6(Sh, Uh);
-    const float uth = L.tau[jh] - dot6(Sh, pAx);
+    const float invDh = 1.f / (dot6(Sh, Uh) + c.armature);
+    const float uth = fma_(-c.jdamp, L.u[6 + jh], L.tau[jh]) - dot6(Sh, pAx);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -1186,7 +1187,7 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
     /* the phases index bodies as lane >> 2 (four lanes per body in the one-env form): (lane & 15) << 2 gives body = lane & 15 */
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_kin_ankle(c, L, x.reg(lane), L.q[qi], (lane & 15) << 2); });
     x.stamp(1);
-    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_hip(L, x.reg(lane), (lane & 15) << 2); });
+    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_hip(c, L, x.reg(lane), (lane & 15) << 2); });
     x.stamp(2);
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_leg_sum(L, lane & 15); phase_leg_sum(L, (lane & 15) + 16); });
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_base(L, x.reg(lane), (lane & 15) << 2); });

@@ -116,6 +116,12 @@ typedef struct hrl_model {
     /* contacts kept per substep, 1..12 (candidates beyond it are dropped in candidate order: ground, walls, boxes, cubes, capsule pairs).
      * Default 12, the most the solver's 44 rows hold. */
     int32_t max_contacts;
+    /* assets/ant.xml:8 gives every joint `armature="1" damping="1"` (MuJoCo's rotor inertia, kg m^2, and viscous damping, N m s / rad).  Whether
+     * Bullet's MJCF importer honours either is not decidable from the reference tree (the torque scale was argued with the
+     * armature ignored); the specification leaves both out.  As parameters: joint_armature is added to every hinge's diagonal entry of the
+     * mass matrix (the articulated-body D_j = S_j . I^A S_j + armature), joint_damping * rate is subtracted from the joint torque each substep.
+     * Defaults 0, 0. */
+    float joint_damping, joint_armature;
 } hrl_model;
 
 typedef struct hrl_config {

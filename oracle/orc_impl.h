@@ -592,6 +592,7 @@ typedef struct FN(orc_consts) {
     int max_contacts, damping_on;   /* hrl_model.max_contacts; base damping switched on */
     REAL damp_lin, damp_ang;        /* max(0, 1 - h * damping): factor on the torso's unconstrained linear / angular velocity per substep */
     REAL restitution, rest_thr;     /* hrl_model.restitution / restitution_threshold */
+    REAL jdamp, armature;           /* hrl_model.joint_damping / joint_armature (assets/ant.xml:8; 0, 0 in the specification) */
 } FN(orc_consts);
 
 /* static collision world: ground plane + lateral half-spaces + axis-aligned boxes
@@ -634,6 +635,7 @@ void FN(orc_consts_init)(const hrl_model *M, FN(orc_consts) * K) {
     K->max_contacts = M->max_contacts; K->damping_on = M->linear_damping != 0 || M->angular_damping != 0;
     { REAL sl = R_(1) - K->h * R_(M->linear_damping), sa = R_(1) - K->h * R_(M->angular_damping); K->damp_lin = sl > 0 ? sl : 0; K->damp_ang = sa > 0 ? sa : 0; }
     K->restitution = R_(M->restitution); K->rest_thr = R_(M->restitution_threshold);
+    K->jdamp = R_(M->joint_damping); K->armature = R_(M->joint_armature);
     const double d2r = pi / 180.0;
     const double lo[NJ] = {-40, 30, -40, -100, -40, -100, -40, 30}, hi[NJ] = {40, 100, 40, -30, 40, -30, 40, 100};
     for (int j = 0; j < NJ; ++j) { K->lo[j] = R_(lo[j] * d2r); K->hi[j] = R_(hi[j] * d2r); }
@@ -790,9 +792,9 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
         for (int s = 1; s >= 0; --s) {
             int j = 2 * l + s, child = 1 + j;
             FN(matvec6)(D->U[j], IA[child], D->S[j]);
-            REAL Dj = FN(dot6)(D->S[j], D->U[j]);
+            REAL Dj = FN(dot6)(D->S[j], D->U[j]) + K->armature; /* the rotor inertia of assets/ant.xml:8 where the model is told to have one */
             D->invD[j] = R_(1) / Dj;
-            D->uterm[j] = (tau ? tau[j] : R_(0)) - FN(dot6)(D->S[j], pA[child]);
+            D->uterm[j] = FMA_(-K->jdamp, u[6 + j], (tau ? tau[j] : R_(0))) - FN(dot6)(D->S[j], pA[child]); /* viscous joint damping likewise */
             REAL Ia[6][6], pa_[6], Iac[6];
             for (int a = 0; a < 6; ++a) /* symmetric rank-1 downdate, upper triangle mirrored */
                 for (int b = a; b < 6; ++b) { Ia[a][b] = FMA_(-(D->U[j][a] * D->invD[j]), D->U[j][b], IA[child][a][b]); Ia[b][a] = Ia[a][b]; }

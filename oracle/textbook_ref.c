@@ -38,7 +38,7 @@
  *
  * Frozen = never touched by a performance change.  It changes with the MODEL only; so far in round 5: the end-point spheres against boxes
  * became the capsules of the asset (a cube fits between the ankle and tip spheres of a foot capsule), and the parameters hrl_model gained
- * (base damping, restitution, the contact cap; all off / unchanged at their defaults) were added.
+ * (base damping, restitution, the contact cap, joint damping and armature; all off / unchanged at their defaults) were added.
  */
 #include <math.h>
 #include <stdint.h>
@@ -61,6 +61,7 @@ typedef struct tb_params {
     double linear_damping, angular_damping; /* the free velocity of the base is scaled by max(0, 1 - h * damping) every substep */
     double restitution, restitution_threshold; /* normal rows of approaches faster than the threshold ask for restitution * speed of separation */
     int32_t max_contacts; /* contacts kept per substep, <= TB_MAXC */
+    double joint_damping, joint_armature; /* assets/ant.xml:8 `damping` / `armature` where the model is told to have them (defaults 0, 0) */
 } tb_params;
 
 typedef struct tb_out {
@@ -423,9 +424,10 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
     const double h = P->h;
     tb_kinematics(P, q, u, &K);
     tb_mass_bias(P, &K, M, bias_f);
+    for (int j = 0; j < TB_NJ; ++j) M[(6 + j) * TB_NV + (6 + j)] += P->joint_armature; /* rotor inertia on the joint's diagonal */
     memcpy(Lc, M, sizeof(M));
     chol_factor(TB_NV, Lc);
-    for (int k = 0; k < TB_NV; ++k) rhs[k] = (k >= 6 ? tau[k - 6] : 0.0) - bias_f[k];
+    for (int k = 0; k < TB_NV; ++k) rhs[k] = (k >= 6 ? tau[k - 6] - P->joint_damping * u[k] : 0.0) - bias_f[k];
     chol_solve(TB_NV, Lc, rhs);
     double un[TB_NV];
     for (int k = 0; k < TB_NV; ++k) un[k] = u[k] + h * rhs[k];

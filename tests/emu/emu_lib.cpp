@@ -172,7 +172,7 @@ extern "C" void emu_dyn_dump(const hrl_config *cfg, const float *q, const float 
     for (int i = 0; i < 16; ++i) { L.q[0][i] = i < 15 ? q[i] : 0.f; L.u[i] = i < 14 ? u[i] : 0.f; }
     for (int j = 0; j < 8; ++j) L.tau[j] = tau[j];
     x.each([&](int lane) { phase_kin_ankle(c, L, x.reg(lane), L.q[0], lane); });
-    x.each([&](int lane) { phase_hip(L, x.reg(lane), lane); });
+    x.each([&](int lane) { phase_hip(c, L, x.reg(lane), lane); });
     x.each([&](int lane) { phase_leg_sum(L, lane); });
     x.each([&](int lane) { phase_base(L, x.reg(lane), lane); });
     int o = 0;

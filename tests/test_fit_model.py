@@ -34,13 +34,13 @@ def recorded_steps(true_model, n, seed):
 
 
 def test_fit_recovers_moved_model_parameters():
-    true = dict(density=850.0, contact_erp=0.6, friction_ground=0.55, linear_damping=1.5, solver_iters=8)
+    true = dict(density=850.0, contact_erp=0.6, friction_ground=0.55, joint_damping=1.0, joint_armature=1.0, solver_iters=8)   # (damping / armature: assets/ant.xml:8)
     steps = recorded_steps(true, 160, seed=3)
     rep = fit_model.Replay(K.HRL_ANT_GATHER, steps)
     fitted, before, after = fit_model.fit(rep, list(true), verbose=False)
     assert before[0] > 1e-3 and after[0] < 1e-7, (before, after)          # the default model is off by millimetres per step, the fitted one reproduces the records
     assert fitted['solver_iters'] == 8
-    for k in ('density', 'contact_erp', 'friction_ground', 'linear_damping'):
+    for k in ('density', 'contact_erp', 'friction_ground', 'joint_damping', 'joint_armature'):
         assert abs(fitted[k] - true[k]) <= 0.02 * abs(true[k]), (k, fitted[k], true[k])
 
 

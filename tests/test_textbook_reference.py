@@ -246,7 +246,7 @@ def test_lcp_residual_five_sweeps_against_converged():
 def test_optimised_spec_equals_textbook_over_the_model_parameters():
     """The engine parameters of `hrl_model` are part of the C-ABI: 400 random contact states, each with its OWN model -- density, gravity, time
     step, both ERPs, both friction coefficients, contact distance, limit margin, rate clamp, limit impulse cap, ground height, 1..13 sweeps,
-    self collision on / off, arena size, base damping, restitution and its threshold, the contact cap -- one substep of the optimised specification against the frozen textbook reference: the two derivations
+    self collision on / off, arena size, base damping, restitution and its threshold, the contact cap, joint damping and armature -- one substep of the optimised specification against the frozen textbook reference: the two derivations
     agree to rounding everywhere in the parameter space, not only at the defaults."""
     rng = np.random.RandomState(77)
     worst, rows, selfc = 0.0, [], 0
@@ -263,7 +263,9 @@ def test_optimised_spec_equals_textbook_over_the_model_parameters():
                   # ABI v7: base damping, restitution, the contact cap
                   model_linear_damping=f32(rng.choice([0.0, 0.0, 0.04, 1.0, 50.0])), model_angular_damping=f32(rng.choice([0.0, 0.0, 0.04, 2.0, 400.0])),
                   model_restitution=f32(rng.choice([0.0, 0.0, 0.3, 1.0])), model_restitution_threshold=f32(rng.choice([0.0, 0.2, 1.5])),
-                  model_max_contacts=int(rng.choice([12, 12, 1, 3, 8])))
+                  model_max_contacts=int(rng.choice([12, 12, 1, 3, 8])),
+                  # assets/ant.xml:8 `damping` / `armature`, where the model is told to have them
+                  model_joint_damping=f32(rng.choice([0.0, 0.0, 1.0, 25.0])), model_joint_armature=f32(rng.choice([0.0, 0.0, 1.0, 0.05])))
         cfg = orc.default_config(K.HRL_ANT_GATHER, **kw)
         p = tb.params(cfg)
         q, u, tau = rand_state(rng, xy=(-wx / 2 - 0.1, wx / 2 + 0.1, -wy / 2 - 0.1, wy / 2 + 0.1), joint_slack=0.3 if i % 3 == 0 else 0.1)
@@ -338,6 +340,20 @@ def test_model_parameters_of_abi_v7_do_what_they_say():
         assert out.n_contacts == 4 and np.abs(u1 - u2).max() < 1e-9
         want = (e * 2.0 if 2.0 > thr else 0.0) - 0.001 / h   # the speculative row lets it close the 1 mm gap (-gap / h); restitution adds e x the impact speed
         assert u2[5] == pytest.approx(want, abs=0.01), (e, thr, u2[5])   # (four coupled corner rows, five sweeps: converged to a percent)
+    # joint damping and armature (assets/ant.xml:8) on a free-floating ant: the textbook mass matrix gets `armature` on the joints' diagonal, the joint torque
+    # loses damping x rate; the articulated-body recursion (D_j + armature, tau_j - d rate_j) gives the same accelerations
+    cfg = orc.default_config(K.HRL_ANT_FLAT, model_gravity=0.0, model_joint_damping=3.0, model_joint_armature=1.0)
+    rng = np.random.RandomState(4)
+    for _ in range(10):
+        q, u, tau = rand_state(rng, z=(2, 3), tilt=3.0)
+        q1, u1, _ = tb.ant_substep(tb.params(cfg), q, u, tau)
+        q2, u2, _ = orc_substeps(cfg, q, u, tau)
+        assert max(np.abs(q1 - q2).max(), np.abs(u1 - u2).max()) < 1e-9
+    q = np.zeros(15); q[2] = 3.0; q[6] = 1.0; q[7:] = 0.5 * (LO + HI)
+    u = np.zeros(14); u[6] = 2.0    # one hip turning, nothing else: with a rotor 100 x heavier than the leg the rate just decays by (1 - h d / armature)
+    cfgA = orc.default_config(K.HRL_ANT_FLAT, model_gravity=0.0, model_joint_damping=50.0, model_joint_armature=500.0)
+    q2, u2, _ = orc_substeps(cfgA, q, u, np.zeros(8))
+    assert u2[6] == pytest.approx(2.0 * (1 - h * 50.0 / 500.0), rel=5e-3)
     # the cap: an ant lying flat touches with more than three spheres; max_contacts = 3 keeps the first three candidates
     cfg12, cfg3 = orc.default_config(K.HRL_ANT_FLAT), orc.default_config(K.HRL_ANT_FLAT, model_max_contacts=3)
     q = np.zeros(15); q[2] = 0.09; q[6] = 1.0; q[7:] = np.radians([0, 30, 0, -30, 0, -30, 0, 30])

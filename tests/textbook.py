@@ -18,7 +18,7 @@ class tb_params(C.Structure):
                 ('plane_n', (C.c_double * 3) * 4), ('plane_d', C.c_double * 4),
                 ('box_lo', (C.c_double * 3) * MAXBOX), ('box_hi', (C.c_double * 3) * MAXBOX),
                 ('linear_damping', C.c_double), ('angular_damping', C.c_double), ('restitution', C.c_double), ('restitution_threshold', C.c_double),
-                ('max_contacts', C.c_int32)]
+                ('max_contacts', C.c_int32), ('joint_damping', C.c_double), ('joint_armature', C.c_double)]
 
 
 class tb_out(C.Structure):
@@ -50,6 +50,7 @@ def params(cfg, items=None, self_collision=None):
     p.iters = m.solver_iters
     p.linear_damping, p.angular_damping, p.restitution, p.restitution_threshold = m.linear_damping, m.angular_damping, m.restitution, m.restitution_threshold
     p.max_contacts = m.max_contacts
+    p.joint_damping, p.joint_armature = m.joint_damping, m.joint_armature
     p.self_collision = int(getattr(m, 'self_collision', 0)) if self_collision is None else int(self_collision)
     kind = cfg.env_kind
     hx = hy = 0.0

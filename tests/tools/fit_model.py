@@ -4,7 +4,7 @@
 tools/make_pybullet_golden.py records, where pybullet + gym + the reference are installed, `(qpos, qvel, items, action) -> (qpos', qvel')` of the
 reference's own step() into tests/golden/pybullet_<env>.json; tests/test_pybullet_golden.py replays them on the oracle at the DEFAULT model and
 reports the deviation.  The model choices nothing in the reference tree decides are parameters of `hrl_model` (density, both ERPs, frictions,
-contact distance, limit margin, base damping, restitution, solver sweeps, the contact cap: include/hrl_envs.h), so closing a deviation is a
+contact distance, limit margin, base damping, restitution, joint damping and armature, solver sweeps, the contact cap: include/hrl_envs.h), so closing a deviation is a
 search over them, not a kernel edit.  This tool does that search on the fp64 CPU oracle (test infrastructure: it runs oracle/liborc.so) and
 prints the fitted parameters as `model_*` keyword arguments of `default_config` / fields of `hrl_config.model`:
 
@@ -31,7 +31,8 @@ KIND = {'AntGatherBulletEnv': K.HRL_ANT_GATHER, 'AntMazeBulletEnv': K.HRL_ANT_MA
 # (lower, upper) of the search, in the parameter's own unit; positive ones are searched in log space
 CONTINUOUS = {'density': (1.0, 5000.0), 'contact_erp': (0.0, 1.0), 'limit_erp': (0.0, 1.0), 'friction_ground': (0.0, 3.0), 'friction_robot': (0.0, 4.0),
               'contact_dist': (0.0, 0.1), 'limit_margin': (0.0, 1.0), 'linear_damping': (0.0, 20.0), 'angular_damping': (0.0, 20.0),
-              'restitution': (0.0, 1.0), 'torque_scale': (10.0, 1000.0), 'limit_max_impulse': (0.1, 1e4)}
+              'restitution': (0.0, 1.0), 'torque_scale': (10.0, 1000.0), 'limit_max_impulse': (0.1, 1e4),
+              'joint_damping': (0.0, 50.0), 'joint_armature': (0.0, 10.0)}
 INTEGER = {'solver_iters': range(1, 21), 'max_contacts': range(1, 13)}
 
 

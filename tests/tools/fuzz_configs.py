@@ -59,6 +59,7 @@ def draw_model(rng, kw, kind):
     if rng.rand() < 0.2: kw['model_angular_damping'] = f32(pick(rng, [0.0, 0.04, 2.0, 300.0]))
     if rng.rand() < 0.2: kw['model_restitution'] = f32(pick(rng, [0.0, 0.25, 0.5, 1.0])); kw['model_restitution_threshold'] = f32(pick(rng, [0.0, 0.2, 1.0]))
     if rng.rand() < 0.2: kw['model_max_contacts'] = int(pick(rng, [1, 2, 4, 7, 11, 12]))
+    if rng.rand() < 0.2: kw['model_joint_damping'] = f32(pick(rng, [0.0, 1.0, 30.0])); kw['model_joint_armature'] = f32(pick(rng, [0.0, 1.0, 0.01]))
     if kind != K.HRL_POINT_GATHER and rng.rand() < 0.3: kw['model_self_collision'] = int(rng.randint(2))
     if rng.rand() < 0.15: kw['model_step_group'] = 1
 
