@@ -214,7 +214,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.flag_w_env = c.flag_ant_env_rew_weight; d.flag_w_path = c.flag_path_rew_weight; d.flag_w_dist = c.flag_dist_rew_weight; d.flag_goal_rew = c.flag_goal_reach_rew;
     d.max_contacts = m.max_contacts;
     d.damping_on = (m.linear_damping != 0.f) || (m.angular_damping != 0.f);
-    { const float sl = 1.f - d.h * m.linear_damping, sa = 1.f - d.h * m.angular_damping; d.damp_lin = sl > 0.f ? sl : 0.f; d.damp_ang = sa > 0.f ? sa : 0.f; }
+    d.damp_lin = m.linear_damping; d.damp_ang = m.angular_damping;
     d.restitution = m.restitution; d.rest_thr = m.restitution_threshold;
     d.jdamp = m.joint_damping; d.armature = m.joint_armature;
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);

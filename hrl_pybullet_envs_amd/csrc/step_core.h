@@ -89,7 +89,7 @@ struct DevCfg {
     float w_elec, w_stall, w_jal; /* upstream WalkerBaseBulletEnv.electricity_cost / stall_torque_cost / joints_at_limit_cost (AntMaze -2, -0.1, -0.1; AntFlagrun 0, 0, 0) */
     int flag_path_on;             /* the env keeps `_goal_start_pos` / `_sq_dist_goal` in its items record (manual goals, goals near the robot, or a path reward weight) */
     int max_contacts;             /* contacts kept per substep, <= MAXC */
-    int damping_on;               /* base damping: the torso twist of the unconstrained update is scaled by damp_ang / damp_lin */
+    int damping_on;               /* hrl_model.linear_damping / angular_damping (damp_lin / damp_ang) are not both zero: every body gets Bullet's damping wrench */
     float damp_lin, damp_ang;
     float restitution, rest_thr;  /* > 0: normal rows of fast approaches ask for a separating velocity */
     int items_stride; /* floats per env of the items buffer (hrl_items_stride): 32 for the default configs */
@@ -462,6 +462,20 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
         sym6_matvec(Iv, If, bv); crf(f, bv, Iv); cross3(ng, bc, fg2);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { pAf[k] = f[k] - ng[k]; pAf[3 + k] = f[3 + k] - fg2[k]; }
+    }
+    if (c.damping_on) { /* hrl_model.linear_damping / angular_damping (default 0 / 0: skipped, wave-uniform): the body's bias force gets Bullet's damping
+                           wrench -- force m v_c k_l (1 + |v_c|) at the centre of mass, torque (I_c omega) k_a (1 + |omega|) -- about O */
+        float wc[3], vc[3], fd[3], nd[3], cf[3];
+        cross3(wc, bv, bc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vc[k] = bv[3 + k] + wc[k];
+        const float kl = c.damp_lin * (1.f + sqrtf(dot3(vc, vc))), ka = c.damp_ang * (1.f + sqrtf(dot3(bv, bv)));
+        const float ew = dot3(be, bv);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { fd[k] = (bm * vc[k]) * kl; nd[k] = fma_(bbe * ew, be[k], bal * bv[k]) * ka; }
+        cross3(cf, bc, fd);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pAf[k] = pAf[k] + (nd[k] + cf[k]); pAf[3 + k] = pAf[3 + k] + fd[k]; }
     }
     if (type != 0) return; /* aux body: continues in K2; torso: in B */
     /* one destination at a time: stores to consecutive addresses that follow each other merge into wide LDS writes */
@@ -1192,12 +1206,7 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_leg_sum(L, lane & 15); phase_leg_sum(L, (lane & 15) + 16); });
     x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_base(L, x.reg(lane), (lane & 15) << 2); });
     x.stamp(3);
-    x.leader([&](int lane) {
-        WaveLds &L = x.lds(lane >> 4);
-        float v = phase_forward_vel(c, L, lane & 15);
-        if (c.damping_on) { const int d = lane & 15; v = v * (d < 3 ? c.damp_ang : (d < 6 ? c.damp_lin : 1.f)); } /* hrl_model.linear_damping / angular_damping (default: off, wave-uniform) */
-        L.ustar[lane & 15] = v;
-    });
+    x.leader([&](int lane) { WaveLds &L = x.lds(lane >> 4); const float v = phase_forward_vel(c, L, lane & 15); L.ustar[lane & 15] = v; });
     x.stamp(4);
 }
 
@@ -1570,7 +1579,12 @@ HRL_DEV int point_substep(X &x, const DevCfg &c, int qi, bool items_on) {
         if (d == 3) v = fma_(c.h, L.tau[0] / m, L.u[3]);
         if (d == 4) v = fma_(c.h, L.tau[1] / m, L.u[4]);
         if (d == 5) v = fma_(c.h, L.tau[2] / m - c.g, L.u[5]);
-        if (c.damping_on) v = v * (d < 3 ? c.damp_ang : c.damp_lin); /* hrl_model.linear_damping / angular_damping (default: off) */
+        if (c.damping_on) { /* hrl_model.linear_damping / angular_damping (default: off): Bullet's damping of a free body with an isotropic inertia,
+                               dv = -h v k_l (1 + |v|), domega = -h omega k_a (1 + |omega|), velocities of the start of the substep */
+            const float nw = sqrtf(dot3(L.u, L.u)), nv = sqrtf(dot3(L.u + 3, L.u + 3));
+            const float kk = d < 3 ? c.damp_ang * (1.f + nw) : c.damp_lin * (1.f + nv);
+            v = fma_(-(c.h * kk), L.u[d < 6 ? d : 0], v);
+        }
         x.reg(lane).ud = d < 6 ? v : 0.f;
         if (lane < 16) L.ustar[lane] = d < 6 ? v : 0.f;
         float ax_[3], ay_[3], az_[3];

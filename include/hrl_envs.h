@@ -106,8 +106,10 @@ typedef struct hrl_model {
     /* ---- ABI v7: model choices nothing in the reference tree decides (the arithmetic lives in the absent pybullet wheel), as parameters, so
      * that fitting recorded pybullet steps (tools/make_pybullet_golden.py) is a config change.  The defaults are the build's specification
      *  and cost nothing: each feature is skipped by a wave-uniform test when its parameter is at the default. ---- */
-    /* base damping (Bullet's multibodies have a small built-in linear / angular damping of the base): per substep the torso's
-     * linear / angular velocity of the unconstrained update is scaled by max(0, 1 - timestep * damping).  Default 0 (none). */
+    /* Damping of the bodies' motion in the form Bullet's multibodies apply it (recalled: btMultiBody adds, for the base and every link, the
+     * bias force m v k_l (1 + |v|) at the body's centre of mass and the bias torque (I omega) k_a (1 + |omega|), v / omega the body's velocity at
+     * the start of the substep; pybullet documents k_l = k_a = 0.04 as the default of changeDynamics(linearDamping / angularDamping)).  The
+     * specification leaves it out (0, 0: a velocity of 1 m/s would lose 0.1 % per env step); set 0.04 / 0.04 to have it. */
     float linear_damping, angular_damping;
     /* restitution of a contact whose bodies approach faster than restitution_threshold along the normal: the normal row then asks for a
      * separating velocity of restitution * (approach speed) (Bullet combines the two bodies' restitutions by their product, SURVEY A.3:

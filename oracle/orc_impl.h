@@ -589,8 +589,8 @@ typedef struct FN(orc_consts) {
     REAL lo[NJ], hi[NJ];  /* joint ranges, assets/ant.xml:18-54                                          */
     REAL mu_self;         /* friction between two ant links = friction_robot^2 (Bullet combines by product)       */
     int iters, nsub, self_collision, item_collision;
-    int max_contacts, damping_on;   /* hrl_model.max_contacts; base damping switched on */
-    REAL damp_lin, damp_ang;        /* max(0, 1 - h * damping): factor on the torso's unconstrained linear / angular velocity per substep */
+    int max_contacts, damping_on;   /* hrl_model.max_contacts; damping of the bodies switched on */
+    REAL damp_lin, damp_ang;        /* hrl_model.linear_damping / angular_damping: k_l, k_a of Bullet's damping wrench on every body */
     REAL restitution, rest_thr;     /* hrl_model.restitution / restitution_threshold */
     REAL jdamp, armature;           /* hrl_model.joint_damping / joint_armature (assets/ant.xml:8; 0, 0 in the specification) */
 } FN(orc_consts);
@@ -633,7 +633,7 @@ void FN(orc_consts_init)(const hrl_model *M, FN(orc_consts) * K) {
     K->iters = M->solver_iters; K->nsub = M->frame_skip;
     K->mu_self = R_(M->friction_robot * M->friction_robot); K->self_collision = M->self_collision; K->item_collision = M->item_collision;
     K->max_contacts = M->max_contacts; K->damping_on = M->linear_damping != 0 || M->angular_damping != 0;
-    { REAL sl = R_(1) - K->h * R_(M->linear_damping), sa = R_(1) - K->h * R_(M->angular_damping); K->damp_lin = sl > 0 ? sl : 0; K->damp_ang = sa > 0 ? sa : 0; }
+    K->damp_lin = R_(M->linear_damping); K->damp_ang = R_(M->angular_damping);
     K->restitution = R_(M->restitution); K->rest_thr = R_(M->restitution_threshold);
     K->jdamp = R_(M->joint_damping); K->armature = R_(M->joint_armature);
     const double d2r = pi / 180.0;
@@ -744,8 +744,9 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
     REAL zero3[3] = {0, 0, 0};
     FN(spatial_inertia)(IA[0], K->m0, K->a0, K->b0, D->Z, zero3);
     for (int i = 0; i < 6; ++i) v[0][i] = u[i];
-    REAL com[NBODY][3], mass[NBODY];
-    FN(v3set)(com[0], 0, 0, 0); mass[0] = K->m0;
+    REAL com[NBODY][3], mass[NBODY], bal[NBODY], bbe[NBODY], bax[NBODY][3]; /* per body: COM, mass, central inertia alpha 1 + beta e e^T */
+    FN(v3set)(com[0], 0, 0, 0); mass[0] = K->m0; bal[0] = K->a0; bbe[0] = K->b0;
+    for (int k = 0; k < 3; ++k) bax[0][k] = D->Z[k];
     for (int l = 0; l < 4; ++l) {
         REAL qh = q[7 + 2 * l], qa = q[8 + 2 * l];
         REAL ch, sh, ca, sa;
@@ -771,8 +772,8 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
         FN(v3cross)(D->S[ja] + 3, D->pa[l], axw);
         FN(spatial_inertia)(IA[bx], K->m1, K->a1, K->b1, e1, caux);
         FN(spatial_inertia)(IA[bf], K->m2, K->a2, K->b2, e2, cfoot);
-        for (int k = 0; k < 3; ++k) { com[bx][k] = caux[k]; com[bf][k] = cfoot[k]; }
-        mass[bx] = K->m1; mass[bf] = K->m2;
+        for (int k = 0; k < 3; ++k) { com[bx][k] = caux[k]; com[bf][k] = cfoot[k]; bax[bx][k] = e1[k]; bax[bf][k] = e2[k]; }
+        mass[bx] = K->m1; mass[bf] = K->m2; bal[bx] = K->a1; bbe[bx] = K->b1; bal[bf] = K->a2; bbe[bf] = K->b2;
         REAL qdh = u[6 + 2 * l], qda = u[7 + 2 * l], vjh[6], vja[6];
         for (int k = 0; k < 6; ++k) { vjh[k] = D->S[jh][k] * qdh; v[bx][k] = v[0][k] + vjh[k]; }
         for (int k = 0; k < 6; ++k) { vja[k] = D->S[ja][k] * qda; v[bf][k] = v[bx][k] + vja[k]; }
@@ -785,6 +786,17 @@ void FN(orc_dynamics)(const FN(orc_consts) * K, const REAL *q, const REAL *u, co
         FN(crf)(f, v[b], Iv);
         FN(v3cross)(ng, com[b], fg);
         for (int k = 0; k < 3; ++k) { pA[b][k] = f[k] - ng[k]; pA[b][3 + k] = f[3 + k] - fg[k]; }
+        if (K->damping_on) { /* hrl_model.linear_damping / angular_damping: Bullet's damping wrench of the body -- force m v_c k_l (1 + |v_c|) at its centre of
+                                mass, torque (I_c omega) k_a (1 + |omega|) -- about O, from the velocities at the start of the substep */
+            REAL wc[3], vc[3], fd[3], nd[3], cf[3];
+            FN(v3cross)(wc, v[b], com[b]);
+            for (int k = 0; k < 3; ++k) vc[k] = v[b][3 + k] + wc[k];
+            const REAL kl = K->damp_lin * (R_(1) + RSQRT(FN(v3dot)(vc, vc))), ka = K->damp_ang * (R_(1) + RSQRT(FN(v3dot)(v[b], v[b])));
+            const REAL ew = FN(v3dot)(bax[b], v[b]);
+            for (int k = 0; k < 3; ++k) { fd[k] = (mass[b] * vc[k]) * kl; nd[k] = FMA_(bbe[b] * ew, bax[b][k], bal[b] * v[b][k]) * ka; }
+            FN(v3cross)(cf, com[b], fd);
+            for (int k = 0; k < 3; ++k) { pA[b][k] = pA[b][k] + (nd[k] + cf[k]); pA[b][3 + k] = pA[b][3 + k] + fd[k]; }
+        }
     }
     /* backward pass: ankle then hip of every leg; leg contributions are summed (l0+l1)+(l2+l3) into the base */
     REAL Ileg[4][6][6], pleg[4][6];
@@ -1162,7 +1174,6 @@ void FN(orc_ant_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, REAL
     for (int k = 0; k < 3; ++k) { un[k] = FMA_(h, D.a0[k], u[k]); un[3 + k] = FMA_(h, D.a0[3 + k] + wxv[k], u[3 + k]); }
     for (int j = 0; j < NJ; ++j) un[6 + j] = FMA_(h, D.qdd[j], u[6 + j]);
     un[14] = un[15] = 0;
-    if (K->damping_on) for (int k = 0; k < 3; ++k) { un[k] = un[k] * K->damp_ang; un[3 + k] = un[3 + k] * K->damp_lin; } /* hrl_model.angular_damping / linear_damping */
     REAL u16[16]; /* the velocity at the start of the substep, dof order: approach speeds of the restitution rows */
     for (int k = 0; k < NDOF; ++k) u16[k] = u[k];
     u16[14] = u16[15] = 0;
@@ -1243,7 +1254,11 @@ void FN(orc_point_substep)(const FN(orc_consts) * K, const FN(orc_world) * W, RE
     REAL un[6];
     for (int k = 0; k < 3; ++k) un[k] = u[k];
     un[3] = FMA_(h, force[0] / m, u[3]); un[4] = FMA_(h, force[1] / m, u[4]); un[5] = FMA_(h, force[2] / m - K->g, u[5]);
-    if (K->damping_on) for (int k = 0; k < 3; ++k) { un[k] = un[k] * K->damp_ang; un[3 + k] = un[3 + k] * K->damp_lin; }
+    if (K->damping_on) { /* Bullet's damping of a free body with an isotropic inertia, velocities of the start of the substep */
+        const REAL nw = RSQRT(FN(v3dot)(u, u)), nv = RSQRT(FN(v3dot)(u + 3, u + 3));
+        const REAL ka = K->damp_ang * (R_(1) + nw), kl = K->damp_lin * (R_(1) + nv);
+        for (int k = 0; k < 3; ++k) { un[k] = FMA_(-(h * ka), u[k], un[k]); un[3 + k] = FMA_(-(h * kl), u[3 + k], un[3 + k]); }
+    }
     /* contacts: 8 corners vs ground, lateral planes and item cubes in surface-major order, then every cube's 8 corners vs the
      * player's oriented box -- the half that catches a cube under the middle of a face --, at most MAXC in all */
     REAL Jr[3 * MAXC][16], Br[3 * MAXC][16], bias[3 * MAXC], hic[3 * MAXC], lam[3 * MAXC], mu_row[3 * MAXC];

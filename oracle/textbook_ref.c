@@ -38,7 +38,7 @@
  *
  * Frozen = never touched by a performance change.  It changes with the MODEL only; so far in round 5: the end-point spheres against boxes
  * became the capsules of the asset (a cube fits between the ankle and tip spheres of a foot capsule), and the parameters hrl_model gained
- * (base damping, restitution, the contact cap, joint damping and armature; all off / unchanged at their defaults) were added.
+ * (Bullet's per-body damping, restitution, the contact cap, joint damping and armature; all off / unchanged at their defaults) were added.
  */
 #include <math.h>
 #include <stdint.h>
@@ -58,7 +58,7 @@ typedef struct tb_params {
     double plane_n[4][3], plane_d[4]; /* inside: n.p - d > 0 */
     double box_lo[TB_MAXBOX][3], box_hi[TB_MAXBOX][3];
     /* model parameters of hrl_model added in ABI v7 (defaults: 0, 0, 0, 0.2, 12) */
-    double linear_damping, angular_damping; /* the free velocity of the base is scaled by max(0, 1 - h * damping) every substep */
+    double linear_damping, angular_damping; /* k_l, k_a: every body feels the force -m v k_l (1 + |v|) at its COM and the torque -(I omega) k_a (1 + |omega|) */
     double restitution, restitution_threshold; /* normal rows of approaches faster than the threshold ask for restitution * speed of separation */
     int32_t max_contacts; /* contacts kept per substep, <= TB_MAXC */
     double joint_damping, joint_armature; /* assets/ant.xml:8 `damping` / `armature` where the model is told to have them (defaults 0, 0) */
@@ -275,6 +275,8 @@ static void chol_solve(int n, const double *L, double *x /* in: b, out: A^-1 b *
     }
 }
 
+static double v3_norm(const double *a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
 /* mass matrix and bias force of the ant at (q, u) */
 static void tb_mass_bias(const tb_params *P, const tb_kin *K, double *M /* 14x14 */, double *bias /* 14 */) {
     memset(M, 0, sizeof(double) * TB_NV * TB_NV);
@@ -297,6 +299,10 @@ static void tb_mass_bias(const tb_params *P, const tb_kin *K, double *M /* 14x14
         }
         v3_cross(g, B->w, Iw);
         for (int i = 0; i < 3; ++i) { f[i] = B->m * (B->a0[i] + (i == 2 ? P->gravity : 0.0)); n[i] = Ia[i] + g[i]; }
+        { /* damping of the body's motion, the form Bullet's multibodies use: an external wrench, so a bias force */
+            const double kl = P->linear_damping * (1 + v3_norm(B->v)), ka = P->angular_damping * (1 + v3_norm(B->w));
+            for (int i = 0; i < 3; ++i) { f[i] += B->m * B->v[i] * kl; n[i] += Iw[i] * ka; }
+        }
         for (int r = 0; r < TB_NV; ++r)
             for (int i = 0; i < 3; ++i) bias[r] += B->Jv[i][r] * f[i] + B->Jw[i][r] * n[i];
     }
@@ -431,10 +437,6 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
     chol_solve(TB_NV, Lc, rhs);
     double un[TB_NV];
     for (int k = 0; k < TB_NV; ++k) un[k] = u[k] + h * rhs[k];
-    { /* base damping */
-        double sa = 1 - h * P->angular_damping, sl = 1 - h * P->linear_damping;
-        for (int k = 0; k < 3; ++k) { un[k] *= sa > 0 ? sa : 0; un[3 + k] *= sl > 0 ? sl : 0; }
-    }
     const int cap = P->max_contacts > 0 && P->max_contacts < TB_MAXC ? P->max_contacts : TB_MAXC;
 
     /* ---- rows */
@@ -578,9 +580,9 @@ void tb_point_substep(const tb_params *P, double *q, double *u, const double *fo
     m3_from_quat(R, q + 3);
     /* an isotropic inertia tensor has no gyroscopic torque: omega is unchanged by the free motion */
     for (int k = 0; k < 3; ++k) { un[k] = u[k]; un[3 + k] = u[3 + k] + h * (force[k] / m - (k == 2 ? P->gravity : 0.0)); }
-    { /* base damping */
-        double sa = 1 - h * P->angular_damping, sl = 1 - h * P->linear_damping;
-        for (int k = 0; k < 3; ++k) { un[k] *= sa > 0 ? sa : 0; un[3 + k] *= sl > 0 ? sl : 0; }
+    { /* damping: the same wrench on the one free body (isotropic inertia: the torque -I omega k_a (1 + |omega|) decelerates omega by omega k_a (1 + |omega|)) */
+        const double kl = P->linear_damping * (1 + v3_norm(u + 3)), ka = P->angular_damping * (1 + v3_norm(u));
+        for (int k = 0; k < 3; ++k) { un[k] -= h * u[k] * ka; un[3 + k] -= h * u[3 + k] * kl; }
     }
     const int cap = P->max_contacts > 0 && P->max_contacts < TB_MAXC ? P->max_contacts : TB_MAXC;
     static _Thread_local double J[TB_MAXR][TB_NV], B[TB_MAXR][TB_NV];

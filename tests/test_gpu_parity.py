@@ -398,6 +398,10 @@ CONFIG_MATRIX = [
     (K.HRL_ANT_FLAT, 1, dict()),
     (K.HRL_ANT_GATHER, 3, dict(model_solver_iters=2, model_frame_skip=2, model_limit_margin=0.1)),
     (K.HRL_ANT_GATHER, 40, dict(model_self_collision=0, model_item_collision=0)),
+    # hrl_model of ABI v7, all on at once: Bullet's per-body damping (pybullet's 0.04 and a strong one), restitution, a tight contact cap, joint damping + armature
+    (K.HRL_ANT_GATHER, 66, dict(model_linear_damping=0.04, model_angular_damping=0.04, model_restitution=0.3, model_max_contacts=6, model_joint_damping=1.0, model_joint_armature=1.0)),
+    (K.HRL_ANT_MAZE, 35, dict(model_linear_damping=3.0, model_angular_damping=8.0, model_restitution_threshold=0.0, model_restitution=0.8)),
+    (K.HRL_POINT_GATHER, 46, dict(model_linear_damping=0.04, model_angular_damping=2.0, model_restitution=0.5, model_max_contacts=3)),
     (K.HRL_ANT_GATHER, 70, dict(robot_coll_dist=0.0)),
     (K.HRL_POINT_GATHER, 45, dict(robot_coll_dist=-1.0, respawn=0)),
     (K.HRL_ANT_MAZE, 33, dict(inner_rew_weight=1.0)),

@@ -246,7 +246,7 @@ def test_lcp_residual_five_sweeps_against_converged():
 def test_optimised_spec_equals_textbook_over_the_model_parameters():
     """The engine parameters of `hrl_model` are part of the C-ABI: 400 random contact states, each with its OWN model -- density, gravity, time
     step, both ERPs, both friction coefficients, contact distance, limit margin, rate clamp, limit impulse cap, ground height, 1..13 sweeps,
-    self collision on / off, arena size, base damping, restitution and its threshold, the contact cap, joint damping and armature -- one substep of the optimised specification against the frozen textbook reference: the two derivations
+    self collision on / off, arena size, Bullet's per-body damping, restitution and its threshold, the contact cap, joint damping and armature -- one substep of the optimised specification against the frozen textbook reference: the two derivations
     agree to rounding everywhere in the parameter space, not only at the defaults."""
     rng = np.random.RandomState(77)
     worst, rows, selfc = 0.0, [], 0
@@ -260,7 +260,7 @@ def test_optimised_spec_equals_textbook_over_the_model_parameters():
                   model_max_joint_vel=f32(rng.choice([5.0, 30.0, 100.0, 1000.0])), model_limit_max_impulse=f32(rng.choice([0.5, 10.0, 100.0, 1e6])),
                   model_ground_z=f32(rng.choice([0.0, 0.005, 0.05])), model_solver_iters=int(rng.choice([1, 2, 3, 5, 8, 13])),
                   model_self_collision=int(rng.rand() < 0.5),
-                  # ABI v7: base damping, restitution, the contact cap
+                  # ABI v7: damping, restitution, the contact cap
                   model_linear_damping=f32(rng.choice([0.0, 0.0, 0.04, 1.0, 50.0])), model_angular_damping=f32(rng.choice([0.0, 0.0, 0.04, 2.0, 400.0])),
                   model_restitution=f32(rng.choice([0.0, 0.0, 0.3, 1.0])), model_restitution_threshold=f32(rng.choice([0.0, 0.2, 1.5])),
                   model_max_contacts=int(rng.choice([12, 12, 1, 3, 8])),
@@ -317,7 +317,8 @@ def test_pointbot_spec_equals_textbook_over_states_and_parameters():
 
 def test_model_parameters_of_abi_v7_do_what_they_say():
     """hrl_model.linear_damping / angular_damping / restitution / max_contacts (defaults 0 / 0 / 0 / 12: the build's specification):
-    a free-flying ant's base velocity decays by (1 - h d) per substep; a cube dropped flat on the ground leaves it at restitution x its impact
+    a free-flying ant in pure translation decelerates by v k_l (1 + |v|) (Bullet's per-body damping force m v k_l (1 + |v|) sums to that, and, being
+    proportional to the masses, turns nothing); a cube dropped flat on the ground leaves it at restitution x its impact
     speed (and stays down at the default 0); the cap keeps the first candidates.  Optimised specification and textbook reference alike."""
     h = 0.0165 / 4
     # damping: no gravity, no contacts, only the base moving (every joint rate 0: the legs ride along)
@@ -325,10 +326,31 @@ def test_model_parameters_of_abi_v7_do_what_they_say():
     q = np.zeros(15); q[2] = 3.0; q[6] = 1.0; q[7:] = 0.5 * (LO + HI)
     u = np.zeros(14); u[3:6] = [1.0, -2.0, 0.5]
     q2, u2, _ = orc_substeps(cfg, q, u, np.zeros(8), 10)
-    np.testing.assert_allclose(u2[3:6], u[3:6] * (1 - h * 2.0) ** 10, rtol=1e-6)
-    u = np.zeros(14); u[2] = 1.5   # spinning about the vertical: the symmetric ant keeps its axis
+    want = u[3:6].copy()
+    for _ in range(10):
+        want = want * (1 - h * 2.0 * (1 + np.linalg.norm(want)))
+    np.testing.assert_allclose(u2[3:6], want, rtol=1e-6)
+    assert np.abs(u2[:3]).max() < 1e-9 and np.abs(u2[6:]).max() < 1e-9
+    qt, ut = q.copy(), u.copy()
+    for _ in range(10):
+        qt, ut, _ = tb.ant_substep(tb.params(cfg), qt, ut, np.zeros(8))
+    assert np.abs(ut - u2).max() < 1e-9
+    # spinning about the vertical (the symmetric ant keeps its axis): the torques (I_c omega) k_a (1 + |omega|) about the bodies' own centres and the
+    # linear damping of the legs' circling centres brake it: slower than a lone body would be (the legs' m r^2 is braked only through k_l), and it does slow
+    u = np.zeros(14); u[2] = 1.5
     q2, u2, _ = orc_substeps(cfg, q, u, np.zeros(8), 10)
-    assert u2[2] == pytest.approx(1.5 * (1 - h * 5.0) ** 10, rel=1e-3) and abs(u2[0]) < 1e-6 and abs(u2[1]) < 1e-6
+    assert 1.5 * (1 - h * 5.0 * 2.5) ** 10 < u2[2] < 1.5 * (1 - h * 0.5) ** 10 and abs(u2[0]) < 1e-6 and abs(u2[1]) < 1e-6
+    qt, ut = q.copy(), u.copy()
+    for _ in range(10):
+        qt, ut, _ = tb.ant_substep(tb.params(cfg), qt, ut, np.zeros(8))
+    assert np.abs(ut - u2).max() < 1e-9
+    # the PointBot's cube: one free body, isotropic inertia
+    cfg = orc.default_config(K.HRL_POINT_GATHER, model_gravity=0.0, model_linear_damping=2.0, model_angular_damping=5.0)
+    qq = np.array([0, 0, 3.0, 0, 0, 0, 1.0]); uu = np.array([0.3, -0.2, 1.0, 1.0, -2.0, 0.5])
+    orc.lib().orc_point_substeps_f64(C.byref(cfg), orc.ptr(qq), orc.ptr(uu), orc.ptr(np.zeros(3)), 1)
+    w0, v0 = np.array([0.3, -0.2, 1.0]), np.array([1.0, -2.0, 0.5])
+    np.testing.assert_allclose(uu[:3], w0 * (1 - h * 5.0 * (1 + np.linalg.norm(w0))), rtol=1e-8)   # (the time step of the config is a float32)
+    np.testing.assert_allclose(uu[3:], v0 * (1 - h * 2.0 * (1 + np.linalg.norm(v0))), rtol=1e-8)
     # restitution: the PointBot's cube, flat, 1 mm above the ground, coming down at 2 m/s
     for e, thr in ((0.0, 0.2), (0.5, 0.2), (1.0, 0.2), (0.5, 5.0)):
         cfg = orc.default_config(K.HRL_POINT_GATHER, model_restitution=e, model_restitution_threshold=thr, model_gravity=0.0)

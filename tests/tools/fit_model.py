@@ -4,7 +4,7 @@
 tools/make_pybullet_golden.py records, where pybullet + gym + the reference are installed, `(qpos, qvel, items, action) -> (qpos', qvel')` of the
 reference's own step() into tests/golden/pybullet_<env>.json; tests/test_pybullet_golden.py replays them on the oracle at the DEFAULT model and
 reports the deviation.  The model choices nothing in the reference tree decides are parameters of `hrl_model` (density, both ERPs, frictions,
-contact distance, limit margin, base damping, restitution, joint damping and armature, solver sweeps, the contact cap: include/hrl_envs.h), so closing a deviation is a
+contact distance, limit margin, the bodies' damping, restitution, joint damping and armature, solver sweeps, the contact cap: include/hrl_envs.h), so closing a deviation is a
 search over them, not a kernel edit.  This tool does that search on the fp64 CPU oracle (test infrastructure: it runs oracle/liborc.so) and
 prints the fitted parameters as `model_*` keyword arguments of `default_config` / fields of `hrl_config.model`:
 
