@@ -1939,6 +1939,15 @@ void FN(orc_ant_leg_points)(const hrl_model *M, const REAL *q, REAL *out36) {
     for (int l = 0; l < 4; ++l)
         for (int k = 0; k < 3; ++k) { out36[9 * l + k] = q[k] + D.ph[l][k]; out36[9 * l + 3 + k] = q[k] + D.pa[l][k]; out36[9 * l + 6 + k] = q[k] + D.tip[l][k]; }
 }
+/* the hard-wired ant model as numbers (tests/test_assets.py holds them against assets/ant.xml): radii, capsule lengths, masses and central
+ * inertias (alpha, beta) of the three body types, joint ranges [rad] */
+void FN(orc_model_constants)(const hrl_model *M, REAL *out29) {
+    FN(orc_consts) K;
+    FN(orc_consts_init)(M, &K);
+    const REAL v[13] = {K.r_torso, K.r_caps, K.L1, K.L2, K.m0, K.a0, K.b0, K.m1, K.a1, K.b1, K.m2, K.a2, K.b2};
+    for (int k = 0; k < 13; ++k) out29[k] = v[k];
+    for (int j = 0; j < NJ; ++j) { out29[13 + j] = K.lo[j]; out29[21 + j] = K.hi[j]; }
+}
 /* accelerations [a0(6) | qdd(8)] for tests */
 void FN(orc_ant_accel)(const hrl_model *M, const REAL *q, const REAL *u, const REAL *tau, REAL *out14) {
     FN(orc_consts) K; FN(orc_dyn) D;

@@ -556,6 +556,17 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
     for (int j = 0; j < TB_NJ; ++j) q[7 + j] += h * u[6 + j];
 }
 
+/* hip point, ankle point and foot tip of every leg and the centres of mass of the nine bodies, world coordinates (tests/test_assets.py) */
+void tb_ant_points(const tb_params *P, const double *q, double *legs36, double *coms27) {
+    static _Thread_local tb_kin K;
+    double u0[TB_NV] = {0};
+    tb_kinematics(P, q, u0, &K);
+    for (int l = 0; l < 4; ++l)
+        for (int k = 0; k < 3; ++k) { legs36[9 * l + k] = q[k] + K.ph[l][k]; legs36[9 * l + 3 + k] = q[k] + K.pa[l][k]; legs36[9 * l + 6 + k] = q[k] + K.tip[l][k]; }
+    for (int b = 0; b < TB_NB; ++b)
+        for (int k = 0; k < 3; ++k) coms27[3 * b + k] = q[k] + K.B[b].c[k];
+}
+
 /* mass matrix, bias force, forward-dynamics acceleration and total momentum of the free ant (tests) */
 void tb_ant_dynamics(const tb_params *P, const double *q, const double *u, const double *tau, double *M_out, double *bias_out, double *udot_out) {
     static _Thread_local tb_kin K;

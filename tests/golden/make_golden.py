@@ -1103,6 +1103,42 @@ def main():
                                                                          _AntMazeMjEnv, AntFlagrunBulletEnv, AntMjEnv, PointBot, MjAnt)},
         'registered': [{k: plain(v) for k, v in r.items()} for r in REGISTERED]}
 
+    # ------------------------------------------------------------------------------------------ assets (data files, parsed; no Python imported)
+    # The numbers of hrl_pybullet_envs/assets/*.xml that decide the rigid-body MODEL (geometry, joint frames and ranges, obstacle sizes): the one
+    # part of the physics the reference tree itself holds.  tests/test_assets.py builds the ant from them with a generic MJCF forward
+    # kinematics and compares it with the oracle's / the textbook reference's hard-wired ant.
+    import xml.etree.ElementTree as ET
+    adir = os.path.join(REF, 'hrl_pybullet_envs', 'assets')
+
+    def nums(t):
+        return [float(x) for x in t.split()]
+
+    def mj_body(b):
+        return {'name': b.get('name'), 'pos': nums(b.get('pos', '0 0 0')),
+                'joints': [{'name': j.get('name'), 'type': j.get('type'), 'axis': nums(j.get('axis', '0 0 1')), 'pos': nums(j.get('pos', '0 0 0')),
+                            'range': nums(j.get('range')) if j.get('range') else None} for j in b.findall('joint')],
+                'geoms': [{'name': g.get('name'), 'type': g.get('type'), 'size': nums(g.get('size')), 'pos': nums(g.get('pos', '0 0 0')),
+                           'fromto': nums(g.get('fromto')) if g.get('fromto') else None,
+                           **{k: (nums(g.get(k)) if k == 'friction' else float(g.get(k))) for k in ('mass', 'friction', 'condim') if g.get(k)}}
+                          for g in b.findall('geom')],
+                'bodies': [mj_body(c) for c in b.findall('body')]}
+
+    ant = ET.parse(os.path.join(adir, 'ant.xml')).getroot()
+    comp, dflt = ant.find('compiler'), ant.find('default')
+    cube = ET.parse(os.path.join(adir, 'player_cube.xml')).getroot()
+
+    def urdf_box(fn):
+        link = ET.parse(os.path.join(adir, fn)).getroot().find('link')
+        return {'collision_box_size': nums(link.find('collision/geometry/box').get('size')), 'mass': float(link.find('inertial/mass').get('value'))}
+
+    G['assets'] = {
+        'ant': {'compiler': dict(comp.attrib), 'default_joint': dict(dflt.find('joint').attrib), 'default_geom': dict(dflt.find('geom').attrib),
+                'init_qpos': nums(ant.find('custom/numeric').get('data')),
+                'torso': mj_body(ant.find('worldbody/body')),
+                'actuators': [{'joint': m.get('joint'), 'gear': float(m.get('gear')), 'ctrlrange': nums(m.get('ctrlrange'))} for m in ant.findall('actuator/motor')]},
+        'player_cube': mj_body(cube.find('worldbody/body')),
+        'box': urdf_box('box.xml'), 'food': urdf_box('food.xml'), 'poison': urdf_box('poison.xml'), 'wall': urdf_box('wall.xml'), 'plane': urdf_box('plane.xml')}
+
     only = set(sys.argv[1:])  # optional: names of the fixtures to (re)write; default all
     for name, val in G.items():
         if only and name not in only:
