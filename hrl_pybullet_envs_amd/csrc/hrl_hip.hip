@@ -11,8 +11,10 @@
  *     one v_readlane_b32 (no LDS, no barrier, no reduction on the dependent chain),
  *   - ballot + popcount for compacting active contacts / limits into solver rows,
  *   - the wave's issue priority rotated with the substep (GpuExec::priority): the four workgroups of a CU take turns.
- * There is no cross-workgroup communication, so no XCD-aware block remap is needed: blockIdx.x = group index and the
- * dispatcher's round-robin over the 8 XCDs spreads the groups evenly.
+ * There is no cross-workgroup communication, but neighbouring envs SHARE CACHE LINES of the output arrays (reward 4 B, done 1 B, info 16 B per
+ * env, observation rows that are no multiple of a line): the dispatcher deals workgroups to the 8 XCDs round-robin by blockIdx, each XCD has its
+ * own L2, so with blockIdx = group index eight L2s each held a piece of every such line and wrote it back separately.  xcd_group() gives
+ * every XCD one contiguous eighth of the groups instead.
  */
 #include <hip/hip_runtime.h>
 
@@ -163,6 +165,13 @@ struct GpuExec {
     }
 };
 
+/* blockIdx -> index of the env group this workgroup steps: XCD (blockIdx & 7) takes the groups [x * per + min(x, rem), ...) in order, so that
+ * the envs whose output rows share cache lines are written through ONE L2 (a bijection for every grid size) */
+__device__ __forceinline__ int xcd_group() {
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x, x = b & 7, per = nb >> 3, rem = nb & 7;
+    return x * per + (x < rem ? x : rem) + (b >> 3);
+}
+
 /* The ~0.5 KB of constants are read through a pointer (scalar loads on demand, scalar-cache resident) rather than
  * passed by value: by-value kernel arguments were all preloaded into SGPRs and spilled.
  * One kernel per env kind: each contains only its own env's code, which keeps the instruction footprint small
@@ -183,14 +192,15 @@ __global__ __launch_bounds__(64 * G, 4) void k_step(DevBufs b, const DevCfg *__r
     if ((threadIdx.x & 63) == 0) L[threadIdx.x >> 6].dbg_rows = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
 #endif
-    step_entry<KIND>(x, b, *cp, (int)blockIdx.x * G + ((int)threadIdx.x >> 6));
+    const int env = xcd_group() * G + ((int)threadIdx.x >> 6);
+    step_entry<KIND>(x, b, *cp, env);
 #ifdef HRL_WGTIME
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1)::"memory");
-    if (b.stamps && (threadIdx.x & 63) == 0 && (int)blockIdx.x * G + ((int)threadIdx.x >> 6) < cp->n_envs) { /* a wave of a ragged last group has no row in the buffer */
+    if (b.stamps && (threadIdx.x & 63) == 0 && env < cp->n_envs) { /* a wave of a ragged last group has no row in the buffer */
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *o = b.stamps + 4 * ((int)blockIdx.x * G + ((int)threadIdx.x >> 6));
+        unsigned long long *o = b.stamps + 4 * env;
         o[0] = wg_t0; o[1] = wg_t1; o[2] = hw; o[3] = (xcc & 15) | ((unsigned long long)(unsigned)L[threadIdx.x >> 6].dbg_rows << 8);
     }
 #endif
@@ -200,20 +210,20 @@ __global__ __launch_bounds__(64, 4) void k_reset(DevBufs b, const DevCfg *__rest
     __shared__ WaveLds L[1];
     LaneRegs regs;
     GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
-    reset_entry<KIND>(x, b, *cp, (int)blockIdx.x);
+    reset_entry<KIND>(x, b, *cp, xcd_group());
 }
 template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_observe(DevBufs b, const DevCfg *__restrict__ cp) {
     __shared__ WaveLds L[1];
     LaneRegs regs;
     GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
-    observe_entry<KIND>(x, b, *cp, (int)blockIdx.x);
+    observe_entry<KIND>(x, b, *cp, xcd_group());
 }
 __global__ __launch_bounds__(64, 4) void k_set_goals(DevBufs b, const DevCfg *__restrict__ cp, const float *goals_xy, int n_goals, uint8_t *ok) {
     __shared__ WaveLds L[1];
     LaneRegs regs;
     GpuExec<1> x{L, regs, (int)threadIdx.x, 0};
-    set_goals_entry(x, b, *cp, (int)blockIdx.x, goals_xy, n_goals, ok);
+    set_goals_entry(x, b, *cp, xcd_group(), goals_xy, n_goals, ok);
 }
 using kernel_fn = void (*)(DevBufs, const DevCfg *);
 /* group = envs per workgroup of the step kernel: 4 for the ant kinds (1 selectable for A/B measurements), 1 for the point bot */

@@ -140,6 +140,7 @@ struct alignas(16) WaveLds {
     float st[32];        /* packed state record as stored in HBM */
     float jlim[2][NJ];   /* joint ranges, copied from the constants when the env is loaded (phase L reads them per lane) */
     float items[2 * HRL_MAX_ITEMS]; /* the env's items record (the default configs use the first 32 floats) */
+    float items0[32];    /* its first 32 floats as they were loaded: store_env writes back only the entries the step changed (a pickup, a new goal) */
     float act[8];
     int aux[4];
     float q[2][16];      /* ping-pong: substep s reads q[s&1], writes q[(s+1)&1] */
@@ -187,6 +188,7 @@ struct F2b { float ln, dl; }; /* a row's candidate impulse and its change; the c
 /* Fused multiply-adds are written out explicitly (and the sources are compiled with -ffp-contract=off) so that the
  * rounding of every operation is part of the algorithm's definition: DESIGN.md 3.7. */
 HRL_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+HRL_DEV unsigned float_bits(float f) { unsigned u; __builtin_memcpy(&u, &f, sizeof u); return u; }
 HRL_DEV void cross3(float *o, const float *a, const float *b) {
     float x = fma_(a[1], b[2], -(a[2] * b[1])), y = fma_(a[2], b[0], -(a[0] * b[2])), z = fma_(a[0], b[1], -(a[1] * b[0]));
     o[0] = x; o[1] = y; o[2] = z;
@@ -2236,7 +2238,7 @@ HRL_DEV void load_env(X &x, const DevBufs &b, const DevCfg &c, int e, bool with_
     WaveLds &L = x.lds();
     x.each([&](int lane) {
         if (lane < 32) L.st[lane] = b.state[(size_t)e * 32 + lane];
-        else L.items[lane - 32] = b.items ? b.items[(size_t)e * c.items_stride + (lane - 32)] : 0.f;
+        else { const float v = b.items ? b.items[(size_t)e * c.items_stride + (lane - 32)] : 0.f; L.items[lane - 32] = v; L.items0[lane - 32] = v; }
 #pragma unroll 1
         for (int o = 32; o < c.items_stride; o += 64) /* a longer items record (more than 16 items / 15 manual goals): the rest of it */
             if (o + lane < c.items_stride) L.items[o + lane] = b.items ? b.items[(size_t)e * c.items_stride + (o + lane)] : 0.f;
@@ -2251,7 +2253,10 @@ HRL_DEV void store_env(X &x, const DevBufs &b, const DevCfg &c, int e) {
     WaveLds &L = x.lds();
     x.each([&](int lane) {
         if (lane < 32) b.state[(size_t)e * 32 + lane] = L.st[lane];
-        else if (b.items) b.items[(size_t)e * c.items_stride + (lane - 32)] = L.items[lane - 32];
+        else if (b.items) { /* most steps change nothing in the items record: 128 B per env that need not be written (bit compare: a NaN is a change too) */
+            const float v = L.items[lane - 32];
+            if (float_bits(v) != float_bits(L.items0[lane - 32])) b.items[(size_t)e * c.items_stride + (lane - 32)] = v;
+        }
 #pragma unroll 1
         for (int o = 32; o < c.items_stride; o += 64)
             if (b.items && o + lane < c.items_stride) b.items[(size_t)e * c.items_stride + (o + lane)] = L.items[o + lane];
