@@ -183,5 +183,16 @@ class BatchedGymEnv:
         return RobotView(self)
 
     @property
+    def robot_body(self):
+        """`self.robot_body.pose().xyz()` / `.rpy()` as the reference's envs read the torso (ant_maze_bullet_env.py:67,125,130)"""
+        return self.robot.robot_body
+
+    @property
+    def potential(self):
+        """upstream WalkerBaseBulletEnv.potential: the potential the last step (or reset) left, what the next step's `progress` is measured from (MjAnt.py:50-52)"""
+        p = self._backend().state[:, K.HRL_POTENTIAL_OFF].double().cpu().numpy()
+        return float(p[0]) if self.num_envs == 1 else p
+
+    @property
     def unwrapped(self):
         return self

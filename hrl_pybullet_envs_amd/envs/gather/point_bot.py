@@ -26,6 +26,7 @@ class PointBot:
     body_real_xyz = property(lambda self: self._view.body_real_xyz if self._view else np.array(self.start_pos, dtype=float))
     body_xyz = property(lambda self: self._view.body_xyz if self._view else np.array(self.start_pos, dtype=float))
     body_rpy = property(lambda self: self._view.body_rpy if self._view else np.zeros(3))
+    robot_body = property(lambda self: self._view.robot_body if self._view else None)   # upstream BodyPart of the cube: pose().xyz() / .rpy(), get_position(), speed()
 
     def alive_bonus(self, z, pitch):
         return 1                           # point_bot.py:73-74: cannot die

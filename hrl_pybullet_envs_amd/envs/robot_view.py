@@ -1,6 +1,7 @@
 """The robot attributes a trainer written against the reference reads between steps -- `env.robot.walk_target_x/y`,
-`body_xyz`, `body_real_xyz`, `body_rpy`, `walk_target_dist`, `initial_z` (upstream WalkerBase, SURVEY Appendix A.5;
-point_bot.py:48-67) -- as read-only views over the env's state tensors.  Single env: python / numpy values like the reference;
+`body_xyz`, `body_real_xyz`, `body_rpy`, `walk_target_dist`, `initial_z`, `joint_speeds`, `joints_at_limit`, `feet_contact`, `calc_potential()`
+(upstream WalkerBase; point_bot.py:48-67; read in-tree at MjAnt.py:51-68) and `robot_body.pose().xyz()` / `.rpy()` /
+`.get_position()` (read in-tree at ant_maze_bullet_env.py:67,125,130, ant_flagrun_env.py:104-105,128) -- as read-only views over the env's state tensors.  Single env: python / numpy values like the reference;
 batched: one row per env (numpy, fp64, computed on the host from one copy of the state: informational, not the step path)."""
 import numpy as np
 
@@ -54,9 +55,92 @@ def ant_parts_centroid(qpos, n_static, static_sum):
     return np.stack([(13 * qpos[:, 0] + s[:, 0] + static_sum[0]) / n, (13 * qpos[:, 1] + s[:, 1] + static_sum[1]) / n], 1)
 
 
+class PoseView:
+    """upstream robot_bases.Pose_Helper: what `robot_body.pose()` returns"""
+
+    def __init__(self, body):
+        self._b = body
+
+    def xyz(self):
+        return self._b.get_position()
+
+    def rpy(self):
+        return self._b._r.body_rpy
+
+    def orientation(self):
+        return self._b.get_orientation()
+
+
+class BodyView:
+    """upstream robot_bases.BodyPart of the torso (`robot.robot_body`, `env.robot_body`): position, orientation (quaternion x y z w), velocity"""
+
+    def __init__(self, robot):
+        self._r = robot
+
+    def pose(self):
+        return PoseView(self)
+
+    def get_position(self):
+        return self._r.body_real_xyz
+
+    current_position = get_position
+
+    def get_orientation(self):
+        return self._r._out(self._r._state()[:, 3:7])
+
+    current_orientation = get_orientation
+
+    def get_pose(self):
+        return np.concatenate([np.atleast_2d(self.get_position()), np.atleast_2d(self.get_orientation())], 1)[() if self._r._e.num_envs > 1 else 0]
+
+    def speed(self):
+        return self._r._out(self._r._state()[:, K.HRL_QVEL_OFF:K.HRL_QVEL_OFF + 3])
+
+
+_ANT_LO = np.deg2rad([-40.0, 30, -40, -100, -40, -100, -40, 30])   # assets/ant.xml:18-54, tree order
+_ANT_HI = np.deg2rad([40.0, 100, 40, -30, 40, -30, 40, 100])
+
+
 class RobotView:
     def __init__(self, env):
         self._e = env
+
+    @property
+    def robot_body(self):
+        return BodyView(self)
+
+    def _ant(self, what):
+        if self._e._cfg.env_kind == K.HRL_POINT_GATHER:
+            raise AttributeError(f'{what}: the PointBot has no joints (point_bot.py:10-74)')
+
+    @property
+    def joint_speeds(self):
+        """upstream WalkerBase.calc_state: `j[1::2]`, the joint rates scaled by 0.1 (what the electricity cost multiplies, MjAnt.py:65)"""
+        self._ant('joint_speeds')
+        return self._out(0.1 * self._state()[:, K.HRL_QVEL_OFF + 6:K.HRL_QVEL_OFF + 14])
+
+    @property
+    def joints_at_limit(self):
+        """upstream WalkerBase.calc_state: how many joints are beyond 99 % of their half range (MjAnt.py:40,68)"""
+        self._ant('joints_at_limit')
+        q = self._state()[:, 7:15]
+        n = np.count_nonzero(np.abs(2.0 * (q - 0.5 * (_ANT_LO + _ANT_HI)) / (_ANT_HI - _ANT_LO)) > 0.99, axis=1)
+        return int(n[0]) if self._e.num_envs == 1 else n
+
+    @property
+    def feet_contact(self):
+        """the four feet's ground-contact flags as the last step left them (MjAnt.py:55-63; upstream WalkerBaseBulletEnv.step): kept by the kernel for the
+        kinds whose observation shows them (AntMaze, AntFlagrun: bits 28..31 of aux[1])"""
+        if self._e._cfg.env_kind not in (K.HRL_ANT_MAZE, K.HRL_ANT_FLAGRUN):
+            raise AttributeError('feet_contact: kept only for AntMazeBulletEnv / AntFlagrunBulletEnv, whose observations contain the flags')
+        bits = self._e._backend().aux[:, 1].cpu().numpy().astype(np.int64) >> 28
+        return self._out(((bits[:, None] >> np.arange(4)) & 1).astype(np.float32))
+
+    def calc_potential(self):
+        """upstream WalkerBase.calc_potential: -walk_target_dist / dt, dt = the env step of 0.0165 s (MjAnt.py:51, ant_flagrun_env.py:119)"""
+        m = self._e._cfg.model
+        d = self.walk_target_dist
+        return -d / (m.timestep * m.frame_skip)
 
     def _state(self):
         return self._e._backend().state.double().cpu().numpy()

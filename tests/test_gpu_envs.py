@@ -380,6 +380,33 @@ def test_bench_starts_two_ranks_from_a_bare_shell():
     assert 'rccl' not in one and one['config']['parallelism'] == 'one GPU, one process, no collective'   # nothing claimed that did not run
 
 
+def test_bench_launched_as_the_driver_launches_n_2():
+    """The driver's own command for N = 2, word for word -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 --steps 20 --warmup 5` -- with nothing changed but the backend (gloo: both ranks share this box's one GPU, which
+    RCCL refuses): default env count, default settle, default gather interval.  One JSON line from rank 0, weak scaling, the timed region's gather ran."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--backend', 'gloo'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 20 and out['warmup'] == 5 and out['scaling'] == 'weak' and out['steady_state'] is True
+    assert out['config']['global_envs'] == 2 * 4096 and out['config']['returns_gathered_ok'] is True
+    assert out['rccl']['world_size'] == 2 and out['rccl']['ranks_seen'] == [0, 1] and out['rccl']['gather_count'] == 1   # 325 steps, a gather every 20: the 16th falls into the timed 20
+    assert 'cpu_baseline' not in out    # the CPU leg belongs to the N = 1 line
+
+
 def test_bench_four_ranks_of_the_config5_shape():
     """The shape of the driver's N = 8 run of BASELINE.json configs[4], as far as a one-GPU box may go (at most six processes on the card: four
     ranks + this one): `--gpus 4 --kind mixed` over gloo, every rank half AntGather half PointGather on two streams, the ReturnGatherer
@@ -719,6 +746,48 @@ def test_attributes_a_trainer_reads_between_steps():
     assert tuple(a.stadium_scene.food.shape) == (8, 8, 2) and torch.equal(a.stadium_scene.all_items.reshape(8, 32), a._backend().items[:, :32])   # a batch: tensors
     assert a.robot.body_xyz.shape == (8, 3) and a.robot.body_real_xyz.shape == (8, 3)
     a.close()
+
+
+def test_robot_attributes_the_reference_reads_in_its_own_step():
+    """`robot.joints_at_limit`, `robot.calc_potential()`, `env.potential`, `robot.feet_contact`, `robot.joint_speeds`, `env.robot_body.pose().xyz()` /
+    `.rpy()` / `robot.robot_body.get_position()` -- the upstream attributes the reference's in-tree step() code reads (MjAnt.py:40-68,
+    ant_maze_bullet_env.py:67,125-130, ant_flagrun_env.py:104-105) -- as views over the live state: AntMjEnv's reward is rebuilt from them."""
+    import hrl_pybullet_envs_amd as H
+    e = H.AntMjEnv(seed=2)
+    e.reset()
+    rng = np.random.RandomState(0)
+    for t in range(30):
+        p0 = e.potential
+        obs, r, d, _ = e.step(rng.uniform(-1, 1, 8))
+        alive = 1.0 if obs[2] > 0.26 else -1.0
+        assert r == pytest.approx(alive + (e.potential - p0) - 0.1 * e.robot.joints_at_limit, abs=2e-2), t   # (potentials are ~6e4 in fp32: their difference carries ~4e-3)
+        assert e.potential == pytest.approx(e.robot.calc_potential(), rel=1e-6)
+        assert np.allclose(e.robot.joint_speeds, 0.1 * obs[21:29]) and np.allclose(e.robot_body.pose().xyz(), obs[0:3]) and np.allclose(e.robot.robot_body.get_orientation(), obs[3:7])
+        assert np.allclose(e.robot_body.speed(), obs[15:18]) and np.allclose(e.robot_body.pose().rpy(), e.robot.body_rpy)
+        if d:
+            break
+    e.close()
+    m = H.AntMazeBulletEnv(seed=1)
+    m.reset()
+    seen = set()
+    for t in range(40):
+        before = np.array(m.robot.feet_contact)
+        obs, r, d, _ = m.step(rng.uniform(-1, 1, 8) * 0.3)
+        assert np.array_equal(obs[22:26], before), t        # the observation shows the flags of the step before (upstream's order), feet_contact the current ones
+        seen.add(tuple(m.robot.feet_contact))
+        assert np.allclose(m.robot_body.pose().xyz()[:2], m.robot.body_real_xyz[:2])
+    assert len(seen) > 1 and m.robot.feet_contact.shape == (4,)
+    m.close()
+    b = H.AntMazeBulletEnv(num_envs=6, seed=1)
+    b.reset()
+    assert b.robot.feet_contact.shape == (6, 4) and b.robot.joints_at_limit.shape == (6,) and b.potential.shape == (6,) and b.robot_body.pose().xyz().shape == (6, 3)
+    b.close()
+    pt = H.PointGatherBulletEnv(seed=0)
+    pt.reset()
+    assert np.allclose(pt.robot.robot_body.pose().xyz(), pt.robot.body_real_xyz)
+    with pytest.raises(AttributeError):
+        H.AntGatherBulletEnv(seed=0).robot.feet_contact
+    pt.close()
 
 
 def test_step_host_equals_the_device_path():
