@@ -829,3 +829,32 @@ def test_random_legal_configs_on_device():
         for kind in F.KINDS:
             r, _ = F.run(F.GpuSide, kind, seed * 16 + kind, 30)
             assert r is None, r
+
+
+def test_device_reproduces_the_committed_specification_fingerprint():
+    """tests/golden/spec_fingerprint.json (sha256 of the buffers of 16 envs of every kind after the reset and 1, 10, 80 steps; the oracle and the host
+    executor reproduce it in tests/test_spec_fingerprint.py): the device's bytes, read back through the C-ABI buffers, hash to the same digests."""
+    import json
+    import spec_fingerprint as S
+
+    from hrl_pybullet_envs_amd.vec_env import BatchedEnv
+
+    class Dev:   # the buffers of BatchedEnv under the names tests/orc.py::OracleEnv gives them, as numpy
+        def __init__(self, cfg):
+            self.e, self.ad = BatchedEnv(cfg, 'cuda:0'), orc.act_dim(cfg)
+
+        def reset(self):
+            self.e.reset()
+
+        def step(self, a):
+            self.e.step(torch.from_numpy(a).cuda())
+
+        def __getattr__(self, name):
+            t = getattr(self.e, {'rew': 'reward'}.get(name, name))
+            a = t.cpu().numpy()
+            if name == 'items' and not self.e._uses_items:   # kinds that keep nothing there hand the library NULL: the oracle's record stays zero
+                a = np.zeros_like(a)
+            return a
+    want = json.load(open(S.PATH))
+    got = S.fingerprint(Dev)
+    assert got == want, [k for k in want if got.get(k) != want[k]]
