@@ -3,7 +3,7 @@
  *
  * One wavefront = one environment; four env-waves form a 256-thread workgroup (one for the PointBot).  A wave runs the phases of
  * step_core.h with
- *   - per-wave state staged in LDS (WaveLds 7.4 KB, <= 128 VGPRs -> 16 waves per CU, 4 per SIMD),
+ *   - per-wave state staged in LDS (WaveLds 7.5 KB, <= 128 VGPRs -> 16 waves per CU, 4 per SIMD),
  *   - the lane-sparse articulated-body phases of the four envs of a group executed once, 16 lanes per env, by the group's
  *     leader wave (two s_barrier per substep); everything else by the env's own wave behind wave-level LDS fences,
  *   - coalesced 128-byte loads/stores of the packed state / item records (lane i <-> float i of the record),

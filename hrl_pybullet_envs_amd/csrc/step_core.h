@@ -111,7 +111,7 @@ struct DevBufs {
     unsigned long long *stamps; /* diagnostic builds only (tools/stamp_profile.py): per-phase cycle sums */
 };
 
-/* Per-wave LDS record ("LDS-staged link/joint state"), 7.4 KB, 16-byte aligned (wide LDS accesses).  Three users with disjoint lifetimes share the first
+/* Per-wave LDS record ("LDS-staged link/joint state"), 7.5 KB, 16-byte aligned (wide LDS accesses).  Three users with disjoint lifetimes share the first
  * block: the K1 -> K2 hand-off of a substep, the velocity responses B of the solver rows (written in phase R1, read
  * until the end of the substep) and the task scratch of the epilogue (observation packing, after the substeps). */
 struct alignas(16) WaveLds {
@@ -2450,6 +2450,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             done = (alive < 0.f) || L.flags[0];
             const float pot = -L.scal[3] / c.dt, progress = pot - L.st[31];
             rew = ((alive + progress) + -0.1f * L.scal[5]) + 0.f;
+            food = alive; dead = progress; /* info[0..1] of the locomotion kinds: the first two entries of `self.rewards` (MjAnt.py:82-84) */
             L.red[0] = pot;
         } else if (KIND == 5) { /* upstream WalkerBaseBulletEnv.step with zeroed cost weights (ant_flagrun_env.py:133-135),
                                    then ant_flagrun_env.py:162-204: goal reward, retarget on reach / timeout, out of goals */
@@ -2468,6 +2469,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             for (int j = 0; j < NJ; ++j) { const float a = L.act[j]; e1 += fabsf(a * L.s28[9 + 2 * j]); e2 += a * a; }
             const float electricity = c.w_elec * (e1 / NJ) + c.w_stall * (e2 / NJ);
             rew = ((((alive + progress) + electricity) + c.w_jal * L.scal[5]) + 0.f) * c.flag_w_env; /* r *= ant_env_rew_weight (:169) */
+            food = alive; dead = progress;
             if (c.flag_path_on) { /* :174-176: how far along the straight line from where the goal was received to the goal, over the squared distance then
                                      (the record holds both; 0 / 0 before a manual env got its first goal: NaN, as in the reference) */
                 const float gsx = L.items[HRL_FLAG_START_OFF], gsy = L.items[HRL_FLAG_START_OFF + 1];
@@ -2494,6 +2496,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             for (int i = 0; i < 29; ++i) if (!isfinite(L.st[i])) idone = 1;
             const float wtd = L.scal[3], pot = -wtd / c.dt, progress = pot - L.st[31];
             const float inner = ((alive + progress) + -0.1f * L.scal[5]) + 0.f;
+            food = alive; dead = progress;
             rew = inner * c.inner_rew_weight;
             done = idone;
             if (wtd < c.tol) { rew += 1.f; done = 1; }
@@ -2507,6 +2510,7 @@ HRL_DEV void step_entry(X &x, const DevBufs &b, const DevCfg &c, int e) {
             for (int j = 0; j < NJ; ++j) { const float a = L.act[j]; e1 += fabsf(a * L.s28[9 + 2 * j]); e2 += a * a; }
             const float electricity = c.w_elec * (e1 / NJ) + c.w_stall * (e2 / NJ);
             const float inner = (((alive + progress) + electricity) + c.w_jal * L.scal[5]) + 0.f;
+            food = alive; dead = progress;
             rew = inner * c.inner_rew_weight;
             done = idone;
             const int t = L.aux[0] + 1;

@@ -137,6 +137,7 @@ class BatchedGymEnv:
     def step(self, a):
         self._sync_class_weights()
         env = self._backend()
+        self._last_a = a        # (what `rewards` recomputes the electricity term from)
         if self.num_envs == 1:
             # numpy in / numpy out like the reference: one launch + one synchronisation, the kernel reads the action from and
             # writes its outputs to pinned host memory (BatchedEnv.step_host)
@@ -192,6 +193,30 @@ class BatchedGymEnv:
         """upstream WalkerBaseBulletEnv.potential: the potential the last step (or reset) left, what the next step's `progress` is measured from (MjAnt.py:50-52)"""
         p = self._backend().state[:, K.HRL_POTENTIAL_OFF].double().cpu().numpy()
         return float(p[0]) if self.num_envs == 1 else p
+
+    @property
+    def rewards(self):
+        """The terms of the last step's locomotion reward, upstream's `self.rewards` (MjAnt.py:82-87: [alive, progress, joints_at_limit_cost,
+        feet_collision_cost]; upstream WalkerBaseBulletEnv.step for AntMaze / AntFlagrun: [alive, progress, electricity_cost, joints_at_limit_cost,
+        feet_collision_cost]).  alive and progress are the kernel's own values (info[:, 0:2] of these kinds); the cost terms are recomputed on the host
+        from the state the step left and the action it was given.  One env: a list of floats; a batch: a list of [N] arrays (rows whose episode has
+        just ended and was reset in place show the cost terms of the new episode's first state)."""
+        kind = self._cfg.env_kind
+        if kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER):
+            raise AttributeError('rewards: the gather envs have no locomotion reward (ant_gather_env.py:118-119 returns food_reward + dead_rew)')
+        info = self._backend().info[:, 0:2].double().cpu().numpy()
+        r = self.robot
+        jal = np.atleast_1d(r.joints_at_limit).astype(np.float64)
+        mj = kind in (K.HRL_ANT_FLAT, K.HRL_ANT_MAZE_MJ)
+        terms = [info[:, 0], info[:, 1]]
+        if not mj:
+            a = getattr(self, '_last_a', None)
+            a = np.zeros((self.num_envs, 8)) if a is None else (a.detach().double().cpu().numpy() if hasattr(a, 'detach') else np.asarray(a, np.float64)).reshape(self.num_envs, 8)
+            js = np.atleast_2d(r.joint_speeds)
+            c = self._cfg
+            terms.append(c.walker_electricity_cost * np.abs(a * js).mean(axis=1) + c.walker_stall_torque_cost * np.square(a).mean(axis=1))
+        terms += [(-0.1 if mj else self._cfg.walker_joints_at_limit_cost) * jal, np.zeros(self.num_envs)]
+        return [float(t[0]) for t in terms] if self.num_envs == 1 else terms
 
     @property
     def unwrapped(self):

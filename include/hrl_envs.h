@@ -53,7 +53,7 @@ extern "C" {
 #define HRL_MAX_OBS 256     /* widest observation: AntMazeMj with 64 bins = 29 + 3 * 64 + 1 = 222 */
 #define HRL_AUX_STRIDE 4    /* int32: t_episode, t_lifetime (AntMaze / AntFlagrun: low 28 bits; bits 28..31 = the feet contacts of the last step, what upstream's
                                robot.feet_contact holds when the next step's calc_state() reads it), episode_index, target_index (flagrun: goal index | steps_since_goal_change << 16 | rewarded << 31) */
-#define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew, episode_return (running; final when done), episode_len */
+#define HRL_INFO_STRIDE 4   /* float: food_rew, dead_rew (gather kinds; the locomotion kinds: alive, progress -- `self.rewards[0:2]`, MjAnt.py:82-84), episode_return (running; final when done), episode_len */
 #define HRL_MAX_TARGETS 64  /* maze kinds: `targets` of the constructor (ant_maze_bullet_env.py:23) */
 #define HRL_MAX_GOALS 61    /* flagrun manual goals (flag_goal_capacity) */
 /* flagrun items record (the modes that keep one): current goal | where the robot stood when it got that goal | squared distance to it then

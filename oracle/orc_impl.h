@@ -1729,6 +1729,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         FN(make_obs)(E, st, items, aux, feet, obs, &wtd, &nlim, 0, 0);
         REAL pot = -wtd / (K->h * R_(K->nsub));
         FN(orc_antmj_reward)(obs, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &rew, &done);
+        food_rew = st[2] > R_(0.26) ? R_(1) : R_(-1); dead_rew = pot - st[HRL_POTENTIAL_OFF]; /* info[0..1] of the locomotion kinds: alive, progress (`self.rewards[0:2]`, MjAnt.py:82-84) */
         st[HRL_POTENTIAL_OFF] = pot;
     } else if (cfg->env_kind == HRL_ANT_FLAGRUN) { /* upstream WalkerBaseBulletEnv.step with its cost weights zeroed
                                                      (ant_flagrun_env.py:133-135), then ant_flagrun_env.py:162-204 */
@@ -1741,6 +1742,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         int idone = alive < 0;
         for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
         REAL pot = -wtd / (K->h * R_(K->nsub)), progress = pot - st[HRL_POTENTIAL_OFF];
+        food_rew = alive; dead_rew = progress; /* info[0..1]: the first two entries of upstream's `self.rewards` */
         st[HRL_POTENTIAL_OFF] = pot; /* next_target() re-reads the same stale potential (:116), i.e. leaves it unchanged */
         const int budget = close_mode ? (1 << 20) : cfg->flag_max_targets; /* max_target_dist mode never runs out (:113-114) */
         int goals_left = manual ? cur : budget - cur; /* manual: `cur` counts the pending goals */
@@ -1770,6 +1772,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         FN(orc_ant_calc_state)(cfg, K, st, st + HRL_QVEL_OFF, st[HRL_INITZ_OFF], tgt, feet, s28, &nlim, &wtd, rpy, 0);
         REAL pot = -wtd / (K->h * R_(K->nsub));
         FN(orc_antmj_reward)(st, st[HRL_POTENTIAL_OFF], pot, nlim, R_(-0.1), &inner, &idone);
+        food_rew = st[2] > R_(0.26) ? R_(1) : R_(-1); dead_rew = pot - st[HRL_POTENTIAL_OFF];
         st[HRL_POTENTIAL_OFF] = pot;
         FN(orc_maze_mj_task)(cfg, st, rpy[2], inner, idone, wtd, aux[0], &FN(maze_lines)[0][0], 7, obs, &rew, &done);
     } else { /* maze: upstream WalkerBaseBulletEnv.step then ant_maze_bullet_env.py:77-97 */
@@ -1780,6 +1783,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
         int idone = alive < 0;
         for (int i = 0; i < 28; ++i) if (!isfinite(s28[i])) idone = 1;
         REAL pot = -wtd / (K->h * R_(K->nsub)), progress = pot - st[HRL_POTENTIAL_OFF];
+        food_rew = alive; dead_rew = progress;
         st[HRL_POTENTIAL_OFF] = pot;
         REAL e1 = 0, e2 = 0;
         for (int j = 0; j < NJ; ++j) { REAL a = act[j]; e1 += RFABS(a * s28[9 + 2 * j]); e2 += a * a; }
@@ -1799,7 +1803,7 @@ void FN(orc_env_step_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *it
     *rew_out = rew; *done_out = (uint8_t)done;
     if (truncated) *truncated = (uint8_t)trunc;
     if (rows_out) *rows_out += n_rows_step;
-    info[0] = food_rew; info[1] = dead_rew; info[2] = st[HRL_EPRET_OFF]; info[3] = R_(aux[0]);
+    info[0] = food_rew; info[1] = dead_rew; info[2] = st[HRL_EPRET_OFF]; info[3] = R_(aux[0]); /* (locomotion kinds: alive, progress in the first two) */
     /* what step() returns in the reference is the state of THIS step (ant_gather_env.py:96,118-119, ant_maze_bullet_env.py:82,97): kept in
      * final_obs when the episode ends, because the in-place reset below overwrites obs with the next episode's first observation */
     if (done && final_obs) { const int od = orc_obs_dim(cfg); for (int i = 0; i < od; ++i) final_obs[i] = obs[i]; }

@@ -761,13 +761,16 @@ def test_robot_attributes_the_reference_reads_in_its_own_step():
         obs, r, d, _ = e.step(rng.uniform(-1, 1, 8))
         alive = 1.0 if obs[2] > 0.26 else -1.0
         assert r == pytest.approx(alive + (e.potential - p0) - 0.1 * e.robot.joints_at_limit, abs=2e-2), t   # (potentials are ~6e4 in fp32: their difference carries ~4e-3)
+        rw = e.rewards                          # MjAnt.py:82-87: [alive, progress, joints_at_limit_cost, feet_collision_cost]
+        assert len(rw) == 4 and rw[0] == alive and rw[2] == pytest.approx(-0.1 * e.robot.joints_at_limit) and rw[3] == 0.0
+        assert np.float32(np.float32(rw[0] + rw[1]) + np.float32(rw[2])) == np.float32(r), (t, rw, r)    # the kernel's own sum, to the bit
         assert e.potential == pytest.approx(e.robot.calc_potential(), rel=1e-6)
         assert np.allclose(e.robot.joint_speeds, 0.1 * obs[21:29]) and np.allclose(e.robot_body.pose().xyz(), obs[0:3]) and np.allclose(e.robot.robot_body.get_orientation(), obs[3:7])
         assert np.allclose(e.robot_body.speed(), obs[15:18]) and np.allclose(e.robot_body.pose().rpy(), e.robot.body_rpy)
         if d:
             break
     e.close()
-    m = H.AntMazeBulletEnv(seed=1)
+    m = H.AntMazeBulletEnv(seed=1, inner_rew_weight=1.0)
     m.reset()
     seen = set()
     for t in range(40):
@@ -775,18 +778,27 @@ def test_robot_attributes_the_reference_reads_in_its_own_step():
         obs, r, d, _ = m.step(rng.uniform(-1, 1, 8) * 0.3)
         assert np.array_equal(obs[22:26], before), t        # the observation shows the flags of the step before (upstream's order), feet_contact the current ones
         seen.add(tuple(m.robot.feet_contact))
+        rw = m.rewards                          # upstream WalkerBaseBulletEnv.step: [alive, progress, electricity_cost, joints_at_limit_cost, feet_collision_cost]
+        assert len(rw) == 5 and rw[0] in (1.0, -1.0) and rw[2] <= 0 and rw[4] == 0.0
+        if not d:
+            assert r == pytest.approx(sum(rw) * m.inner_rew_weight, rel=1e-6, abs=1e-5), (t, rw, r)   # ant_maze_bullet_env.py:82-84: rew = inner * inner_rew_weight (+ the sparse terms when done);
+            # (the first step's progress is ~6e4: the reset took its potential before the target was switched, ant_maze_bullet_env.py:104-116)
         assert np.allclose(m.robot_body.pose().xyz()[:2], m.robot.body_real_xyz[:2])
     assert len(seen) > 1 and m.robot.feet_contact.shape == (4,)
     m.close()
     b = H.AntMazeBulletEnv(num_envs=6, seed=1)
     b.reset()
+    b.step(torch.zeros(6, 8, device='cuda'))
     assert b.robot.feet_contact.shape == (6, 4) and b.robot.joints_at_limit.shape == (6,) and b.potential.shape == (6,) and b.robot_body.pose().xyz().shape == (6, 3)
+    assert len(b.rewards) == 5 and all(x.shape == (6,) for x in b.rewards)
     b.close()
     pt = H.PointGatherBulletEnv(seed=0)
     pt.reset()
     assert np.allclose(pt.robot.robot_body.pose().xyz(), pt.robot.body_real_xyz)
     with pytest.raises(AttributeError):
         H.AntGatherBulletEnv(seed=0).robot.feet_contact
+    with pytest.raises(AttributeError):
+        pt.rewards
     pt.close()
 
 
