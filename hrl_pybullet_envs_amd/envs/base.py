@@ -88,6 +88,7 @@ class BatchedGymEnv:
         self.observation_space = _make_box(-np.inf, np.inf, (od,))
         self.action_space = _make_box(-1.0, 1.0, (ad,))
         self._env = None
+        self._last_a = None   # the action of the last step(): `rewards` recomputes the electricity term from it
 
     # lazily created so that constructing an env (e.g. to read its spaces) needs no GPU
     def _backend(self):
@@ -210,7 +211,7 @@ class BatchedGymEnv:
         mj = kind in (K.HRL_ANT_FLAT, K.HRL_ANT_MAZE_MJ)
         terms = [info[:, 0], info[:, 1]]
         if not mj:
-            a = getattr(self, '_last_a', None)
+            a = self._last_a
             a = np.zeros((self.num_envs, 8)) if a is None else (a.detach().double().cpu().numpy() if hasattr(a, 'detach') else np.asarray(a, np.float64)).reshape(self.num_envs, 8)
             js = np.atleast_2d(r.joint_speeds)
             c = self._cfg
