@@ -267,13 +267,15 @@ def main():
     torch.cuda.synchronize(dev)
     gatherer = ReturnGatherer([(e, s) for _, e, _, s in envs], world, counts=[n] * world) if world > 1 else None
     gather_every = max(1, min(args.gather_every, args.steps))  # a short run (the driver's --steps 20) still gathers inside the timed region
+    gather_phase = gather_every // 2   # launched in the MIDDLE of its interval: a collective queued behind the window's last step would be waited for, exposed, by the
+    #                                    synchronisation that ends the window (one all-gather latency in a 20-launch window); queued mid-window it overlaps the steps that follow
 
     def run(k0, k):
         for t in range(k0, k0 + k):
             for _, env, acts, stream in envs:
                 with torch.cuda.stream(stream):
                     env.step(acts[t % T])
-            if gatherer is not None and (t + 1) % gather_every == 0:
+            if gatherer is not None and (t + 1) % gather_every == gather_phase:
                 gatherer.launch()
             if (t & 63) == 63:
                 wd.beat()   # the launch queue is bounded: the host gets here only as fast as the GPU works the launches off
@@ -326,7 +328,8 @@ def main():
         g = gatherer.latest()
         gathered_ok = bool(g is not None and g.numel() == world * n and torch.isfinite(g).all())
         times = gatherer.gather_times_us(first=n_warm_gathers)   # the collectives of the timed region (launch index >= the warmup's count), HIP events on the side stream
-        expected = (args.settle + args.warmup + args.steps) // gather_every - n_warm_gathers
+        t_first = args.settle + args.warmup
+        expected = sum(1 for t in range(t_first, t_first + args.steps) if (t + 1) % gather_every == gather_phase)
         assert len(times) == min(expected, gatherer.KEEP), (len(times), expected)
         tmax = torch.tensor([max(times) if times else 0.0], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
