@@ -296,6 +296,7 @@ def main():
     if world > 1:
         wd.at('barrier before the timed region')
         torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
     wd.at('timed region')
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in envs]  # made before the clock starts (hipEventCreate is host time, not step time)
     t0 = time.perf_counter()
@@ -310,16 +311,18 @@ def main():
     for (e0, e1), (_, _, _, stream) in zip(ev, envs):
         e1.record(stream)
     torch.cuda.synchronize(dev)
+    wall_own = time.perf_counter() - t0   # this rank's K steps, all its streams drained
     if world > 1:
         wd.at('barrier after the timed region')
         torch.distributed.barrier()
-    wall = time.perf_counter() - t0
+    wall = time.perf_counter() - t0       # the contract's bracket: barrier + synchronize on both sides (`value`); the closing barrier itself -- an all-reduce and
+    #                                       a synchronisation -- is in it, `ms_per_step_before_barrier` shows the steps without it
     wd.at('reductions after the timed region')
     dev_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     if world > 1:
-        tt = torch.tensor([wall], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+        tt = torch.tensor([wall, wall_own], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        wall = float(tt.item())
+        wall, wall_own = float(tt[0].item()), float(tt[1].item())
     for _, env, _, _ in envs:
         assert bool(torch.isfinite(env.state).all()), 'non-finite state after the timed region'
     gathered_ok = None
@@ -378,6 +381,8 @@ def main():
                                       f'every {gather_every} steps on a side stream (see `rccl`)'},
             'roofline': roofline(dom_kind, dom_env.num_envs, launch_s),
         }
+        if world > 1:   # the slowest rank's own K steps, before the barrier that closes the timed bracket (that barrier is inside `value` / `ms_per_step`)
+            out['ms_per_step_before_barrier'] = wall_own / args.steps * 1e3
         if args.kind == 'mixed':
             out['roofline']['streams_ms_per_step'] = {k: ms / (args.steps - first) for (k, _, _, _), ms in zip(envs, dev_ms)}
         if gathered_ok is not None:

@@ -405,6 +405,7 @@ def test_bench_launched_as_the_driver_launches_n_2():
     assert out['config']['global_envs'] == 2 * 4096 and out['config']['returns_gathered_ok'] is True
     assert out["rccl"]["world_size"] == 2 and out["rccl"]["ranks_seen"] == [0, 1] and out["rccl"]["gather_count"] == 1   # a gather every 20 steps, queued mid-interval: one falls into the timed 20
     assert 'cpu_baseline' not in out    # the CPU leg belongs to the N = 1 line
+    assert 0 < out['ms_per_step_before_barrier'] <= out['ms_per_step']   # the closing barrier is inside the contract's bracket; the line also says what the steps took without it
 
 
 def test_bench_four_ranks_of_the_config5_shape():
