@@ -3,6 +3,8 @@
 Same class names / constructor kwargs as the reference (hrl_pybullet_envs/__init__.py:3-16); `make(id)` resolves the
 reference's registered ids with their 2000-step limit.  With gym installed the ids are also registered with `max_episode_steps=2000`
 (gym.make then wraps the single-env object in its own TimeLimit, as it does with the reference's)."""
+import types
+
 from .envs.MjAnt import AntMjEnv
 from .envs.ant_flagrun.ant_flagrun_env import AntFlagrunBulletEnv
 from .envs.ant_maze.ant_maze_bullet_env import AntMazeBulletEnv
@@ -22,6 +24,9 @@ def make(env_id, **kwargs):
         raise KeyError(f'unknown env id {env_id!r}; known: {sorted(_REGISTRY)}')
     env = _REGISTRY[env_id](**kwargs)
     env.max_episode_steps = env.REGISTERED_STEP_LIMIT
+    cls = type(env)
+    env.spec = types.SimpleNamespace(id=env_id, entry_point=f'{cls.__module__}:{cls.__name__}', max_episode_steps=env.REGISTERED_STEP_LIMIT,
+                                     reward_threshold=None, nondeterministic=False, kwargs=dict(kwargs))   # gym's EnvSpec fields of the registration (:11-16)
     return env
 
 

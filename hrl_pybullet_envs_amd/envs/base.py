@@ -75,6 +75,24 @@ class BatchedGymEnv:
         if self._env is not None:   # a constant of the library handle: replaced in place (hrl_update_config), buffers and pinned host memory stay
             self._env.update_config(self._cfg)
 
+    # what gym.make()'s TimeLimit wrapper and registration leave on the object a user of the reference holds (hrl_pybullet_envs/__init__.py:11-16):
+    # `env._max_episode_steps`, `env._elapsed_steps` (gym.wrappers.TimeLimit), `env.spec.id` / `.max_episode_steps` (set by make())
+    spec = None
+
+    @property
+    def _max_episode_steps(self):
+        return self.max_episode_steps or None   # TimeLimit holds None when there is no limit
+
+    @_max_episode_steps.setter
+    def _max_episode_steps(self, n):
+        self.max_episode_steps = 0 if n is None else n
+
+    @property
+    def _elapsed_steps(self):
+        """steps of the running episode (TimeLimit's counter; the kernel's aux[0]): an int for one env, [N] for a batch"""
+        t = self._backend().aux[:, 0].cpu().numpy()
+        return int(t[0]) if self.num_envs == 1 else t
+
     def _finish_init(self, cfg, num_envs, device, seed):
         if num_envs < 1:
             raise ValueError('num_envs must be >= 1')

@@ -524,3 +524,16 @@ def test_readme_and_design_cite_tools_and_tests_that_exist():
         for path, name in set(re.findall(r'(tests/[A-Za-z_0-9]+\.py)::([A-Za-z_0-9]+)', text)):
             src = open(os.path.join(root, path)).read()
             assert re.search(r'def %s[A-Za-z_0-9]*\(' % re.escape(name.rstrip('_')), src), (doc, path, name)
+
+
+def test_make_leaves_what_gym_make_leaves_on_the_object():
+    """`gym.make('<Class>-v0')` of the reference hands back a TimeLimit-wrapped env (hrl_pybullet_envs/__init__.py:11-16): trainers read
+    `env._max_episode_steps` and `env.spec.id` / `env.spec.max_episode_steps` off it.  make() of this package leaves the same (no GPU touched)."""
+    import hrl_pybullet_envs_amd as H
+    env = H.make('AntMazeBulletEnv-v0', num_envs=4)
+    assert env._max_episode_steps == 2000 and env.spec.id == 'AntMazeBulletEnv-v0' and env.spec.max_episode_steps == 2000
+    assert env.spec.entry_point.endswith(':AntMazeBulletEnv') and env.spec.kwargs == {'num_envs': 4}
+    env._max_episode_steps = 500            # the idiom of trainers that shorten episodes
+    assert env.max_episode_steps == 500
+    one = H.AntGatherBulletEnv()            # constructed directly: no wrapper, no limit, no spec -- like the reference's bare class
+    assert one._max_episode_steps is None and one.spec is None
