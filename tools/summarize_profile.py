@@ -57,16 +57,19 @@ def main():
             'command': 'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 50 --warmup 300 --no-cpu-baseline; '
                        'every figure = mean over the last 50 launches (the settled window)',
             'kernel_us_window': kernel_us, 'kernel_us_all_launches': kernel_us_all,
-            'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch (rocprofv3); on gfx950 FETCH_SIZE is calibrated (x2) only for 16-B/lane '
-                     'streams (MI355X_MICROARCH.md, HBM): the dword-per-lane scratch traffic and 4-B/lane record loads here are '
-                     'reported uncorrected; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles',
+            'units': 'FETCH_SIZE / WRITE_SIZE in KiB per launch as rocprofv3 reports them (RAW).  On gfx950 FETCH_SIZE reports half of the bytes '
+                     '(MI355X_MICROARCH.md, HBM) -- calibrated on these kernels\' own access pattern, 4-B-per-lane record loads and small rows '
+                     'with known byte counts (tools/traffic_calib.sh, profiles/r5_traffic_calibration.txt): FETCH_SIZE x 0.50, WRITE_SIZE x 1.000 -- '
+                     'so pmc_summary.json and the bench line use 2 x FETCH_SIZE + WRITE_SIZE; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles',
             'counters': counters}
     json.dump(meta, open(os.path.join(out_dir, f'{tag}_pmc.json'), 'w'), indent=1)
     if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
         path = os.path.join(out_dir, 'pmc_summary.json')
         summ = json.load(open(path)) if os.path.exists(path) else {}
         summ[kind] = {'tag': tag, 'envs_per_launch': n_envs, 'source_sha256': kernel_source_hash(),
-                      'fetch_bytes_per_env': counters['FETCH_SIZE']['mean_per_launch'] * 1024 / n_envs,
+                      # the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes; confirmed for this access pattern: tools/traffic_calib.sh)
+                      'fetch_bytes_per_env': 2.0 * counters['FETCH_SIZE']['mean_per_launch'] * 1024 / n_envs,
+                      'fetch_bytes_per_env_raw_counter': counters['FETCH_SIZE']['mean_per_launch'] * 1024 / n_envs,
                       'write_bytes_per_env': counters['WRITE_SIZE']['mean_per_launch'] * 1024 / n_envs}
         if 'SQ_INSTS_VALU' in counters:  # one wave per env: per-wave counters are per-env counters
             summ[kind]['valu_insts_per_env'] = counters['SQ_INSTS_VALU']['mean_per_wave']
