@@ -201,10 +201,16 @@ def roofline(kind, n, launch_s):
         s = {}
     alg = ALG_BYTES[kind] * n
     achieved = alg / launch_s / 1e9
-    traffic = (s['fetch_bytes_per_env'] + s['write_bytes_per_env']) * n if 'fetch_bytes_per_env' in s else None
+    # HBM-side bytes per launch from the committed counter passes (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction, calibrated on this access pattern,
+    # profiles/r5_traffic_calibration.txt) -- only for the env count they were collected at: the fetch side has a fixed part per launch (the kernel's text,
+    # fetched again by each of the eight L2s), so a per-env figure does not scale to another batch size
+    same_n = s.get('envs_per_launch') == n
+    traffic = (s['fetch_bytes_per_env'] + s['write_bytes_per_env']) * n if 'fetch_bytes_per_env' in s and same_n else None
     out = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
            'traffic': traffic, 'kernel': f'k_step<{kind}>', 'kernel_avg_us': launch_s * 1e6, 'algorithmic_bytes_per_launch': alg,
            'note': 'the path is VALU-issue/latency bound (~170 flop/B, serial recursion): `valu` is the roofline that binds, DESIGN.md 5'}
+    if 'fetch_bytes_per_env' in s and not same_n:
+        out['traffic_note'] = f"counters were collected at {s.get('envs_per_launch')} envs per launch, not {n}: not scaled (fixed part per launch)"
     out['pmc_stale'] = stale  # True: profiles/pmc_summary.json was collected from different kernel sources; traffic / valu withheld
     if 'valu_insts_per_env' in s:
         per_simd = s['valu_insts_per_env'] * n / N_SIMD * VALU_ISSUE_CYCLES

@@ -286,7 +286,7 @@ def test_bench_withholds_counters_of_other_code(monkeypatch):
     sources being benched (roofline.pmc_stale otherwise, counters withheld)."""
     import bench
     from hrl_pybullet_envs_amd.build import kernel_source_hash
-    fresh = {'tag': 't', 'source_sha256': kernel_source_hash(), 'fetch_bytes_per_env': 250.0, 'write_bytes_per_env': 480.0,
+    fresh = {'tag': 't', 'source_sha256': kernel_source_hash(), 'envs_per_launch': 4096, 'fetch_bytes_per_env': 250.0, 'write_bytes_per_env': 480.0,
              'valu_insts_per_env': 6000.0, 'wave_cycles_per_env': 100000.0, 'kernel_us_profiled': 50.0}
     monkeypatch.setattr(bench, 'pmc_summary', lambda kind: dict(fresh))
     r = bench.roofline('gather', 4096, 50e-6)
@@ -295,6 +295,9 @@ def test_bench_withholds_counters_of_other_code(monkeypatch):
     monkeypatch.setattr(bench, 'pmc_summary', lambda kind: dict(fresh, source_sha256='0' * 64))
     r = bench.roofline('gather', 4096, 50e-6)
     assert r['pmc_stale'] is True and r['traffic'] is None and 'valu' not in r
+    monkeypatch.setattr(bench, 'pmc_summary', lambda kind: dict(fresh))
+    r = bench.roofline('gather', 32768, 400e-6)   # another batch size than the counters were taken at: the fetch side has a fixed part per launch, nothing is scaled
+    assert r['traffic'] is None and '4096' in r['traffic_note'] and r['valu']['insts_per_env'] == 6000.0
     monkeypatch.setattr(bench, 'pmc_summary', lambda kind: {})
     assert bench.roofline('gather', 4096, 50e-6)['pmc_stale'] is False   # no summary committed for this kernel: nothing to be stale
 
