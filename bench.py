@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument('--kind', default='gather', choices=sorted(KIND_NAMES))
     ap.add_argument('--gather-every', type=int, default=100, help='all-gather episode returns every K steps (N>1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--model', action='append', default=[], metavar='FIELD=VALUE', help='experiments only: an hrl_model field other than the default (e.g. '
+                    '--model linear_damping=0 --model angular_damping=0); the line then says so in config.model_overrides and is not the headline')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo only to rehearse N>1 on a box with fewer GPUs')
     ap.add_argument('--settle', type=int, default=300, help='untimed steps before --warmup, whatever the caller passes for --warmup: the timed window then '
                     'sees ants that stand (the first ~50 steps after a reset have fewer contacts and shorter launches); 0 = time the post-reset transient')
@@ -265,7 +267,11 @@ def main():
         parts = [(args.kind, n, rank * n)]
     envs = []
     for kname, cnt, off in parts:
-        env = BatchedEnv(_lib.default_config(kinds[kname], num_envs=cnt, seed=0, auto_reset=1, env_id_offset=off), dev)
+        cfg = _lib.default_config(kinds[kname], num_envs=cnt, seed=0, auto_reset=1, env_id_offset=off)
+        for kv in args.model:
+            k, v = kv.split('=', 1)
+            setattr(cfg.model, k, type(getattr(cfg.model, k))(float(v)))
+        env = BatchedEnv(cfg, dev)
         env.reset()
         acts = torch.rand(T, cnt, env.act_dim, device=dev, generator=gen) * 2 - 1
         stream = main_stream if len(parts) == 1 else torch.cuda.Stream(device=dev)  # one HIP stream per sub-shard: the launches overlap
@@ -379,9 +385,13 @@ def main():
             # mean constraint rows per env and env step in the timed window (joint limits + 3 per contact, summed over the 4 substeps): the sweeps
             # are serial in the rows, so this is the regime the launch time belongs to (hrl_buffers.solver_rows)
             'solver_rows_per_env_step': {k: float(env.solver_rows.sum().item()) / (env.num_envs * args.steps) for k, env, _, _ in envs},
+            # the env with the most rows over the window: a launch lasts as long as its slowest env's chain (one env of 4096 that lies against a wall with 12
+            # contacts, 23 rows per substep instead of 20, makes every launch 3 - 4 us longer)
+            'solver_rows_max_env': {k: float(env.solver_rows.max().item()) / args.steps for k, env, _, _ in envs},
             'config': {'workload': f'{shard}, U(-1,1) actions pre-generated on device, auto-reset, max_episode_steps 2000',
                        'envs_per_gpu': n, 'global_envs': world * n,
                        'substeps_per_step': 4,
+                       **({'model_overrides': list(args.model)} if args.model else {}),
                        'parallelism': 'one GPU, one process, no collective' if world == 1 else
                                       f'env-sharded x{world} (one process per GPU), no data-path collective; all-gather of episode returns '
                                       f'every {gather_every} steps on a side stream (see `rccl`)'},

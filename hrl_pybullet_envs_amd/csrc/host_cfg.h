@@ -42,7 +42,8 @@ inline int default_config(int32_t kind, hrl_config *c) {
     m.point_force = 500.f; /* point_bot.py:29 */
     m.self_collision = kind != HRL_POINT_GATHER; /* URDF_USE_SELF_COLLISION | ..._EXCLUDE_ALL_PARENTS */
     m.item_collision = kind == HRL_ANT_GATHER || kind == HRL_POINT_GATHER; /* food.xml / poison.xml are collidable boxes */
-    m.linear_damping = 0.f; m.angular_damping = 0.f; m.restitution = 0.f; m.restitution_threshold = 0.2f; m.max_contacts = MAXC; m.joint_damping = 0.f; m.joint_armature = 0.f; /* DESIGN.md 3.9 */
+    m.linear_damping = 0.04f; m.angular_damping = 0.04f; /* btMultiBody's built-in damping, pybullet's documented default */
+    m.restitution = 0.f; m.restitution_threshold = 0.2f; m.max_contacts = MAXC; m.joint_damping = 0.f; m.joint_armature = 0.f; /* DESIGN.md 3.9 */
     if (kind != HRL_ANT_GATHER && kind != HRL_POINT_GATHER) c->walk_target[0] = 1000.f; /* upstream WalkerBase default walk target (1e3, 0) until the env sets one */
     if (kind == HRL_ANT_MAZE) {
         static const float t[4][2] = {{2, -3}, {2, 0}, {2, 3}, {-2, 4}}; /* ant_maze_bullet_env.py:13-14 */

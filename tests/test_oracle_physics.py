@@ -108,7 +108,7 @@ def test_aba_forward_dynamics_at_rest():
 
 def _free_flight(h, gravity, T=0.2):
     cfg = orc.default_config(K.HRL_ANT_FLAT, model_ground_z=-1000.0, model_limit_margin=-1e9, model_timestep=h,
-                             model_max_joint_vel=1e9, model_gravity=gravity)
+                             model_max_joint_vel=1e9, model_gravity=gravity, model_linear_damping=0.0, model_angular_damping=0.0)   # conservative dynamics only
     q = np.zeros(15); q[2] = 0.75; q[6] = 1; q[7:] = np.deg2rad([0, 60, 0, -60, 0, -60, 0, 60])
     u = np.zeros(14); u[:3] = [1.0, -2.0, 0.5]; u[3:6] = [0.3, 0.2, 1.0]; u[6:] = [1, -2, 0.5, 1.5, -1, 2, 0.7, -0.3]
     e0 = energy_momentum(cfg.model, q, u)

@@ -134,7 +134,7 @@ def normal_force(out, h, surface=None):
 
 def test_resting_ant_normal_forces_carry_its_weight():
     """Ant at rest on the ground: the ground normal impulses per substep / h equal M g (182.2 kg x 9.8) within 1 %."""
-    cfg = orc.default_config(K.HRL_ANT_FLAT)
+    cfg = orc.default_config(K.HRL_ANT_FLAT, model_linear_damping=0.0, model_angular_damping=0.0)   # a statement about the contact rows: without the bodies' damping
     p = tb.params(cfg)
     q = np.zeros(15); q[2] = 0.6; q[6] = 1; q[7:] = 0.5 * (LO + HI); q[8::2] = [1.0, -1.0, -1.0, 1.0]
     q, u, outs = settle(p, q, np.zeros(14), np.zeros(8), 1500)
@@ -151,7 +151,7 @@ def test_resting_cube_and_sliding_friction():
     """PointBot cube (10 kg, friction 0.1 x 0.8): at rest the four bottom corners carry m g within 1 %; sliding along x
     with no applied force it decelerates at mu g within 2 % (the friction pyramid is exact along its axes) and every
     friction impulse stays within the Coulomb bound of its normal impulse."""
-    cfg = orc.default_config(K.HRL_POINT_GATHER)
+    cfg = orc.default_config(K.HRL_POINT_GATHER, model_linear_damping=0.0, model_angular_damping=0.0)   # friction alone decelerates it (the default damping adds 0.04 v (1 + v))
     p = tb.params(cfg)
     q = np.array([0, 0, 0.36, 0, 0, 0, 1.0]); u = np.zeros(6)
     for s in range(400):
@@ -169,7 +169,7 @@ def test_resting_cube_and_sliding_friction():
     assert abs(decel - p.mu * p.gravity) / (p.mu * p.gravity) < 0.02, (decel, p.mu * p.gravity)
     # the optimised specification slides the same cube the same way
     qo, uo = np.array([0, 0, 0.36, 0, 0, 0, 1.0]), np.zeros(6)
-    cfgm = orc.default_config(K.HRL_POINT_GATHER)
+    cfgm = cfg
     qt, ut = qo.copy(), uo.copy(); ut[3] = uo[3] = 1.5
     for s in range(50):
         qt, ut, _ = tb.point_substep(p, qt, ut, np.array([3.0, -2.0, 0.0]))

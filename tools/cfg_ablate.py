@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cost of the optional collision passes at run time (no rebuild): the same kernel with item_collision / self_collision
-switched off in the config.  GPU box: python tools/cfg_ablate.py [n_envs]"""
+switched off in the config, and of the optional model parameters switched on.  GPU box: python tools/cfg_ablate.py [n_envs]"""
 import ctypes as C
 import os
 import sys
@@ -19,7 +19,10 @@ def main():
     acts = torch.rand(64, n, 8, device='cuda') * 2 - 1
     envs = {}
     for name, kw in (('default', {}), ('no cubes', dict(item_collision=0)), ('no self', dict(self_collision=0)),
-                     ('neither', dict(item_collision=0, self_collision=0))):
+                     ('neither', dict(item_collision=0, self_collision=0)),
+                     ('damping 0.04', dict(linear_damping=0.04, angular_damping=0.04)),            # Bullet's per-body damping at pybullet's documented default
+                     ('damping, joint damping 1 + armature 1', dict(linear_damping=0.04, angular_damping=0.04, joint_damping=1.0, joint_armature=1.0)),
+                     ('restitution 0.5', dict(restitution=0.5))):
         cfg = _lib.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=0, auto_reset=1)
         for k, v in kw.items():
             setattr(cfg.model, k, v)
@@ -40,7 +43,7 @@ def main():
             res[name].append(e0.elapsed_time(e1) / 200 * 1e3)
     for name, v in res.items():
         v = sorted(v)
-        print(f'{n} envs  {name:10s} median {v[len(v) // 2]:7.1f} us  min {v[0]:7.1f} us')
+        print(f'{n} envs  {name:40s} median {v[len(v) // 2]:7.1f} us  min {v[0]:7.1f} us')
 
 
 if __name__ == '__main__':
