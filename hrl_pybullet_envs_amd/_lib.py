@@ -6,7 +6,7 @@ import os
 from . import _capi as K
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libhrl_envs_hip.so')
+LIB_PATH = os.environ.get('HRL_ENVS_LIB') or os.path.join(_PKG, 'libhrl_envs_hip.so')   # HRL_ENVS_LIB: another build of the same ABI (A/B measurements)
 _lib = None
 
 # every symbol include/hrl_envs.h declares

@@ -53,6 +53,7 @@ namespace hrl {
 constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (assets/ant.xml:18-54) */
 constexpr int MAXC = 12;  /* contacts kept per substep */
 constexpr int MAXR = 44;  /* constraint rows per substep: 8 limits + 12 * (normal + 2 friction) */
+constexpr int HOT_ROWS = 20; /* rows per substep of a standing ant: an env with more is the launch's straggler (ant_env_block) */
 constexpr int MAXB = NJ + MAXC; /* bounded rows that come first in the sweep order: joint limits, then contact normals */
 constexpr int MAXF = 2 * MAXC;  /* friction rows, a pair per contact, after all the normals */
 static_assert(MAXB + MAXF == MAXR && MAXB % 4 == 0 && MAXF % 4 == 0, "row blocks are built in groups of four");
@@ -1529,6 +1530,13 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi) { /* returns the subste
     WaveLds &L = x.lds();
     x.refresh();
     const int nC = x.uniform(L.nC), nL = x.uniform(L.nL), nS = x.uniform(L.nS);
+#ifndef HRL_NO_HOT_ROWS /* (A/B builds of tools/variants.py define it) */
+    /* Longest job first: a launch lasts as long as its slowest env, and an env's chain grows with its rows.  An env with more rows than a standing
+     * ant's (four feet x 3 + eight joints near their stops = 20) takes the top issue priority for the rest of its block; the rotation at the head of
+     * the next substep takes it back.  Scheduling only.  One such env among 4096 cost a launch 3 - 4 us; this gives 1.4 of them back
+     * (profiles/EXPERIMENTS.md 8). */
+    if (nL + 3 * nC > HOT_ROWS) x.priority(3);
+#endif
     x.each([&](int lane) {
         x.reg(lane).ud = L.ustar[lane & 15]; /* the velocity if no row turns up */
         phase_build_row(c, L, x.reg(lane), lane, nL, nC);
