@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Two populations of 4096 AntGather envs side by side, the bodies' damping off and on (hrl_model.linear_damping / angular_damping), in the settled regime:
+launch time, solver rows of every env, the mean over the groups' slowest envs.  What it showed: a launch in which ONE env holds 88 - 92 rows per step instead of a
+standing ant's 80 lasts 3 - 4 us longer, damped or not (profiles/EXPERIMENTS.md 8.w).  GPU box: python tools/damping_probe.py"""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 from hrl_pybullet_envs_amd import _capi as K, _lib
