@@ -20,8 +20,8 @@ def main():
     envs = {}
     for name, kw in (('default', {}), ('no cubes', dict(item_collision=0)), ('no self', dict(self_collision=0)),
                      ('neither', dict(item_collision=0, self_collision=0)),
-                     ('damping 0.04', dict(linear_damping=0.04, angular_damping=0.04)),            # Bullet's per-body damping at pybullet's documented default
-                     ('damping, joint damping 1 + armature 1', dict(linear_damping=0.04, angular_damping=0.04, joint_damping=1.0, joint_armature=1.0)),
+                     ('no damping', dict(linear_damping=0.0, angular_damping=0.0)),                # (the default has Bullet's per-body damping: 0.04 / 0.04)
+                     ('joint damping 1 + armature 1', dict(joint_damping=1.0, joint_armature=1.0)),
                      ('restitution 0.5', dict(restitution=0.5))):
         cfg = _lib.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=0, auto_reset=1)
         for k, v in kw.items():
