@@ -301,10 +301,10 @@ def main():
     run(0, args.settle)   # untimed, before the caller's warmup: the ants come to stand (the driver passes --warmup 5)
     wd.at('warmup')
     run(args.settle, args.warmup)
-    torch.cuda.synchronize(dev)
     n_warm_gathers = gatherer.k if gatherer is not None else 0
     for _, env, _, _ in envs:   # solver rows per env over the timed window: the regime the launch time belongs to, in the line itself
         env.count_solver_rows()
+    torch.cuda.synchronize(dev)   # (after the counters' zero-fill kernel too: set-up work is done before the clock starts)
     if world > 1:
         wd.at('barrier before the timed region')
         torch.distributed.barrier()
