@@ -18,6 +18,16 @@ def _free_port():
     return p
 
 
+def _spawn(fn, world, total, steps, out_dir):
+    """mp.spawn on a free port; ONE more try on another port if the rendezvous itself fails (the port found free was taken in between, a peer
+    was slow to come up on a loaded machine) -- an assertion inside a worker is not retried away: it fails the second time too."""
+    try:
+        mp.spawn(fn, args=(world, _free_port(), total, steps, out_dir), nprocs=world, join=True)
+    except Exception as e:   # noqa: BLE001 -- torch raises ProcessRaisedException / ProcessExitedException / RuntimeError here
+        print('first spawn failed, trying once more:', str(e)[-300:])
+        mp.spawn(fn, args=(world, _free_port(), total, steps, out_dir), nprocs=world, join=True)
+
+
 def _worker(rank, world, port, total, steps, out_dir):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -97,7 +107,7 @@ def test_eight_ranks_uneven_mixed_shards_gather_through_the_benchs_gatherer(tmp_
     AntGather half PointGather on the host executor, `ReturnGatherer` -- the class bench.py drives on a side stream -- exchanging the shard sizes
     and gathering both halves' running returns.  Every snapshot is the single-process result in global-id order."""
     total, steps, world = 37, 15, 8
-    mp.spawn(_worker8, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker8, world, total, steps, str(tmp_path))
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from hrl_pybullet_envs_amd.dist import shard_range
     rets = np.concatenate([np.load(tmp_path / f'ret{r}.npy') for r in range(world)])
@@ -126,7 +136,7 @@ def test_eight_ranks_uneven_mixed_shards_gather_through_the_benchs_gatherer(tmp_
 @pytest.mark.parametrize('total', [12, 13])  # 13: uneven shards (7 + 6), the gather pads to the largest
 def test_two_rank_sharding_matches_single_process(tmp_path, total):
     steps, world = 30, 2
-    mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, world, total, steps, str(tmp_path))
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import emu_env
     import orc
