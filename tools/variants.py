@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B compiler-flag variants of the HIP library in ONE process, interleaved rounds (cdna_hip_programming.md rule 24).
-Variants are built beforehand into build/variants/lib_<name>.so.  GPU box: python tools/variants.py"""
+Variants are built beforehand into build/variants/lib_<name>.so.  GPU box: python tools/variants.py [envs] [kind] [settle steps] [seed]"""
 import ctypes as C
 import glob
 import os
@@ -26,10 +26,12 @@ def bind(path):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     kind = int(sys.argv[2]) if len(sys.argv) > 2 else K.HRL_ANT_GATHER
+    settle = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # untimed steps of every variant before the first timed round (the settled regime: 500)
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     libs = {'product': bind(_lib.LIB_PATH)}
     for p in sorted(glob.glob(os.path.join(ROOT, 'build', 'variants', 'lib_*.so'))):
         libs[os.path.basename(p)[4:-3]] = bind(p)
-    cfg = _lib.default_config(kind, num_envs=n, seed=0, auto_reset=1)
+    cfg = _lib.default_config(kind, num_envs=n, seed=seed, auto_reset=1)
     obs_dim, act_dim = _lib.lib().hrl_obs_dim(C.byref(cfg)), _lib.lib().hrl_act_dim(C.byref(cfg))
     envs = {}
     acts = torch.rand(64, n, act_dim, device='cuda') * 2 - 1
@@ -46,6 +48,8 @@ def main():
             t['final'] = torch.zeros(n, obs_dim, device='cuda'); t['trunc'] = torch.zeros(n, dtype=torch.uint8, device='cuda')
             b.final_obs = t['final'].data_ptr(); b.truncated = t['trunc'].data_ptr()
         L.hrl_reset(h, C.byref(b), None, None)
+        for k in range(settle):
+            b.actions = acts[k % 64].data_ptr(); L.hrl_step(h, C.byref(b), None)
         envs[name] = (L, h, b, t)
     res = {k: [] for k in envs}
     for rnd in range(6):
