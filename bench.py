@@ -302,9 +302,7 @@ def main():
     wd.at('warmup')
     run(args.settle, args.warmup)
     n_warm_gathers = gatherer.k if gatherer is not None else 0
-    for _, env, _, _ in envs:   # solver rows per env over the timed window: the regime the launch time belongs to, in the line itself
-        env.count_solver_rows()
-    torch.cuda.synchronize(dev)   # (after the counters' zero-fill kernel too: set-up work is done before the clock starts)
+    torch.cuda.synchronize(dev)   # set-up work is done before the clock starts; settle, warm-up and timed launches are the SAME launch: the shipped default, no diagnostic output bound
     if world > 1:
         wd.at('barrier before the timed region')
         torch.distributed.barrier()
@@ -353,6 +351,18 @@ def main():
                 'gather_count': len(times), 'gather_every': gather_every, 'gather_bytes_per_rank': 4 * n,
                 'gather_us_max': float(tmax.item()), 'gather_us_median_rank0': float(sorted(times)[len(times) // 2]) if times else None,
                 'collective': 'all_gather_into_tensor of the episode returns on a side stream, off the step path'}
+    # solver rows per env: the regime the launch time belongs to, in the line itself.  Counted in an UNTIMED pass over the launches that follow the window
+    # (the counter is a per-env read-modify-write the shipped configuration does not do, so it is not bound inside the window; the regime is the settled
+    # one either way: an env's row count persists from step to step).  No collective in it.
+    rows_steps = max(1, min(args.steps, 200))
+    for _, env, _, _ in envs:
+        env.count_solver_rows()
+    t_rows = args.settle + args.warmup + args.steps
+    for t in range(t_rows, t_rows + rows_steps):
+        for _, env, acts, stream in envs:
+            with torch.cuda.stream(stream):
+                env.step(acts[t % T])
+    torch.cuda.synchronize(dev)
     if world > 1:  # all collectives are done: leave the group before rank 0 spends ~25 s of host time on the CPU baseline
         wd.at('final barrier')
         torch.distributed.barrier()
@@ -382,12 +392,13 @@ def main():
             # True: at least 200 untimed steps (settle + warmup) lie between the reset and the timed window -- the ants stand, the contact count and
             # with it the launch time have levelled off (launches are ~5 % shorter in the first 50 steps after a reset)
             'steady_state': args.settle + args.warmup >= 200, 'settle_steps': args.settle,
-            # mean constraint rows per env and env step in the timed window (joint limits + 3 per contact, summed over the 4 substeps): the sweeps
-            # are serial in the rows, so this is the regime the launch time belongs to (hrl_buffers.solver_rows)
-            'solver_rows_per_env_step': {k: float(env.solver_rows.sum().item()) / (env.num_envs * args.steps) for k, env, _, _ in envs},
-            # the env with the most rows over the window: a launch lasts as long as its slowest env's chain (one env of 4096 that lies against a wall with 12
+            # mean constraint rows per env and env step (joint limits + 3 per contact, summed over the 4 substeps) over the `solver_rows_steps` untimed launches
+            # right after the timed window: the sweeps are serial in the rows, so this is the regime the launch time belongs to (hrl_buffers.solver_rows)
+            'solver_rows_per_env_step': {k: float(env.solver_rows.sum().item()) / (env.num_envs * rows_steps) for k, env, _, _ in envs},
+            # the env with the most rows: a launch lasts as long as its slowest env's chain (one env of 4096 that lies against a wall with 12
             # contacts, 23 rows per substep instead of 20, makes every launch 3 - 4 us longer)
-            'solver_rows_max_env': {k: float(env.solver_rows.max().item()) / args.steps for k, env, _, _ in envs},
+            'solver_rows_max_env': {k: float(env.solver_rows.max().item()) / rows_steps for k, env, _, _ in envs},
+            'solver_rows_steps': rows_steps,
             'config': {'workload': f'{shard}, U(-1,1) actions pre-generated on device, auto-reset, max_episode_steps 2000',
                        'envs_per_gpu': n, 'global_envs': world * n,
                        'substeps_per_step': 4,

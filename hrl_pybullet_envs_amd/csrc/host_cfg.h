@@ -210,7 +210,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.flag_size = c.flag_size; d.flag_max_targets = c.flag_max_targets; d.flag_timeout = c.flag_timeout;
     d.flag_switch = c.flag_switch_on_collision; d.flag_mtd = c.flag_max_target_dist; d.flag_manual = c.flag_manual_goals;
     d.self_collision = m.self_collision; d.item_collision = m.item_collision; d.mu_self = m.friction_robot * m.friction_robot;
-    d.flag_path_on = c.env_kind == HRL_ANT_FLAGRUN && (c.flag_manual_goals || c.flag_max_target_dist > 0.f || c.flag_path_rew_weight != 0.f);
+    d.flag_path_on = c.env_kind == HRL_ANT_FLAGRUN; /* set_target() keeps `_goal_start_pos` / `_sq_dist_goal` whatever the weights are (ant_flagrun_env.py:98-103): a path reward weight switched on for a live env finds them */
     d.w_elec = c.walker_electricity_cost; d.w_stall = c.walker_stall_torque_cost; d.w_jal = c.walker_joints_at_limit_cost;
     d.flag_w_env = c.flag_ant_env_rew_weight; d.flag_w_path = c.flag_path_rew_weight; d.flag_w_dist = c.flag_dist_rew_weight; d.flag_goal_rew = c.flag_goal_reach_rew;
     d.max_contacts = m.max_contacts;

@@ -373,6 +373,11 @@ int hrl_update_config(hrl_handle *h, const hrl_config *cfg, void *stream) {
     if (cfg->env_kind != h->cfg.env_kind || cfg->num_envs != h->cfg.num_envs || obs_dim(cfg) != obs_dim(&h->cfg) || act_dim(cfg) != act_dim(&h->cfg) ||
         items_stride(cfg) != items_stride(&h->cfg))
         return fail(HRL_ERR_BAD_ARG, "hrl_update_config: env_kind, num_envs, the observation / action width and the items stride belong to the buffers and cannot change on a live handle");
+    /* what decides the MEANING of the records the caller holds: new item slots would be read uninitialised, another goal mode reads the flagrun record differently */
+    if (cfg->n_food != h->cfg.n_food || cfg->n_poison != h->cfg.n_poison)
+        return fail(HRL_ERR_BAD_ARG, "hrl_update_config: n_food / n_poison cannot change on a live handle (the items record holds exactly these items: make a new handle and reset)");
+    if (cfg->flag_manual_goals != h->cfg.flag_manual_goals || (cfg->flag_max_target_dist > 0) != (h->cfg.flag_max_target_dist > 0) || cfg->flag_goal_capacity != h->cfg.flag_goal_capacity)
+        return fail(HRL_ERR_BAD_ARG, "hrl_update_config: the goal mode of a flagrun env (manual goals, goals near the robot, the list capacity) cannot change on a live handle");
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device)
         return fail(HRL_ERR_BAD_ARG, "hrl_update_config: the handle was created on HIP device " + std::to_string(h->device) + ", the current device is " + std::to_string(cur));
@@ -388,7 +393,7 @@ int hrl_update_config(hrl_handle *h, const hrl_config *cfg, void *stream) {
 static bool needs_items(const DevCfg &dc) {
     return dc.kind == HRL_ANT_GATHER || dc.kind == HRL_POINT_GATHER || (dc.kind == HRL_ANT_FLAGRUN && dc.flag_path_on);
 }
-static const char *items_why = "this env keeps state in the items buffer (gather kinds; flagrun with max_target_dist, manual goals or a path reward weight)";
+static const char *items_why = "this env keeps state in the items buffer (gather kinds: the item positions; flagrun: the goal bookkeeping of set_target())";
 
 int hrl_reset(hrl_handle *h, const hrl_buffers *b, const uint8_t *mask, void *stream) {
     if (const int rc = check_call(h, b, "hrl_reset")) return rc;

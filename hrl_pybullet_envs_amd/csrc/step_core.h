@@ -88,7 +88,7 @@ struct DevCfg {
     int obs_dim, act_dim;
     float flag_w_env, flag_w_path, flag_w_dist, flag_goal_rew; /* ant_flagrun_env.py:157-160 */
     float w_elec, w_stall, w_jal; /* upstream WalkerBaseBulletEnv.electricity_cost / stall_torque_cost / joints_at_limit_cost (AntMaze -2, -0.1, -0.1; AntFlagrun 0, 0, 0) */
-    int flag_path_on;             /* the env keeps `_goal_start_pos` / `_sq_dist_goal` in its items record (manual goals, goals near the robot, or a path reward weight) */
+    int flag_path_on;             /* the env keeps `_goal_start_pos` / `_sq_dist_goal` in its items record: every flagrun env (set_target() does, whatever the reward weights are) */
     int max_contacts;             /* contacts kept per substep, <= MAXC */
     int damping_on;               /* hrl_model.linear_damping / angular_damping (damp_lin / damp_ang) are not both zero: every body gets Bullet's damping wrench */
     float damp_lin, damp_ang;
@@ -2185,7 +2185,7 @@ HRL_DEV void reset_env(X &x, const DevCfg &c, long long env) {
                 L.items[2 * i] = px; L.items[2 * i + 1] = py;
             }
         } else if (KIND == 5 && c.flag_path_on) { /* lanes 32..63: the first 32 words of the items record (flagrun layout: include/hrl_envs.h, HRL_FLAG_*; an env
-                                                     of the shared goal list without a path reward keeps nothing in it) */
+                                                     of the shared goal list keeps set_target()'s bookkeeping in it, not the goal) */
             const int w = lane - 32;
             if (c.flag_manual) { /* the walk target and the path-reward state survive the reset, the pending goals do not (ant_flagrun_env.py:149-152) */
                 if (w == 0) L.items[0] = ptx;

@@ -66,31 +66,22 @@ class AntFlagrunBulletEnv(BatchedGymEnv):
         """step() reads the four weights off AntFlagrunBulletEnv (:169-186) and super().step() the three costs off WalkerBaseBulletEnv, every time:
         a change of a class attribute reaches the kernel with the next step (weights set through set_reward_weights() belong to this env alone
         and stay until the CLASS attribute changes again)."""
-        cls, c = type(self), self._cfg
+        cls = type(self)
         now = (float(cls.ant_env_rew_weight), float(cls.path_rew_weight), float(cls.dist_rew_weight), float(cls.goal_reach_rew)) + walker_costs()
         if now != self._class_weights_seen:
-            changed = [a != b for a, b in zip(now, self._class_weights_seen)]
             names = ('flag_ant_env_rew_weight', 'flag_path_rew_weight', 'flag_dist_rew_weight', 'flag_goal_reach_rew',
                      'walker_electricity_cost', 'walker_stall_torque_cost', 'walker_joints_at_limit_cost')
-            for name, v, ch in zip(names, now, changed):
-                if ch:
-                    setattr(c, name, v)
-            self._class_weights_seen = now
-            if self._env is not None:
-                self._env.update_config(c)
+            self._change_config(**{name: v for name, v, seen in zip(names, now, self._class_weights_seen) if v != seen})
+            self._class_weights_seen = now   # (after the library took them: a refused change is tried again at the next step)
 
     def set_reward_weights(self, ant_env_rew_weight=None, path_rew_weight=None, dist_rew_weight=None, goal_reach_rew=None):
         """Changes the reward weights of THIS env (None: keep), in place on a running env (hrl_update_config) -- what assigning to the class
-        attribute does in the reference, whose step() reads it every time.  Switching a path reward on for an env built without one (shared goal
-        list, no record of where the robot stood when it got its goal) starts the path bookkeeping at the next goal / reset."""
-        c = self._cfg
-        new = [c.flag_ant_env_rew_weight if ant_env_rew_weight is None else float(ant_env_rew_weight),
-               c.flag_path_rew_weight if path_rew_weight is None else float(path_rew_weight),
-               c.flag_dist_rew_weight if dist_rew_weight is None else float(dist_rew_weight),
-               c.flag_goal_reach_rew if goal_reach_rew is None else float(goal_reach_rew)]
-        c.flag_ant_env_rew_weight, c.flag_path_rew_weight, c.flag_dist_rew_weight, c.flag_goal_reach_rew = new
-        if self._env is not None:
-            self._env.update_config(c)
+        attribute does in the reference, whose step() reads it every time.  A path reward switched on mid-episode is measured from where the robot
+        stood when it got its CURRENT goal, as in the reference: every flagrun env keeps set_target()'s `_goal_start_pos` / `_sq_dist_goal`
+        (ant_flagrun_env.py:98-103) in its items record whatever the weight is."""
+        new = dict(flag_ant_env_rew_weight=ant_env_rew_weight, flag_path_rew_weight=path_rew_weight, flag_dist_rew_weight=dist_rew_weight,
+                   flag_goal_reach_rew=goal_reach_rew)
+        self._change_config(**{k: float(v) for k, v in new.items() if v is not None})
 
     reward_weights = property(lambda self: dict(ant_env_rew_weight=self._cfg.flag_ant_env_rew_weight, path_rew_weight=self._cfg.flag_path_rew_weight,
                                                 dist_rew_weight=self._cfg.flag_dist_rew_weight, goal_reach_rew=self._cfg.flag_goal_reach_rew))

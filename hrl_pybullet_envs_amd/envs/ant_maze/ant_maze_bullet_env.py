@@ -36,9 +36,7 @@ class AntMazeBulletEnv(BatchedGymEnv):
         AntFlagrunBulletEnv.reset() anywhere in the process has set them to 0, ant_flagrun_env.py:133-135)."""
         c, w = self._cfg, walker_costs()
         if (c.walker_electricity_cost, c.walker_stall_torque_cost, c.walker_joints_at_limit_cost) != tuple(np.float32(x) for x in w):
-            c.walker_electricity_cost, c.walker_stall_torque_cost, c.walker_joints_at_limit_cost = w
-            if self._env is not None:
-                self._env.update_config(c)
+            self._change_config(walker_electricity_cost=w[0], walker_stall_torque_cost=w[1], walker_joints_at_limit_cost=w[2])
 
     @property
     def stadium_scene(self):

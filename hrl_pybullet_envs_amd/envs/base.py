@@ -71,9 +71,17 @@ class BatchedGymEnv:
             raise ValueError('max_episode_steps must be >= 0 (0: no limit)')
         if n == self._cfg.max_episode_steps:
             return
-        self._cfg.max_episode_steps = n
-        if self._env is not None:   # a constant of the library handle: replaced in place (hrl_update_config), buffers and pinned host memory stay
-            self._env.update_config(self._cfg)
+        self._change_config(max_episode_steps=n)   # a constant of the library handle: replaced in place (hrl_update_config), buffers and pinned host memory stay
+
+    def _change_config(self, **fields):
+        """Fields of hrl_config changed on a COPY, handed to the live handle (hrl_update_config) and committed to `self._cfg` only when the library
+        took them: a refused change (it raises, with the library's reason) leaves host and device configs equal."""
+        c = type(self._cfg).from_buffer_copy(self._cfg)
+        for k, v in fields.items():
+            setattr(c, k, v)
+        if self._env is not None:
+            self._env.update_config(c)
+        self._cfg = c
 
     # what gym.make()'s TimeLimit wrapper and registration leave on the object a user of the reference holds (hrl_pybullet_envs/__init__.py:11-16):
     # `env._max_episode_steps`, `env._elapsed_steps` (gym.wrappers.TimeLimit), `env.spec.id` / `.max_episode_steps` (set by make())
@@ -116,11 +124,11 @@ class BatchedGymEnv:
         return self._env
 
     def seed(self, seed=None):
-        """ant_gather_env.py:63-66 / ant_maze_bullet_env.py:99-102: reseeds the env's RNG streams."""
-        self._cfg.seed = 0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
-        if self._env is not None:
-            self._env.close()
-            self._env = None
+        """ant_gather_env.py:63-66 + gather_scene.py:35-36 / ant_maze_bullet_env.py:99-102: reseeds the env's RNG, the simulation carries on.
+        On a live env the seed is a constant of the library handle replaced in place (hrl_update_config): state, items, counters, the tensors
+        handed out and the pinned host buffers stay as they are; the streams are counter-based functions of (seed, env id, counters), so the
+        next respawn / reset / maze target / goal is drawn from the new seed's stream and nothing else moves."""
+        self._change_config(seed=0 if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF)
         return [seed]
 
     def reset(self, mask=None):

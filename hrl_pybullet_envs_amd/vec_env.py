@@ -54,11 +54,11 @@ class BatchedEnv:
                             # valid where done: the terminal observation (the returned obs of such an env is already the next episode's first
                             # when auto_reset is on) and gym's TimeLimit flag
                             'final_observation': o['final_obs'], 'TimeLimit.truncated': o['truncated']}
-        # the items record is state of the gather kinds (item positions) and of a flagrun env with manual goals or goals near the robot; the other
-        # kinds keep nothing in it, and the library takes NULL for it (include/hrl_envs.h): 128 B per env and step less to read and to write back
+        # the items record is state of the gather kinds (item positions) and of every flagrun env (the bookkeeping of set_target(); the goal itself in the
+        # manual and near-the-robot modes); the other kinds keep nothing in it, and the library takes NULL for it (include/hrl_envs.h): 128 B per
+        # env and step less to read and to write back
         c = self.cfg
-        self._uses_items = c.env_kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) or \
-            (c.env_kind == K.HRL_ANT_FLAGRUN and (bool(c.flag_manual_goals) or c.flag_max_target_dist > 0 or c.flag_path_rew_weight != 0))
+        self._uses_items = c.env_kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER, K.HRL_ANT_FLAGRUN)
         goal = o['goal'].data_ptr() if 'goal' in o else None
         if 'goal' in o:  # `target`: the goal after the step; `retargeted`: the rows whose step switched to it (the reference sets info['target'] on those steps only)
             self._info_views['target'] = o['goal'][:, 0:2]
@@ -112,13 +112,6 @@ class BatchedEnv:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hrl_update_config(self._h, C.byref(cfg), self._stream()))
         self.cfg = cfg
-        uses = cfg.env_kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) or \
-            (cfg.env_kind == K.HRL_ANT_FLAGRUN and (bool(cfg.flag_manual_goals) or cfg.flag_max_target_dist > 0 or cfg.flag_path_rew_weight != 0))
-        if uses != self._uses_items:   # a flagrun env whose path reward was switched on / off: the items record joins / leaves the launches
-            self._uses_items = uses
-            self._bufs.items = self.items.data_ptr() if uses else None
-            if self._host is not None:
-                self._hbufs.items = self._bufs.items
 
     def count_solver_rows(self, on=True):
         """Diagnostic: from now on every step ADDS to `self.solver_rows` [N] (int32, zeroed here) the constraint rows each env's solver held
@@ -127,6 +120,8 @@ class BatchedEnv:
         p = self.solver_rows.data_ptr() if on else None
         self._bufs.solver_rows = p
         self._bufs_with_items.solver_rows = p
+        if self._host is not None:   # step_host()'s record too
+            self._hbufs.solver_rows = p
         return self.solver_rows
 
     def close(self):
@@ -198,6 +193,7 @@ class BatchedEnv:
             self._hbufs = K.make_buffers(self.state.data_ptr(), self.items.data_ptr() if self._uses_items else None, self.aux.data_ptr(), t['act'].data_ptr(),
                                          t['obs'].data_ptr(), t['rew'].data_ptr(), t['done'].data_ptr(), t['info'].data_ptr(),
                                          t['final_obs'].data_ptr(), t['trunc'].data_ptr(), t['goal'].data_ptr() if 'goal' in t else None)
+            self._hbufs.solver_rows = self._bufs.solver_rows   # the diagnostic counter, when count_solver_rows() switched it on
         h = self._host_np
         h['act'][...] = actions
         with torch.cuda.device(self.device):

@@ -176,7 +176,8 @@ typedef struct hrl_config {
     /* ABI v7: the class-level reward weights of AntFlagrunBulletEnv (ant_flagrun_env.py:157-160), read by step() as
      * r = ant_env_rew_weight * r_upstream + path_rew_weight * path_rew - dist_rew_weight * walk_target_dist (:169-178), + goal_reach_rew once per
      * goal (:184-186).  path_rew (:174-176) needs where the robot stood and how far the goal was when the goal was set (:100-103): kept in the
-     * items record (HRL_FLAG_START_OFF, HRL_FLAG_SQDIST_OFF), so a config with path_rew_weight != 0 must be given `items`. */
+     * items record (HRL_FLAG_START_OFF, HRL_FLAG_SQDIST_OFF) by EVERY flagrun env whatever the weight is -- as the reference's set_target() does --, so a weight
+     * switched on for a live env (hrl_update_config) finds them: a flagrun env must be given `items`. */
     float flag_ant_env_rew_weight, flag_path_rew_weight, flag_dist_rew_weight, flag_goal_reach_rew; /* 1, 0, 0, 5000 */
     /* ABI v7: the class-level cost weights of upstream WalkerBaseBulletEnv, which the reward of `super().step()` is made of in AntMazeBulletEnv
      * and AntFlagrunBulletEnv (alive + progress + electricity_cost * mean|a * joint_speed| + stall_torque_cost * mean(a^2)
@@ -195,7 +196,7 @@ typedef struct hrl_config {
 typedef struct hrl_buffers {
     uint64_t struct_size; /* sizeof(hrl_buffers) of the header the CALLER was compiled against (hrl_buffers_init sets it) */
     float *state;         /* [N][HRL_STATE_STRIDE]  in/out */
-    float *items;         /* [N][hrl_items_stride()] in/out (gather kinds; flagrun with max_target_dist, manual goals or a path reward); the other kinds keep nothing in it: pass NULL and the record is neither read nor written */
+    float *items;         /* [N][hrl_items_stride()] in/out (gather kinds: the item positions; flagrun: set_target()'s bookkeeping, and the goals of the manual / near-the-robot modes); the other kinds keep nothing in it: pass NULL and the record is neither read nor written */
     int32_t *aux;         /* [N][HRL_AUX_STRIDE]    in/out */
     const float *actions; /* [N][act_dim]           in  (step only) */
     float *obs;           /* [N][obs_dim]           out */
@@ -244,8 +245,13 @@ int hrl_destroy(hrl_handle *h);
 /* Replaces the handle's config by `cfg`, on `stream` (in order with the launches queued there): what changes on a LIVE env in the reference --
  * `env.max_episode_steps` of gym's TimeLimit, AntFlagrunBulletEnv's class-level reward weights (ant_flagrun_env.py:157-160, read in every step),
  * tolerances, timeouts, the engine parameters of hrl_model ... -- without a new handle: state, items, aux and every buffer of the caller stay as
- * they are.  env_kind, num_envs and what the buffers' shapes depend on (observation / action width, items stride) must be what they were
- * (HRL_ERR_BAD_ARG, nothing changed).  The constants are copied at the call (cfg may be freed on return). */
+ * they are.  env_kind, num_envs, what the buffers' shapes depend on (observation / action width, items stride) and what the records' MEANING
+ * depends on (n_food / n_poison: new slots would be uninitialised; a flagrun env's goal mode and list capacity) must be what they were, and cfg
+ * must be a valid config (HRL_ERR_BAD_ARG, nothing changed; a NULL cfg included).  `seed` MAY change: that is `env.seed(s)` on a live env
+ * (ant_gather_env.py:63-66, gather_scene.py:35-36 -- the RNG is reseeded, the simulation carries on): the random streams are counter-based
+ * functions of (seed, global env id, counters in aux), so the draws that follow -- respawns, resets, goals -- come from the new seed's streams and
+ * nothing else moves.  `env_id_offset` may change likewise (the shard is then taken to hold other global ids from the next draw on).
+ * The constants are copied at the call (cfg may be freed on return). */
 int hrl_update_config(hrl_handle *h, const hrl_config *cfg, void *stream);
 
 /* Replaces Env.reset() (ant_gather_env.py:68-74, gather_base.py:67-72, ant_maze_bullet_env.py:104-121,
@@ -264,7 +270,9 @@ int hrl_buffers_init(hrl_buffers *b);
 /* The observation of the state AS IT IS in bufs (state, items, aux) into bufs->obs, without stepping: what the reference does after a
  * teleport -- `resetBasePositionAndOrientation(...)`, `robot.calc_state()`, `_get_obs()` (ant_maze_bullet_env.py:117-121; upstream
  * calc_state + ant_gather_env.py:121-125 get_food_obs, sizeable_enclosed_scene.py:63-97 sense_walls, point_bot.py:48-67).  Nothing but `obs`
- * is written (no pickups, no counters, no reward; feet-contact entries 0 as after a reset).  Envs with mask[i] == 0 keep their row
+ * is written (no pickups, no counters, no reward; the feet-contact entries of AntMaze / AntFlagrun are what robot.feet_contact holds in the
+ * reference at that point: the flags the LAST STEP left in bits 28..31 of aux[1], zeros after a reset -- a replay that wants zeros clears those
+ * bits with the state it writes).  Envs with mask[i] == 0 keep their row
  * (mask == NULL: all).  hrl_set_state() + hrl_observe() is how identical-state parity tests replay the reference's fixtures on the device. */
 int hrl_observe(hrl_handle *h, const hrl_buffers *bufs, const uint8_t *mask, void *stream);
 

@@ -1504,7 +1504,7 @@ void FN(orc_env_init)(const hrl_config *cfg, FN(orc_env) * E) {
 }
 
 /* the env keeps `_goal_start_pos` / `_sq_dist_goal` in its items record (HRL_FLAG_START_OFF, HRL_FLAG_SQDIST_OFF) */
-static int FN(flag_path_on)(const hrl_config *cfg) { return cfg->flag_manual_goals || cfg->flag_max_target_dist > 0 || cfg->flag_path_rew_weight != 0; }
+static int FN(flag_path_on)(const hrl_config *cfg) { (void)cfg; return 1; } /* set_target() keeps both whatever the weights are (ant_flagrun_env.py:98-103), so a weight switched on for a live env finds them */
 /* the goal a flagrun env is chasing: kept in items[0..1] (max_target_dist and manual modes) or the k-th of the shared list */
 static void FN(flag_current_goal)(const hrl_config *cfg, const REAL *items, const int32_t *aux, REAL *g) {
     if (cfg->flag_max_target_dist > 0 || cfg->flag_manual_goals) { g[0] = items[0]; g[1] = items[1]; }
@@ -1603,7 +1603,7 @@ void FN(orc_env_reset_one)(const FN(orc_env) * E, int64_t env, REAL *st, REAL *i
     }
     aux[0] = 0; aux[2] = (int32_t)(ep + 1); /* NB: the flagrun goal stream is keyed by the NEW episode index */
     if (cfg->env_kind == HRL_ANT_MAZE || cfg->env_kind == HRL_ANT_FLAGRUN) aux[1] &= 0x0fffffff; /* robot.feet_contact = 0 (upstream robot_specific_reset) */
-    if (cfg->env_kind == HRL_ANT_FLAGRUN && items && FN(flag_path_on)(cfg)) { /* an env of the shared goal list without a path reward keeps nothing in the record */
+    if (cfg->env_kind == HRL_ANT_FLAGRUN && items && FN(flag_path_on)(cfg)) { /* an env of the shared goal list keeps set_target()'s bookkeeping in the record, not the goal */
         if (cfg->flag_manual_goals) { /* the walk target and the path-reward state survive the reset (:149-152), pending goals do not */
             for (int i = HRL_FLAG_PENDING_OFF; i < orc_items_stride(cfg); ++i) items[i] = 0;
             items[0] = prev_target[0]; items[1] = prev_target[1];

@@ -18,13 +18,29 @@ def _free_port():
     return p
 
 
+_RENDEZVOUS = ('address already in use', 'eaddrinuse', 'connection refused', 'connection reset', 'timed out', 'timeout', 'socket', 'connect() ',
+               'failed to connect', 'rendezvous', 'store')
+
+
+def _rendezvous_failure(e):
+    """True for what a port race or a slow peer raises while the process group comes up (TCPStore / gloo connect errors, init timeouts); an
+    AssertionError anywhere in the worker's traceback is never one."""
+    text = str(e).lower()
+    return 'assertionerror' not in text and any(k in text for k in _RENDEZVOUS)
+
+
 def _spawn(fn, world, total, steps, out_dir):
-    """mp.spawn on a free port; ONE more try on another port if the rendezvous itself fails (the port found free was taken in between, a peer
-    was slow to come up on a loaded machine) -- an assertion inside a worker is not retried away: it fails the second time too."""
+    """mp.spawn on a free port; ONE more try on another port -- into an emptied out_dir -- when the RENDEZVOUS itself failed (the port found free
+    was taken in between, a peer was slow to come up on a loaded machine).  Anything else a worker raises, an assertion first of all, is raised at
+    once: a racy failure of the sharding or of ReturnGatherer must not pass on a second try."""
     try:
         mp.spawn(fn, args=(world, _free_port(), total, steps, out_dir), nprocs=world, join=True)
     except Exception as e:   # noqa: BLE001 -- torch raises ProcessRaisedException / ProcessExitedException / RuntimeError here
-        print('first spawn failed, trying once more:', str(e)[-300:])
+        if not _rendezvous_failure(e):
+            raise
+        print('rendezvous failed, trying once more on another port:', str(e)[-300:])
+        for f in os.listdir(out_dir):
+            os.remove(os.path.join(out_dir, f))
         mp.spawn(fn, args=(world, _free_port(), total, steps, out_dir), nprocs=world, join=True)
 
 
@@ -151,3 +167,12 @@ def test_two_rank_sharding_matches_single_process(tmp_path, total):
     fin = np.concatenate([np.load(tmp_path / f'final{r}.npy') for r in range(world)])   # terminal observations (the 20-step limit has passed) + last truncation flags
     assert np.array_equal(fin[:, :-1], full.final_obs) and np.array_equal(fin[:, -1], full.truncated) and np.any(full.final_obs != 0)
     assert np.array_equal(np.load(tmp_path / 'gathered.npy'), full.info[:, 2])
+
+
+def test_only_rendezvous_failures_are_retried():
+    """an assertion inside a worker is raised at once (a racy sharding bug must not pass on the second try); a port race is retried"""
+    assert _rendezvous_failure(RuntimeError('The server socket has failed to listen on any local network address. Address already in use'))
+    assert _rendezvous_failure(RuntimeError('[c10d] the client socket has timed out after 300s while trying to connect to (127.0.0.1, 29500)'))
+    assert not _rendezvous_failure(Exception('-- Process 1 terminated with the following error:\nTraceback ...\nAssertionError: (3, state)'))
+    assert not _rendezvous_failure(Exception('Traceback ... socket ... AssertionError: gathered'))
+    assert not _rendezvous_failure(ValueError('shapes (5,) (4,) differ'))

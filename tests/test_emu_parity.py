@@ -854,3 +854,42 @@ def test_feet_contact_flags_show_the_previous_step():
     for t in range(20):
         o.step(np.zeros((4, 8), np.float32))
     assert np.all(o.obs[:, 22:26] == 0) and np.all(o.aux[:, 1] == 20)
+
+
+def test_flagrun_path_reward_switched_on_for_a_live_env():
+    """`AntFlagrunBulletEnv.path_rew_weight = 0.5` while an env runs (ant_flagrun_env.py:158,174-176): set_target() has kept `_goal_start_pos` and
+    `_sq_dist_goal` all along (:98-103), so the very next step pays a finite path reward measured from where the robot stood when it got its
+    CURRENT goal.  Every flagrun env keeps both in its items record whatever the weight is -- with the bookkeeping tied to the weight the record
+    of a default env was all zeros and the first steps after the switch paid +-inf (x / 0) until the next goal or reset."""
+    n = 12
+    cfg = orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=9, auto_reset=1, flag_timeout=25, max_episode_steps=2000)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    assert np.all(o.items[:, K.HRL_FLAG_SQDIST_OFF] >= 0.25) and np.all(o.items[:, K.HRL_FLAG_START_OFF:K.HRL_FLAG_START_OFF + 2] == 0)   # goals >= 0.5 from the start (:71-78)
+    rng = np.random.RandomState(1)
+    checked = 0
+    for t in range(90):
+        if t == 33:   # mid-episode, between two goal switches
+            cfg.flag_path_rew_weight = 0.5
+        if t == 70:   # off and on again: the start position is the CURRENT goal's, not a stale one
+            cfg.flag_path_rew_weight = 0.0
+        if t == 75:
+            cfg.flag_path_rew_weight = 0.5
+        xy0, start, sqd = o.state[:, 0:2].copy(), o.items[:, 2:4].copy(), o.items[:, 4].copy()
+        goal = np.zeros((n, 2), np.float32)
+        for i in range(n):
+            orc.lib().orc_flag_goal_f32(C.byref(cfg), int(o.aux[i, 2]), int(o.aux[i, 3] & 0xffff), orc.ptr(goal[i]))
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        o.step(a); e.step(a)
+        for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info', 'goal'):
+            assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, name)
+        assert np.all(np.isfinite(o.rew)), (t, o.rew)
+        keep = (o.done == 0) & (o.goal[:, 2] == 0) & (o.rew < 1000)   # the rows whose record was not rewritten by this step (no switch, no reset, no goal reward)
+        xy = o.state[:, 0:2].astype(np.float64)
+        path = ((xy - start) * (goal.astype(np.float64) - start)).sum(1) / sqd
+        want = (o.info[:, 0].astype(np.float64) + o.info[:, 1]) + cfg.flag_path_rew_weight * path
+        assert np.allclose(o.rew[keep], want[keep], rtol=1e-5, atol=1e-4), (t, o.rew[keep], want[keep])
+        if cfg.flag_path_rew_weight:
+            checked += int(keep.sum())
+            assert not keep.any() or np.abs(path[keep]).max() < 50
+    assert checked > 300

@@ -1014,3 +1014,125 @@ def test_the_measuring_tools_of_the_readme_run():
     for cmd, expect in runs:
         r = subprocess.run([sys.executable] + cmd, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and expect in r.stdout, (cmd, r.returncode, r.stdout[-400:], r.stderr[-800:])
+
+
+def test_seed_on_a_live_env_keeps_the_simulation():
+    """ant_gather_env.py:63-66 + gather_scene.py:35-36: `env.seed(s)` reseeds the RNGs, the simulation carries on.  Here the seed is a constant of
+    the live handle (hrl_update_config): state, items, counters, tensors stay bit for bit; the next respawn and the next reset draw from the new
+    seed's counter-based streams -- equal to the oracle's with its seed changed at the same step."""
+    import hrl_pybullet_envs_amd as H
+    n = 64
+    env = H.AntGatherBulletEnv(num_envs=n, seed=3)
+    o = orc.OracleEnv(orc.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=3, auto_reset=1, max_episode_steps=2000), np.float32)
+    ob = env.reset(); o.reset()
+    be = env._backend()
+    handle, ptrs = be._h, (be.state.data_ptr(), be.items.data_ptr(), be.aux.data_ptr(), ob.data_ptr())
+    rng = np.random.RandomState(5)
+    for t in range(5):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        ob, r, d, info = env.step(torch.from_numpy(a).cuda()); o.step(a)
+    before = [x.cpu().numpy().copy() for x in (be.state, be.items, be.aux)]
+    assert env.seed(7) == [7]
+    o.cfg.seed = 7
+    assert env._backend() is be and be._h == handle and ptrs == (be.state.data_ptr(), be.items.data_ptr(), be.aux.data_ptr(), ob.data_ptr())   # no new handle, no new tensors
+    for x, y in zip((be.state, be.items, be.aux), before):
+        assert np.array_equal(x.cpu().numpy(), y)   # nothing moved
+    # ants put onto items: pickups whose respawn positions come from seed 7's stream
+    o.state[::2, 0:2] = o.items[::2, 0:2] + np.float32(0.1)
+    be.state.copy_(torch.from_numpy(o.state))
+    a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+    items_before = o.items.copy()
+    ob, r, d, info = env.step(torch.from_numpy(a).cuda()); o.step(a)
+    assert (o.rew[::2] >= 1).sum() > n // 4 and (o.items != items_before).any(axis=1).sum() > n // 4
+    for name, x in (('state', be.state), ('items', be.items), ('aux', be.aux), ('obs', ob), ('rew', r)):
+        assert np.array_equal(x.cpu().numpy(), getattr(o, name)), name
+    # the same pickups under the OLD seed put the items elsewhere: the new seed is what was used
+    o3 = orc.OracleEnv(orc.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=3, auto_reset=1, max_episode_steps=2000), np.float32)
+    o3.state[...] = before[0]; o3.items[...] = before[1]; o3.aux[...] = before[2]
+    o3.state[::2, 0:2] = o3.items[::2, 0:2] + np.float32(0.1)
+    o3.step(a)
+    assert not np.array_equal(o3.items, o.items)
+    mask = torch.zeros(n, dtype=torch.uint8, device='cuda'); mask[1::4] = 1
+    ob = env.reset(mask); o.reset(mask.cpu().numpy())   # a reset after the reseed: the new seed's reset streams
+    assert np.array_equal(be.state.cpu().numpy(), o.state) and np.array_equal(be.items.cpu().numpy(), o.items) and np.array_equal(ob.cpu().numpy(), o.obs)
+    env.close()
+    # AntMazeBulletEnv keeps its own `rs` for the target draw (ant_maze_bullet_env.py:48,99-102,110): same constant here
+    mz = H.AntMazeBulletEnv(num_envs=32, seed=1)
+    om = orc.OracleEnv(orc.default_config(K.HRL_ANT_MAZE, num_envs=32, seed=1, auto_reset=1, max_episode_steps=2000), np.float32)
+    mz.reset(); om.reset()
+    for t in range(3):
+        a = rng.uniform(-1, 1, (32, 8)).astype(np.float32)
+        mz.step(torch.from_numpy(a).cuda()); om.step(a)
+    mz.seed(11); om.cfg.seed = 11
+    assert np.array_equal(mz._backend().state.cpu().numpy(), om.state)
+    ob = mz.reset(); om.reset()
+    assert np.array_equal(mz._backend().aux.cpu().numpy(), om.aux) and np.array_equal(ob.cpu().numpy(), om.obs)
+    # the one-env object of the README loop: seed() between steps keeps the pinned host buffers too
+    e1 = H.AntGatherBulletEnv(seed=2)
+    e1.reset()
+    e1.step(np.zeros(8)); hb = e1._backend()._host
+    e1.seed(5)
+    ob1, _, _, _ = e1.step(np.zeros(8))
+    assert e1._backend()._host is hb and e1._cfg.seed == 5 and np.all(np.isfinite(ob1))
+    e1.close()
+
+
+def test_flagrun_path_reward_switched_on_mid_episode_is_finite_and_matches_the_oracle():
+    """`env.set_reward_weights(path_rew_weight=...)` / `AntFlagrunBulletEnv.path_rew_weight = ...` on a running env built without a path
+    reward paid +-inf until the next goal (x / 0: the record of set_target()'s bookkeeping was only kept when the weight was on).  Every flagrun env
+    keeps it now (ant_flagrun_env.py:98-103 does, whatever the weights are)."""
+    import hrl_pybullet_envs_amd as H
+    n = 96
+    env = H.AntFlagrunBulletEnv(timeout=30, num_envs=n, seed=8)
+    o = orc.OracleEnv(orc.default_config(K.HRL_ANT_FLAGRUN, num_envs=n, seed=8, auto_reset=1, flag_timeout=30, max_episode_steps=2000), np.float32)
+    env.reset(); o.reset()
+    be = env._backend()
+    assert np.array_equal(be.items.cpu().numpy(), o.items) and np.all(o.items[:, K.HRL_FLAG_SQDIST_OFF] > 0)
+    rng = np.random.RandomState(2)
+    try:
+        for t in range(60):
+            if t == 17:
+                env.set_reward_weights(path_rew_weight=0.5); o.cfg.flag_path_rew_weight = 0.5
+            if t == 40:   # ... and through the class attribute, as the reference's users do
+                H.AntFlagrunBulletEnv.path_rew_weight = 1.5; o.cfg.flag_path_rew_weight = 1.5
+            a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+            ob, r, d, info = env.step(torch.from_numpy(a).cuda()); o.step(a)
+            rr = r.cpu().numpy()
+            assert np.all(np.isfinite(rr)), (t, rr)
+            assert np.array_equal(rr, o.rew) and np.array_equal(be.items.cpu().numpy(), o.items) and np.array_equal(be.state.cpu().numpy(), o.state), t
+    finally:
+        H.AntFlagrunBulletEnv.path_rew_weight = 0
+    assert np.abs(o.info[:, 2]).max() < 1e6   # episode returns were not poisoned
+    env.close()
+
+
+def test_update_config_refusals_leave_host_and_device_configs_equal():
+    """hrl_update_config: a NULL cfg and changes the records' meaning depends on are HRL_ERR_BAD_ARG with nothing changed; the Python classes
+    change a COPY of their config and commit it only when the library took it."""
+    import ctypes as C
+    import hrl_pybullet_envs_amd as H
+    from hrl_pybullet_envs_amd import _lib
+    env = H.AntGatherBulletEnv(num_envs=16, seed=1)
+    env.reset()
+    be = env._backend()
+    L = _lib.lib()
+    assert L.hrl_update_config(be._h, None, None) == K.HRL_ERR_BAD_ARG and b'null config' in L.hrl_last_error()
+    before = bytes(env._cfg)
+    with pytest.raises(_lib.HrlError, match='n_food'):
+        env._change_config(n_food=7, n_poison=9)   # same stride, other slots
+    with pytest.raises(_lib.HrlError):
+        env._change_config(n_bins=11)              # another observation width
+    with pytest.raises(_lib.HrlError):
+        env._change_config(sensor_range=-1.0)      # an invalid config
+    assert bytes(env._cfg) == before and bytes(be.cfg) == before
+    o = orc.OracleEnv(orc.default_config(K.HRL_ANT_GATHER, num_envs=16, seed=1, auto_reset=1, max_episode_steps=2000), np.float32)
+    o.reset()
+    a = np.zeros((16, 8), np.float32)
+    ob, r, d, info = env.step(torch.from_numpy(a).cuda()); o.step(a)
+    assert np.array_equal(ob.cpu().numpy(), o.obs)   # still the config it was built with
+    env.close()
+    fl = H.AntFlagrunBulletEnv(num_envs=8, seed=1)
+    fl.reset()
+    with pytest.raises(_lib.HrlError, match='goal mode'):
+        fl._change_config(flag_manual_goals=1)
+    fl.close()

@@ -246,7 +246,7 @@ def test_lcp_residual_five_sweeps_against_converged():
 def test_optimised_spec_equals_textbook_over_the_model_parameters():
     """The engine parameters of `hrl_model` are part of the C-ABI: 400 random contact states, each with its OWN model -- density, gravity, time
     step, both ERPs, both friction coefficients, contact distance, limit margin, rate clamp, limit impulse cap, ground height, 1..13 sweeps,
-    self collision on / off, arena size, Bullet's per-body damping, restitution and its threshold, the contact cap, joint damping and armature -- one substep of the optimised specification against the frozen textbook reference: the two derivations
+    self collision on / off, arena size, Bullet's per-body damping, restitution and its threshold, the contact cap, joint damping and armature -- one substep of the optimised specification against the textbook reference: the two derivations
     agree to rounding everywhere in the parameter space, not only at the defaults."""
     rng = np.random.RandomState(77)
     worst, rows, selfc = 0.0, [], 0
@@ -281,9 +281,9 @@ def test_optimised_spec_equals_textbook_over_the_model_parameters():
 
 
 def test_pointbot_spec_equals_textbook_over_states_and_parameters():
-    """The PointBot's cube (ground + arena walls, no item cubes: the frozen reference predates the cube-corner contacts) from 400 random states --
+    """The PointBot's cube (ground + arena walls, no item cubes: the textbook reference predates the cube-corner contacts) from 400 random states --
     any yaw, tipped up to 0.5 rad, against the walls, moving, pushed --, each with its own engine parameters: one substep of the optimised
-    specification against the frozen textbook reference <= 1e-9."""
+    specification against the textbook reference <= 1e-9."""
     rng = np.random.RandomState(91)
     worst, contacts = 0.0, []
     for i in range(400):

@@ -1,4 +1,4 @@
-"""ctypes binding of oracle/libtextbook.so (the frozen fp64 textbook reference).  Test infrastructure only."""
+"""ctypes binding of oracle/libtextbook.so (the fp64 textbook reference (revisions: tests/golden/textbook_revisions.json)).  Test infrastructure only."""
 import ctypes as C
 import os
 import subprocess
