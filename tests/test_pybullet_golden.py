@@ -5,36 +5,23 @@ tests/golden/pybullet_<env>.json are written by tools/make_pybullet_golden.py on
 rigid-body step stays "parity unpinned" (DESIGN.md 6); it never passes on fabricated data.  With the files present it
   * settles SURVEY Appendix A.4 from the recorded link masses (density 1000 kg/m^3, what this build assumes, against MuJoCo's 5),
   * checks the recorded engine parameters against the ones the build restates from memory,
-  * replays every recorded step on the fp64 oracle from the identical (qpos, qvel, items, action) and reports the deviation of qpos', qvel', obs,
-    reward and done per quantity (written to profiles/pybullet_deviation.json), failing where it exceeds the tolerance SURVEY 8d states."""
-import ctypes as C
+  * replays every recorded step on the fp64 oracle from the identical (qpos, qvel, items, action, task bookkeeping) and reports the deviation of
+    qpos', qvel', obs, reward and done per quantity (written to profiles/pybullet_deviation.json), failing where it exceeds the tolerance SURVEY 8d
+    states (tests/pybullet_replay.py).
+The whole road -- generator, this replay, the fit -- runs end to end in tests/test_pin_road_dry_run.py against stand-in packages backed by the oracle."""
 import glob
 import json
-import math
 import os
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
-import orc
-from hrl_pybullet_envs_amd import _capi as K
+import pybullet_replay
+from pybullet_replay import TOL, ant_masses
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', 'pybullet_*.json')))
-KIND = {'AntGatherBulletEnv': K.HRL_ANT_GATHER, 'AntMazeBulletEnv': K.HRL_ANT_MAZE, 'PointGatherBulletEnv': K.HRL_POINT_GATHER,
-        'AntFlagrunBulletEnv': K.HRL_ANT_FLAGRUN}
-# SURVEY 8d "Parity tolerance to state": one env step from identical inputs, oracle-fp64 against the reference
-TOL = {'qpos': 1e-4, 'qvel': 1e-2, 'obs': 1e-4, 'rew': 1e-4}
-
-
-def ant_masses(rho):
-    """Solid torso sphere r 0.25 + four jointless capsules (r 0.08, length 0.2 sqrt 2) = the torso body; aux capsule (same size); foot capsule
-    (length 0.4 sqrt 2): assets/ant.xml:12-58."""
-    rt, rc, l1, l2 = 0.25, 0.08, 0.2 * math.sqrt(2), 0.4 * math.sqrt(2)
-    cap = lambda L: rho * (math.pi * rc * rc * L + 4.0 / 3.0 * math.pi * rc ** 3)
-    return rho * 4.0 / 3.0 * math.pi * rt ** 3 + 4 * cap(l1), cap(l1), cap(l2)
 
 
 def test_the_generator_refuses_to_run_without_pybullet_and_writes_nothing():
@@ -59,60 +46,14 @@ def test_mass_model_hypotheses_are_far_apart():
 @pytest.mark.skipif(not FILES, reason='no tests/golden/pybullet_*.json: run tools/make_pybullet_golden.py where pybullet + gym + the reference are installed '
                                       '(the rigid-body step stays parity-unpinned until then)')
 def test_oracle_against_recorded_pybullet_steps():
-    report = {}
-    worst = {}
-    for path in FILES:
-        g = json.load(open(path))
-        name = g['env_id'].split('-')[0]
-        kind = KIND[name]
-        model = g['model']
-        rep = report.setdefault(name, {})
-        # ---- which density did Bullet's MJCF importer use?
-        if kind != K.HRL_POINT_GATHER:
-            total = model['total_mass']
-            t1000 = sum(ant_masses(1000.0)[i] * (1, 4, 4)[i] for i in range(3)); t5 = sum(ant_masses(5.0)[i] * (1, 4, 4)[i] for i in range(3))
-            rep['total_mass'] = total
-            rep['density_hypothesis'] = 1000 if abs(total - t1000) < abs(total - t5) else 5
-            rep['mass_rel_err_vs_build'] = abs(total - t1000) / t1000
-        eng = model['engine']
-        rep['engine'] = {k: eng.get(k) for k in ('fixedTimeStep', 'numSubSteps', 'numSolverIterations', 'erp', 'contactERP', 'frictionERP', 'gravityAccelerationZ')}
-        # ---- replay
-        dev = {k: [] for k in ('qpos', 'qvel', 'obs', 'rew')}
-        done_flips = steps = 0
-        for ep in g['episodes']:
-            for t, r in enumerate(ep['steps']):
-                kw = {}
-                if kind == K.HRL_ANT_MAZE and 'target' in r:
-                    kw = dict(targets=[tuple(r['target'][:2])])
-                cfg = orc.default_config(kind, num_envs=1, seed=0, auto_reset=0, **kw)
-                o = orc.OracleEnv(cfg, np.float64)
-                o.reset()
-                nq = len(r['qpos'])
-                o.state[0, :nq] = r['qpos']
-                o.state[0, 15:15 + len(r['qvel'])] = r['qvel']
-                if r.get('items') is not None:
-                    o.items[0, :2 * len(r['items'])] = np.asarray(r['items'], np.float64).ravel()
-                if kind == K.HRL_ANT_FLAGRUN and 'walk_target' in r:
-                    o.items[0, 0:2] = r['walk_target']
-                o.aux[0, 0] = t
-                o.step(np.asarray(r['action'], np.float64)[None])
-                dev['qpos'].append(np.abs(o.state[0, :nq] - np.asarray(r['qpos_after'])).max())
-                dev['qvel'].append(np.abs(o.state[0, 15:15 + len(r['qvel'])] - np.asarray(r['qvel_after'])).max())
-                ob = np.asarray(r['obs'], np.float64)
-                if ob.shape == o.obs[0].shape:
-                    dev['obs'].append(np.nanmax(np.abs(o.obs[0] - ob)))
-                dev['rew'].append(abs(float(o.rew[0]) - r['rew']))
-                done_flips += int(bool(o.done[0]) != r['done']); steps += 1
-        rep['steps'] = steps; rep['done_flips'] = done_flips
-        for k, v in dev.items():
-            v = np.asarray(v)
-            rep[k] = {'max': float(v.max()), 'median': float(np.median(v)), 'p99': float(np.percentile(v, 99))} if len(v) else None
-            if len(v):
-                worst[(name, k)] = float(np.median(v))
+    for path in FILES:   # records of the dry run's stand-in packages (tests/pybullet_standin.py: the oracle itself) are not fixtures
+        assert not (json.load(open(path)).get('versions') or {}).get('standin'), f'{path} was recorded from the stand-in packages of the dry run, not from pybullet: remove it'
+    report, worst = pybullet_replay.replay(FILES)
     os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
     with open(os.path.join(ROOT, 'profiles', 'pybullet_deviation.json'), 'w') as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report, indent=1))
     over = {k: v for k, v in worst.items() if v > TOL[k[1]]}
-    assert not over, f'median one-step deviation from pybullet beyond the stated tolerance {TOL}: {over} (full report: profiles/pybullet_deviation.json)'
+    assert not over, (f'median one-step deviation from pybullet beyond the stated tolerance {TOL}: {over} (full report: profiles/pybullet_deviation.json; '
+                      'the engine parameters nothing in the reference tree decides are hrl_model fields: tests/tools/fit_model.py <fixture> fits them)')
     assert all(r.get('density_hypothesis', 1000) == 1000 for r in report.values()), 'Bullet used another density than this build assumes (SURVEY A.4)'

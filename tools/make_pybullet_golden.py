@@ -15,13 +15,16 @@ works, from a checkout of this repository:
 and commit the files it writes, tests/golden/pybullet_<env>.json.  They are DATA ONLY -- inputs and outputs of the reference's own step() -- :
 per env id, per seed, per step
     qpos[15] (x y z, quaternion x y z w, 8 joint angles in hip_1, ankle_1, ... hip_4, ankle_4 order), qvel[14] (v world, omega world, 8 joint rates),
-    items[n][2] (food then poison, gather kinds), target (maze), the action, and after `env.step(action)`: qpos', qvel', items', obs, rew, done,
-    info, the contact points pybullet reports (link pair, position, normal, distance, normal force);
+    items[n][2] (food then poison, gather kinds), target (maze), `task` (what the step reads besides those: potential, initial_z, the feet-contact
+    flags of the step before, the flagrun goal bookkeeping -- task_state()), the action, and after `env.step(action)`: qpos', qvel', items', obs,
+    rew, done, info, the contact points pybullet reports (link pair, position, normal, distance, normal force);
 plus once per env: getDynamicsInfo of every link (mass, friction, local inertia diagonal, restitution, damping), the joint table (name, type,
 limits, axis, parent frame), getPhysicsEngineParameters(), the collision shapes, and the versions of the packages.
 tests/test_pybullet_golden.py picks the files up when they exist: it replays every recorded step on the CPU oracle from the identical
 (qpos, qvel, items, action), reports the deviation per quantity, and settles SURVEY Appendix A.4 (density 1000 vs 5) from the recorded masses.
-Nothing here is ever fabricated: without pybullet the script exits with the list of missing modules and writes nothing."""
+Nothing here is ever fabricated: without pybullet the script exits with the list of missing modules and writes nothing.
+The whole road -- this script, the replay, the fit -- is rehearsed end to end by tests/test_pin_road_dry_run.py against stand-in packages backed by the
+CPU oracle under a perturbed model (tests/pybullet_standin.py; scratch directories only, its records carry `versions.standin` and are refused as fixtures)."""
 import argparse
 import json
 import os
@@ -49,7 +52,7 @@ def tolist(x):
         return [tolist(v) for v in x]
     if isinstance(x, np.ndarray):
         return x.astype(float).tolist()
-    if isinstance(x, (np.floating, np.integer)):
+    if isinstance(x, (np.floating, np.integer, np.bool_)):
         return x.item()
     if isinstance(x, bytes):
         return x.decode(errors='replace')
@@ -122,6 +125,26 @@ class Probe:
                 'engine': tolist(p.getPhysicsEngineParameters())}
 
 
+def task_state(u):
+    """What a step() of the reference reads BESIDES (qpos, qvel, items, action) -- the env's and the robot's own bookkeeping --, taken before the
+    step so that a replay can start from the identical state: upstream WalkerBaseBulletEnv's `potential` (the progress term is measured from it),
+    `robot.initial_z` (obs[0] = z - initial_z) and `robot.feet_contact` (calc_state() shows the flags the step BEFORE left); AntMazeBulletEnv.t
+    (ant_maze_bullet_env.py:78); AntFlagrunBulletEnv's goal bookkeeping (ant_flagrun_env.py:41-52,98-120: steps_since_goal_change, _rewarded,
+    _sq_dist_goal, _goal_start_pos, how many goals are pending and the one next_target() would pop)."""
+    out = {}
+    for k in ('potential', 't', 'steps_since_goal_change', '_rewarded', '_sq_dist_goal', '_goal_start_pos'):
+        if hasattr(u, k):
+            out[k] = tolist(getattr(u, k))
+    if hasattr(u, 'goals'):
+        goals = list(u.goals)
+        out['n_goals_pending'] = len(goals)
+        out['next_goal'] = tolist(list(goals[-1])) if goals else None   # next_target(): self.goals.pop() takes the LAST one (:116)
+    for k in ('initial_z', 'feet_contact'):
+        if hasattr(u.robot, k):
+            out[k] = tolist(getattr(u.robot, k))
+    return out
+
+
 def record(env_id, seeds, steps):
     import gym
     import numpy as np
@@ -140,6 +163,7 @@ def record(env_id, seeds, steps):
             qpos, qvel = pr.qpos_qvel()
             rec = {'qpos': qpos, 'qvel': qvel, 'items': pr.items(), 'action': None}
             u = env.unwrapped
+            rec['task'] = task_state(u)
             if hasattr(u, 'target'):
                 rec['target'] = tolist(np.asarray(u.target))
             if hasattr(u, 'walk_target_x'):
@@ -175,6 +199,14 @@ def main():
     import pybullet
     import hrl_pybullet_envs  # noqa: F401  (registers the ids, hrl_pybullet_envs/__init__.py:11-16)
     versions = {'pybullet_api': pybullet.getAPIVersion(), 'gym': gym.__version__, 'python': sys.version.split()[0]}
+    if getattr(hrl_pybullet_envs, 'standin', False):
+        # the dry run of this road (tests/test_pin_road_dry_run.py): the packages are tests/pybullet_standin.py's, backed by the CPU oracle.  Its
+        # records say so and are refused as fixtures; they never go under tests/golden
+        versions['standin'] = True
+        golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+        if os.path.realpath(a.out) == os.path.realpath(golden):
+            sys.exit('make_pybullet_golden: stand-in packages are installed (a dry run): give --out a scratch directory, tests/golden is for records of the real pybullet')
+    os.makedirs(a.out, exist_ok=True)
     for env_id in a.envs:
         data = record(env_id, a.seeds, a.steps)
         data['versions'] = versions
