@@ -102,9 +102,45 @@ class Watchdog:
         self._done.set()
 
 
+def count_gpus(kfd_root=None):
+    """GPUs of this machine WITHOUT touching the GPU: the KFD topology nodes whose `simd_count` is not 0 (CPU nodes have 0), narrowed by
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when set.  None when the topology cannot be read (no amdgpu driver here: nothing to decide from)."""
+    root = kfd_root or os.environ.get('HRL_KFD_ROOT') or '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        nodes = sorted(os.listdir(root))
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        n += int(props.get('simd_count', '0')) > 0
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
+def preflight(ranks, backend):
+    """Before anything touches the GPU or a rendezvous starts: a job of `ranks` RCCL ranks on a machine with fewer GPUs would sit in
+    init_process_group / its first collective until the watchdog ends it 900 s later.  One line and exit code 2 instead.  (gloo rehearsals share
+    the card on purpose; an unreadable topology decides nothing.)"""
+    have = count_gpus()
+    if backend == 'gloo' or have is None or have >= ranks:
+        return
+    print(f'bench.py: --gpus {ranks} asks for {ranks} ranks (one GPU each), this machine shows {have} GPU(s) '
+          f'(KFD topology, ROCR_/HIP_VISIBLE_DEVICES): not started', file=sys.stderr, flush=True)
+    sys.exit(2)
+
+
 def spawn_ranks(args):
     """Parent of an N-rank run: nothing in this process has touched the GPU (no HIP call, no torch.cuda.*), so the
     ranks are plain child processes; the parent never re-executes itself."""
+    preflight(args.gpus, args.backend)
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL across processes needs it on this driver
@@ -238,6 +274,8 @@ def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
+    if 'WORLD_SIZE' in os.environ:   # a rank of the driver's own torch.distributed.run: the same check, before the rendezvous (every rank leaves with 2 at once)
+        preflight(int(os.environ['WORLD_SIZE']), args.backend)
 
     import torch
 

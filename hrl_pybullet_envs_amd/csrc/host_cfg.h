@@ -149,6 +149,17 @@ inline std::string validate(const hrl_config *c) {
 }
 
 /* kernel constants; the mass model is computed in double and rounded once to fp32 */
+/* Solver rows per substep of an ant that STANDS under config c -- what the straggler rule of ant_env_block compares an env's rows with (scheduling only,
+ * no effect on results).  Its four feet rest on the floor: one contact each, three rows per contact, as far as the contact cap lets them in; every
+ * hinge sits at a stop (the ankles are outside their range at the reset pose already, assets/ant.xml:21-54; under load the hips follow): one limit
+ * row per joint, two where the margin spans the joint's whole range (then both limits are within reach at once).  Defaults: 4 x 3 + 8 = 20. */
+inline int standing_rows(const hrl_config &c, const DevCfg &d) {
+    const int feet = c.model.max_contacts < 4 ? (c.model.max_contacts < 0 ? 0 : c.model.max_contacts) : 4;
+    int rows = 3 * feet;
+    for (int j = 0; j < NJ; ++j) rows += (c.model.limit_margin >= d.jhi[j] - d.jlo[j]) ? 2 : 1;
+    return rows;
+}
+
 inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     memset(&d, 0, sizeof(d));
     d.kind = c.env_kind; d.n_envs = c.num_envs; d.max_episode_steps = c.max_episode_steps; d.auto_reset = c.auto_reset;
@@ -221,6 +232,7 @@ inline void build_devcfg(const hrl_config &c, DevCfg &d) {
     d.obs_dim = obs_dim(&c); d.act_dim = act_dim(&c);
     d.items_stride = items_stride(&c);
     d.item_shift = c.n_food + c.n_poison > 16 ? 6 : 4;
+    d.hot_rows = standing_rows(c, d);
 }
 
 }  // namespace hrl

@@ -53,7 +53,6 @@ namespace hrl {
 constexpr int NJ = 8;     /* hinge joints: hip_1, ankle_1, ..., hip_4, ankle_4 (assets/ant.xml:18-54) */
 constexpr int MAXC = 12;  /* contacts kept per substep */
 constexpr int MAXR = 44;  /* constraint rows per substep: 8 limits + 12 * (normal + 2 friction) */
-constexpr int HOT_ROWS = 20; /* rows per substep of a standing ant: an env with more is the launch's straggler (ant_env_block) */
 constexpr int MAXB = NJ + MAXC; /* bounded rows that come first in the sweep order: joint limits, then contact normals */
 constexpr int MAXF = 2 * MAXC;  /* friction rows, a pair per contact, after all the normals */
 static_assert(MAXB + MAXF == MAXR && MAXB % 4 == 0 && MAXF % 4 == 0, "row blocks are built in groups of four");
@@ -95,6 +94,8 @@ struct DevCfg {
     float restitution, rest_thr;  /* > 0: normal rows of fast approaches ask for a separating velocity */
     int items_stride; /* floats per env of the items buffer (hrl_items_stride): 32 for the default configs */
     int item_shift;   /* respawn key of a contact pickup: item | move << item_shift; 4 for up to 16 items (the streams of ABI <= 5), else 6 */
+    int hot_rows;     /* solver rows per substep of an ant that STANDS under this config (host_cfg.h::standing_rows: its feet's contacts x 3 + its joints at their
+                         stops); an env that holds more is the launch's straggler and takes the top issue priority for its block (ant_env_block).  Scheduling only. */
 };
 
 struct DevBufs {
@@ -493,8 +494,24 @@ HRL_DEV void phase_kin_ankle(const DevCfg &c, WaveLds &L, LaneRegs &g, const flo
 #pragma unroll
     for (int k = 0; k < 6; ++k) L.cb[ja][k] = cba[k];
     float Ua[6], Iac[6];
+#ifdef HRL_VAR_LEAF_CLOSED_FORM /* A/B build only (profiles/EXPERIMENTS.md 9.a): the ankle's U = I S and D = S . U of the LEAF body in closed form -- the foot is rigid and its
+                                   joint axis is fixed in it and perpendicular to its own axis, so U = [alpha w + c x (m d (w x e)); m d (w x e)] and D = alpha + m d^2 is a
+                                   constant: what "joint axes with a zero linear part" buys for this joint without any shift of inertias.  Not the specification (other roundings). */
+    {
+        float tt[3], lin[3], cl[3];
+        const float dd = c.L2 * 0.5f, md = m2 * dd;
+        cross3(tt, axw, e2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lin[k] = md * tt[k];
+        cross3(cl, cfoot, lin);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Ua[k] = fma_(a2_, axw[k], cl[k]); Ua[3 + k] = lin[k]; }
+    }
+    const float invDa = 1.f / (fma_(m2 * (c.L2 * 0.5f), c.L2 * 0.5f, a2_) + c.armature);
+#else
     sym6_matvec(Ua, If, Sa);
     const float invDa = 1.f / (dot6(Sa, Ua) + c.armature);             /* + 0 at the default: the same bits */
+#endif
     const float uta = fma_(-c.jdamp, qda, L.tau[ja]) - dot6(Sa, pAf);   /* - 0 * rate at the default: the same bits */
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -1531,11 +1548,11 @@ HRL_DEV int ant_env_block(X &x, const DevCfg &c, int qi) { /* returns the subste
     x.refresh();
     const int nC = x.uniform(L.nC), nL = x.uniform(L.nL), nS = x.uniform(L.nS);
 #ifndef HRL_NO_HOT_ROWS /* (A/B builds of tools/variants.py define it) */
-    /* Longest job first: a launch lasts as long as its slowest env, and an env's chain grows with its rows.  An env with more rows than a standing
-     * ant's (four feet x 3 + eight joints near their stops = 20) takes the top issue priority for the rest of its block; the rotation at the head of
-     * the next substep takes it back.  Scheduling only.  One such env among 4096 cost a launch 3 - 4 us; this gives 1.4 of them back
-     * (profiles/EXPERIMENTS.md 8). */
-    if (nL + 3 * nC > HOT_ROWS) x.priority(3);
+    /* Longest job first: a launch lasts as long as its slowest env, and an env's chain grows with its rows.  An env with more rows than an ant
+     * that stands under THIS config (DevCfg::hot_rows, derived from the model on the host: four feet x 3 + eight joints at their stops = 20 at the
+     * defaults) takes the top issue priority for the rest of its block; the rotation at the head of the next substep takes it back.  Scheduling
+     * only.  One such env among 4096 cost a launch 3 - 4 us; this gives 1.4 of them back (profiles/EXPERIMENTS.md 8). */
+    if (nL + 3 * nC > c.hot_rows) x.priority(3);
 #endif
     x.each([&](int lane) {
         x.reg(lane).ud = L.ustar[lane & 15]; /* the velocity if no row turns up */

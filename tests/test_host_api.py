@@ -540,3 +540,49 @@ def test_make_leaves_what_gym_make_leaves_on_the_object():
     assert env.max_episode_steps == 500
     one = H.AntGatherBulletEnv()            # constructed directly: no wrapper, no limit, no spec -- like the reference's bare class
     assert one._max_episode_steps is None and one.spec is None
+
+
+def _fake_kfd(root, simds):
+    for i, s in enumerate(simds):
+        d = root / str(i)
+        d.mkdir()
+        (d / 'properties').write_text(f'cpu_cores_count {0 if s else 64}\nsimd_count {s}\nmem_banks_count 1\ngfx_target_version {90500 if s else 0}\n')
+
+
+def test_bench_preflight_counts_gpus_before_anything_touches_one(tmp_path, monkeypatch):
+    """`bench.py --gpus N` on a machine with fewer GPUs: one line and exit code 2 from the PARENT (and from each rank of the driver's own
+    torch.distributed.run, before the rendezvous), instead of N ranks waiting in init_process_group until the watchdog ends them 900 s later.
+    GPUs = KFD topology nodes with simd_count != 0 (a fake sysfs root here), narrowed by ROCR_ / HIP_VISIBLE_DEVICES; gloo rehearsals are let through."""
+    import importlib
+    import subprocess
+    import bench
+    importlib.reload(bench)
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'WORLD_SIZE'):
+        monkeypatch.delenv(var, raising=False)
+    root = tmp_path / 'nodes'
+    root.mkdir()
+    _fake_kfd(root, [0, 0, 1024, 1024])   # two CPU nodes, two GPUs
+    assert bench.count_gpus(str(root)) == 2
+    assert bench.count_gpus(str(tmp_path / 'absent')) is None
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '1')
+    assert bench.count_gpus(str(root)) == 1
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    monkeypatch.setenv('HRL_KFD_ROOT', str(root))
+    called = []
+    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: called.append(cmd) or 0)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '3'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2 and not called            # not started
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '3'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(called) == 1      # enough GPUs: the ranks are spawned
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--backend', 'gloo'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(called) == 2      # a gloo rehearsal shares the card on purpose
+    # a rank of the driver's own launch: same check before the rendezvous, in a real process, within seconds, nothing imported from torch
+    env = dict(os.environ, WORLD_SIZE='8', RANK='3', LOCAL_RANK='3', MASTER_ADDR='127.0.0.1', MASTER_PORT='1', HRL_KFD_ROOT=str(root))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3'], capture_output=True, text=True, env=env, timeout=60)
+    assert p.returncode == 2 and 'shows 2 GPU(s)' in p.stderr and p.stdout == ''

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B compiler-flag variants of the HIP library in ONE process, interleaved rounds (cdna_hip_programming.md rule 24).
-Variants are built beforehand into build/variants/lib_<name>.so.  GPU box: python tools/variants.py [envs] [kind] [settle steps] [seed]"""
+Variants are built beforehand into build/variants/lib_<name>.so.  GPU box: python tools/variants.py [envs] [kind] [settle steps] [seed]
+(HRL_VARIANT_MODEL=field=value,...: hrl_model overrides for every variant)"""
 import ctypes as C
 import glob
 import os
@@ -32,6 +33,9 @@ def main():
     for p in sorted(glob.glob(os.path.join(ROOT, 'build', 'variants', 'lib_*.so'))):
         libs[os.path.basename(p)[4:-3]] = bind(p)
     cfg = _lib.default_config(kind, num_envs=n, seed=seed, auto_reset=1)
+    for kv in filter(None, os.environ.get('HRL_VARIANT_MODEL', '').split(',')):   # e.g. HRL_VARIANT_MODEL=linear_damping=0,angular_damping=0 (the undamped population)
+        k, v = kv.split('=')
+        setattr(cfg.model, k, type(getattr(cfg.model, k))(float(v)))
     obs_dim, act_dim = _lib.lib().hrl_obs_dim(C.byref(cfg)), _lib.lib().hrl_act_dim(C.byref(cfg))
     envs = {}
     acts = torch.rand(64, n, act_dim, device='cuda') * 2 - 1
