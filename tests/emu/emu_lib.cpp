@@ -109,6 +109,7 @@ int emu_obs_dim(const hrl_config *c) { return obs_dim(c); }
 int emu_act_dim(const hrl_config *c) { return act_dim(c); }
 int emu_items_stride(const hrl_config *c) { return items_stride(c); }
 const char *emu_validate(const hrl_config *c) { static std::string s; s = validate(c); return s.c_str(); }
+int emu_hot_rows(const hrl_config *cfg) { DevCfg c; build_devcfg(*cfg, c); return c.hot_rows; } /* the straggler rule's threshold the host derives (host_cfg.h::standing_rows) */
 int emu_reset(const hrl_config *cfg, const hrl_buffers *b, const uint8_t *mask, int reverse) {
     if (!validate(cfg).empty()) return HRL_ERR_BAD_ARG;
     DevCfg c; build_devcfg(*cfg, c);

@@ -893,3 +893,32 @@ def test_flagrun_path_reward_switched_on_for_a_live_env():
             checked += int(keep.sum())
             assert not keep.any() or np.abs(path[keep]).max() < 50
     assert checked > 300
+
+
+def test_straggler_threshold_follows_the_model():
+    """DevCfg::hot_rows (host_cfg.h::standing_rows): the solver rows of an ant that STANDS under the config -- its feet's contacts x 3 as far as the
+    contact cap lets them in, one limit row per joint at its stop, two where the margin spans the joint's whole range -- is what ant_env_block compares an
+    env's rows with (scheduling only).  20 at the defaults, the literal of round 5."""
+    L = emu_env.lib()
+    for kind in (K.HRL_ANT_FLAT, K.HRL_ANT_GATHER, K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ, K.HRL_ANT_FLAGRUN):
+        assert L.emu_hot_rows(C.byref(orc.default_config(kind, num_envs=4))) == 20
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=4, model_max_contacts=2)
+    assert L.emu_hot_rows(C.byref(cfg)) == 6 + 8
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=4, model_limit_margin=1.3)   # spans the ankles' 70 degrees, not the hips' 80
+    assert L.emu_hot_rows(C.byref(cfg)) == 12 + 4 + 8
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=4, model_limit_margin=1.5)
+    assert L.emu_hot_rows(C.byref(cfg)) == 12 + 16
+    # ... and that is what an ant standing on its four feet holds AT MOST (all eight joints at their stops): the settled population under random
+    # torques reaches it and does not pass it -- an env above it has more than its feet on something
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=128, seed=1, auto_reset=1)
+    o = orc.OracleEnv(cfg, np.float32); o.reset()
+    rng = np.random.RandomState(0)
+    for t in range(200):
+        o.step(rng.uniform(-1, 1, (128, 8)).astype(np.float32))
+    rows = []
+    for t in range(20):
+        o.solver_rows[:] = 0
+        o.step(rng.uniform(-1, 1, (128, 8)).astype(np.float32))
+        rows.append(o.solver_rows / 4.0)
+    rows = np.concatenate(rows)
+    assert np.percentile(rows, 95) <= 20.0 and np.percentile(rows, 90) >= 19.0 and (rows > 20).mean() < 0.02, np.percentile(rows, [50, 90, 95, 99])
