@@ -371,6 +371,30 @@ double tb_seg_box_param(const double *p0, const double *p1, const double *lo, co
     return 0.5 * (first + last);
 }
 
+/* Second support point of a capsule that rests (nearly) FLAT on a face of a box -- Bullet keeps a manifold of up to four points per pair there, a single
+ * point lets the capsule rock about it.  The first contact is the axis point P(t1) closest to the box, with normal n1.  When n1 is a face normal (the
+ * closest point of the box lies in a face's interior, or P(t1) is inside the box), the part of the axis that projects into that face is
+ * [ta, tb] = [0, 1] clipped by the two slabs of the other axes; its end FARTHER from t1 (tb on a tie: towards the capsule's free end -- its start is
+ * where the neighbouring capsule of the leg ends) is the candidate: it becomes a contact of its own if
+ * it is at least one capsule radius away from P(t1) along the axis and itself closer to the box than the contact distance (judged by the caller).
+ * Returns 1 and t2, or 0. */
+static int tb_second_point(const double *p0, const double *p1, double t1, const double *n1, double rad, const double *lo, const double *hi, double *t2) {
+    int kf = -1, nz = 0;
+    for (int k = 0; k < 3; ++k) if (n1[k] != 0) { kf = k; ++nz; }
+    if (nz != 1) return 0;
+    double ta = 0, tb = 1, len2 = 0;
+    for (int k = 0; k < 3; ++k) {
+        double d = p1[k] - p0[k];
+        len2 += d * d;
+        if (k == kf || d == 0) continue;
+        double u = (lo[k] - p0[k]) / d, v = (hi[k] - p0[k]) / d, tl = u < v ? u : v, th = u < v ? v : u;
+        if (tl > ta) ta = tl;
+        if (th < tb) tb = th;
+    }
+    *t2 = (tb - t1 >= t1 - ta) ? tb : ta;
+    return (*t2 - t1) * (*t2 - t1) * len2 >= rad * rad;
+}
+
 /* closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9), both of positive length */
 static void tb_seg_seg(const double *p1, const double *q1, const double *p2, const double *q2, double *c1, double *c2) {
     double d1[3], d2[3], r[3];
@@ -469,8 +493,10 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
             srad[s] = R_CAPS; sbody[s] = w == 0 ? 0 : (w == 1 ? 1 + 2 * l : 2 + 2 * l);
         }
     const int nsurf = 1 + P->n_planes + P->n_boxes;
-    for (int f = 0; f < nsurf; ++f)
+    for (int f = 0; f < nsurf; ++f) {
+        double t_first[13], n_first[13][3]; int ok_first[13]; /* box surfaces: the first contact of every shape, for the second support points below */
         for (int s = 0; s < 13; ++s) {
+            ok_first[s] = 0;
             double ctr[3] = {sc[s][0], sc[s][1], sc[s][2]}; /* centre of the sphere that touches, relative to O */
             double p[3] = {q[0] + ctr[0], q[1] + ctr[1], q[2] + ctr[2]}, n[3], dist;
             if (f == 0) { v3_set(n, 0, 0, 1); dist = p[2] - P->ground_z - srad[s]; }
@@ -481,6 +507,8 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
                 double t = tb_seg_box_param(w0, p, blo, bhi);
                 for (int k = 0; k < 3; ++k) { ctr[k] = s0[s][k] + t * (sc[s][k] - s0[s][k]); p[k] = q[k] + ctr[k]; }
                 dist = tb_sphere_box(p, srad[s], blo, bhi, n);
+                t_first[s] = t; ok_first[s] = dist < P->cdist;
+                for (int k = 0; k < 3; ++k) n_first[s][k] = n[k];
             }
             if (!(dist < P->cdist)) continue;
             ++ncand;
@@ -490,6 +518,22 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
             c->surface = f <= P->n_planes ? f : 100 + (f - 1 - P->n_planes);
             for (int k = 0; k < 3; ++k) { c->n[k] = n[k]; c->p[k] = ctr[k] - srad[s] * n[k]; }
         }
+        if (f > P->n_planes) /* a box: after its 13 first contacts, the second support points of the capsules that lie flat on one of its faces, shape-minor */
+            for (int s = 1; s < 13; ++s) {
+                if (!ok_first[s]) continue;
+                const double *blo = P->box_lo[f - 1 - P->n_planes], *bhi = P->box_hi[f - 1 - P->n_planes];
+                double w0[3] = {q[0] + s0[s][0], q[1] + s0[s][1], q[2] + s0[s][2]}, w1[3] = {q[0] + sc[s][0], q[1] + sc[s][1], q[2] + sc[s][2]}, t2, ctr[3], p[3], n[3];
+                if (!tb_second_point(w0, w1, t_first[s], n_first[s], srad[s], blo, bhi, &t2)) continue;
+                for (int k = 0; k < 3; ++k) { ctr[k] = s0[s][k] + t2 * (sc[s][k] - s0[s][k]); p[k] = q[k] + ctr[k]; }
+                double dist = tb_sphere_box(p, srad[s], blo, bhi, n);
+                if (!(dist < P->cdist)) continue;
+                ++ncand;
+                if (nc >= cap) continue;
+                tb_contact *c = &C[nc++];
+                c->bodyA = sbody[s]; c->bodyB = -1; c->dist = dist; c->mu = P->mu; c->surface = 100 + (f - 1 - P->n_planes);
+                for (int k = 0; k < 3; ++k) { c->n[k] = n[k]; c->p[k] = ctr[k] - srad[s] * n[k]; }
+            }
+    }
     if (P->self_collision) { /* capsules of different legs (links that are not ancestors of each other) */
         int pair = 0;
         for (int i = 0; i < 4; ++i)

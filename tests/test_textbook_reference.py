@@ -553,3 +553,47 @@ def test_foot_across_the_corner_of_the_maze_box_is_pushed_out():
         qq, uu, info, dbg, lam = orc_substeps_items(cfg, qq, uu, np.zeros(8), np.zeros((0, 2)), 1)
     pts = leg_points(cfg.model, qq)
     assert seg_box_dist(pts[0, 1], pts[0, 2], lo, hi) > 0.075  # out, to within the solver's slop
+
+
+def _ant_beside_the_box_face(pen, ankle_deg=90.0):
+    """an ant east of the maze box (face x = 1, assets/box.xml:12, maze_scene.py:12-13), 1.2 m up, the feet of legs 1 and 2 (the two that point towards
+    -x) hanging straight down: their axes run PARALLEL to the face, `pen` inside its contact shell"""
+    q = np.zeros(15); q[6] = 1.0
+    q[7:] = np.radians([0, 45, 0, -ankle_deg, 0, -ankle_deg, 0, 45])
+    q[2] = 1.2
+    q[0] = 1 + 0.08 - pen + 0.4   # the ankle points (and with them the vertical foot axes) are 0.4 to the west of the torso centre
+    return q
+
+
+def test_capsule_flat_on_a_box_face_gets_a_second_support_point():
+    """Bullet keeps a manifold of up to four points where a capsule lies on a box face; one point lets it rock.  The model's rule (textbook form,
+    tb_second_point): the first contact is the axis point closest to the box; when its normal is a face normal, the end of the part of the axis over that
+    face that is FARTHER from it (towards the capsule's free end on a tie) is a second contact -- if it is a capsule radius or more away along the axis
+    and itself within the contact distance.  Candidate order: a box's 13 first contacts, then its second points, shape-minor."""
+    cfg = orc.default_config(K.HRL_ANT_MAZE)
+    cfg.model.self_collision = 0
+    p = tb.params(cfg); p.gravity = 0.0
+    q0 = _ant_beside_the_box_face(0.005)
+    q, u, out = tb.ant_substep(p, q0, np.zeros(14), np.zeros(8))
+    # per leg: the aux capsule's end (the ankle point), the foot's first contact (exactly parallel: the middle of the stretch) -- and the foot's second, its tip end
+    assert out.n_contacts == 6 and out.n_candidates == 6 and [out.contact_surface[c] for c in range(6)] == [100] * 6
+    assert np.allclose([out.contact_dist[c] for c in range(6)], -0.005, atol=1e-12)
+    lam = [out.lambda_[out.n_limits + c] for c in range(6)]
+    assert lam[4] > 0.5 and lam[5] > 0.5, lam   # the second points carry load: the foot is pushed out as a whole, not about its middle
+    # a foot a little off parallel: first contact at its nearer end, second at the other while that one is within the contact distance
+    for ankle, want in ((89.5, 6), (91.0, 6), (87.0, 6), (94.0, 4), (96.0, 4)):   # tip nearer (< 90: the ankle end stays at -5 mm) or farther by 0.566 sin(tilt) / sqrt 2: 7 mm at 1 deg, 28 mm > 20 + 5 at 4
+        _, _, o2 = tb.ant_substep(p, _ant_beside_the_box_face(0.005, ankle), np.zeros(14), np.zeros(8))
+        assert o2.n_contacts == want, (ankle, o2.n_contacts)
+        if want == 6:
+            d = [o2.contact_dist[c] for c in range(6)]
+            # (order: aux 1's end, foot 1, aux 2's end, foot 2 -- then the second points of foot 1 and foot 2)
+            assert d[4] > d[1] and d[5] > d[3] and abs((d[4] - d[1]) - 0.5657 / np.sqrt(2) * abs(np.sin(np.radians(90 - ankle)))) < 2e-5   # the far end is the higher one, by the tilt
+    # what it is for: pushed out of the 5 mm overlap, the feet stay parallel to the face (one contact per foot pivots them about their middle: 0.38 deg)
+    tilt = 0.0
+    qq, uu = q0.copy(), np.zeros(14)
+    for s in range(30):
+        qq, uu, o = tb.ant_substep(p, qq, uu, np.zeros(8))
+        pts = leg_points(cfg.model, qq)
+        tilt = max(tilt, max(abs(np.degrees(np.arcsin((pts[l, 2, 0] - pts[l, 1, 0]) / 0.5657))) for l in (1, 2)))
+    assert tilt < 0.1, tilt
+    # (an EDGE contact -- a normal that is not a face normal -- gets none: test_foot_across_the_corner_of_the_maze_box_is_pushed_out counts one contact)
