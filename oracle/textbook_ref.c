@@ -376,8 +376,9 @@ double tb_seg_box_param(const double *p0, const double *p1, const double *lo, co
  * closest point of the box lies in a face's interior, or P(t1) is inside the box), the part of the axis that projects into that face is
  * [ta, tb] = [0, 1] clipped by the two slabs of the other axes; its end FARTHER from t1 (tb on a tie: towards the capsule's free end -- its start is
  * where the neighbouring capsule of the leg ends) is the candidate: it becomes a contact of its own if
- * it is at least one capsule radius away from P(t1) along the axis and itself closer to the box than the contact distance (judged by the caller).
- * Returns 1 and t2, or 0. */
+ * it is at least one capsule radius away from P(t1) along the axis and itself closer to the FACE than the contact distance (judged by the caller: the
+ * second contact keeps the first one's normal and measures its distance to that face's plane -- P(t2) sits on the border of the face's region by
+ * construction, where the closest feature of the box is a matter of rounding).  Returns 1 and t2, or 0. */
 static int tb_second_point(const double *p0, const double *p1, double t1, const double *n1, double rad, const double *lo, const double *hi, double *t2) {
     int kf = -1, nz = 0;
     for (int k = 0; k < 3; ++k) if (n1[k] != 0) { kf = k; ++nz; }
@@ -524,8 +525,10 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
                 const double *blo = P->box_lo[f - 1 - P->n_planes], *bhi = P->box_hi[f - 1 - P->n_planes];
                 double w0[3] = {q[0] + s0[s][0], q[1] + s0[s][1], q[2] + s0[s][2]}, w1[3] = {q[0] + sc[s][0], q[1] + sc[s][1], q[2] + sc[s][2]}, t2, ctr[3], p[3], n[3];
                 if (!tb_second_point(w0, w1, t_first[s], n_first[s], srad[s], blo, bhi, &t2)) continue;
-                for (int k = 0; k < 3; ++k) { ctr[k] = s0[s][k] + t2 * (sc[s][k] - s0[s][k]); p[k] = q[k] + ctr[k]; }
-                double dist = tb_sphere_box(p, srad[s], blo, bhi, n);
+                for (int k = 0; k < 3; ++k) { ctr[k] = s0[s][k] + t2 * (sc[s][k] - s0[s][k]); p[k] = q[k] + ctr[k]; n[k] = 0; }
+                int kf = n_first[s][0] != 0 ? 0 : (n_first[s][1] != 0 ? 1 : 2);
+                n[kf] = n_first[s][kf] > 0 ? 1.0 : -1.0; /* the face of the first contact */
+                double dist = n[kf] * (p[kf] - (n[kf] > 0 ? bhi[kf] : blo[kf])) - srad[s];
                 if (!(dist < P->cdist)) continue;
                 ++ncand;
                 if (nc >= cap) continue;
