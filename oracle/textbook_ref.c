@@ -374,8 +374,9 @@ double tb_seg_box_param(const double *p0, const double *p1, const double *lo, co
 /* Second support point of a capsule that rests (nearly) FLAT on a face of a box -- Bullet keeps a manifold of up to four points per pair there, a single
  * point lets the capsule rock about it.  The first contact is the axis point P(t1) closest to the box, with normal n1.  When n1 is a face normal (the
  * closest point of the box lies in a face's interior, or P(t1) is inside the box), the part of the axis that projects into that face is
- * [ta, tb] = [0, 1] clipped by the two slabs of the other axes; its end FARTHER from t1 (tb on a tie: towards the capsule's free end -- its start is
- * where the neighbouring capsule of the leg ends) is the candidate: it becomes a contact of its own if
+ * [ta, tb] = [0, 1] clipped by the two slabs of the other axes; its end FARTHER from t1 is the candidate -- tb, towards the capsule's free end (its
+ * start is where the neighbouring capsule of the leg ends), unless ta is farther by more than a thousandth of the axis: where a whole stretch is closest
+ * t1 is its exact middle, and a tie must not be decided by rounding --: it becomes a contact of its own if
  * it is at least one capsule radius away from P(t1) along the axis and itself closer to the FACE than the contact distance (judged by the caller: the
  * second contact keeps the first one's normal and measures its distance to that face's plane -- P(t2) sits on the border of the face's region by
  * construction, where the closest feature of the box is a matter of rounding).  Returns 1 and t2, or 0. */
@@ -392,7 +393,7 @@ static int tb_second_point(const double *p0, const double *p1, double t1, const 
         if (tl > ta) ta = tl;
         if (th < tb) tb = th;
     }
-    *t2 = (tb - t1 >= t1 - ta) ? tb : ta;
+    *t2 = ((tb - t1) + 1e-3 >= t1 - ta) ? tb : ta;
     return (*t2 - t1) * (*t2 - t1) * len2 >= rad * rad;
 }
 
