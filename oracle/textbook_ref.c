@@ -495,10 +495,12 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
             srad[s] = R_CAPS; sbody[s] = w == 0 ? 0 : (w == 1 ? 1 + 2 * l : 2 + 2 * l);
         }
     const int nsurf = 1 + P->n_planes + P->n_boxes;
+    static _Thread_local double t_first_all[TB_MAXBOX][13], n_first_all[TB_MAXBOX][13][3]; /* box surfaces: the first contact of every shape, for the second support points below */
+    static _Thread_local int ok_first_all[TB_MAXBOX][13];
     for (int f = 0; f < nsurf; ++f) {
-        double t_first[13], n_first[13][3]; int ok_first[13]; /* box surfaces: the first contact of every shape, for the second support points below */
+        double (*n_first)[3] = f > P->n_planes ? n_first_all[f - 1 - P->n_planes] : 0, *t_first = f > P->n_planes ? t_first_all[f - 1 - P->n_planes] : 0;
+        int *ok_first = f > P->n_planes ? ok_first_all[f - 1 - P->n_planes] : 0;
         for (int s = 0; s < 13; ++s) {
-            ok_first[s] = 0;
             double ctr[3] = {sc[s][0], sc[s][1], sc[s][2]}; /* centre of the sphere that touches, relative to O */
             double p[3] = {q[0] + ctr[0], q[1] + ctr[1], q[2] + ctr[2]}, n[3], dist;
             if (f == 0) { v3_set(n, 0, 0, 1); dist = p[2] - P->ground_z - srad[s]; }
@@ -520,7 +522,12 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
             c->surface = f <= P->n_planes ? f : 100 + (f - 1 - P->n_planes);
             for (int k = 0; k < 3; ++k) { c->n[k] = n[k]; c->p[k] = ctr[k] - srad[s] * n[k]; }
         }
-        if (f > P->n_planes) /* a box: after its 13 first contacts, the second support points of the capsules that lie flat on one of its faces, shape-minor */
+    }
+    /* after the first contacts of every box: the second support points of the capsules that lie flat on a face, in the order of their first contacts
+       (box-major, shape-minor) */
+    for (int f = 1 + P->n_planes; f < nsurf; ++f) {
+        double (*n_first)[3] = n_first_all[f - 1 - P->n_planes], *t_first = t_first_all[f - 1 - P->n_planes];
+        const int *ok_first = ok_first_all[f - 1 - P->n_planes];
             for (int s = 1; s < 13; ++s) {
                 if (!ok_first[s]) continue;
                 const double *blo = P->box_lo[f - 1 - P->n_planes], *bhi = P->box_hi[f - 1 - P->n_planes];
