@@ -372,8 +372,10 @@ double tb_seg_box_param(const double *p0, const double *p1, const double *lo, co
 }
 
 /* Second support point of a capsule that rests (nearly) FLAT on a face of a box -- Bullet keeps a manifold of up to four points per pair there, a single
- * point lets the capsule rock about it.  The first contact is the axis point P(t1) closest to the box, with normal n1.  When n1 is a face normal (the
- * closest point of the box lies in a face's interior, or P(t1) is inside the box), the part of the axis that projects into that face is
+ * point lets the capsule rock about it.  The first contact is the axis point P(t1) closest to the box, with normal n1.  When n1 is a face normal to within
+ * 5.7 degrees (its largest component is 0.995 or more: the closest point of the box lies in a face's interior, P(t1) is inside the box -- or, the usual
+ * case of a capsule longer than the face, P(t1) has just passed the face's edge on its way down and the normal leans by the capsule's own tilt), the part
+ * of the axis that projects into that face is
  * [ta, tb] = [0, 1] clipped by the two slabs of the other axes; its end FARTHER from t1 is the candidate -- tb, towards the capsule's free end (its
  * start is where the neighbouring capsule of the leg ends), unless ta is farther by more than a thousandth of the axis: where a whole stretch is closest
  * t1 is its exact middle, and a tie must not be decided by rounding --: it becomes a contact of its own if
@@ -381,9 +383,9 @@ double tb_seg_box_param(const double *p0, const double *p1, const double *lo, co
  * second contact keeps the first one's normal and measures its distance to that face's plane -- P(t2) sits on the border of the face's region by
  * construction, where the closest feature of the box is a matter of rounding).  Returns 1 and t2, or 0. */
 static int tb_second_point(const double *p0, const double *p1, double t1, const double *n1, double rad, const double *lo, const double *hi, double *t2) {
-    int kf = -1, nz = 0;
-    for (int k = 0; k < 3; ++k) if (n1[k] != 0) { kf = k; ++nz; }
-    if (nz != 1) return 0;
+    int kf = 0;
+    for (int k = 1; k < 3; ++k) if (fabs(n1[k]) > fabs(n1[kf])) kf = k;
+    if (!(fabs(n1[kf]) >= 0.995)) return 0; /* within 5.7 degrees of a face normal */
     double ta = 0, tb = 1, len2 = 0;
     for (int k = 0; k < 3; ++k) {
         double d = p1[k] - p0[k];
@@ -534,7 +536,8 @@ void tb_ant_substep(const tb_params *P, double *q, double *u, const double *tau,
                 double w0[3] = {q[0] + s0[s][0], q[1] + s0[s][1], q[2] + s0[s][2]}, w1[3] = {q[0] + sc[s][0], q[1] + sc[s][1], q[2] + sc[s][2]}, t2, ctr[3], p[3], n[3];
                 if (!tb_second_point(w0, w1, t_first[s], n_first[s], srad[s], blo, bhi, &t2)) continue;
                 for (int k = 0; k < 3; ++k) { ctr[k] = s0[s][k] + t2 * (sc[s][k] - s0[s][k]); p[k] = q[k] + ctr[k]; n[k] = 0; }
-                int kf = n_first[s][0] != 0 ? 0 : (n_first[s][1] != 0 ? 1 : 2);
+                int kf = 0;
+                for (int k = 1; k < 3; ++k) if (fabs(n_first[s][k]) > fabs(n_first[s][kf])) kf = k;
                 n[kf] = n_first[s][kf] > 0 ? 1.0 : -1.0; /* the face of the first contact */
                 double dist = n[kf] * (p[kf] - (n[kf] > 0 ? bhi[kf] : blo[kf])) - srad[s];
                 if (!(dist < P->cdist)) continue;

@@ -597,3 +597,18 @@ def test_capsule_flat_on_a_box_face_gets_a_second_support_point():
         tilt = max(tilt, max(abs(np.degrees(np.arcsin((pts[l, 2, 0] - pts[l, 1, 0]) / 0.5657))) for l in (1, 2)))
     assert tilt < 0.1, tilt
     # (an EDGE contact -- a normal that is not a face normal -- gets none: test_foot_across_the_corner_of_the_maze_box_is_pushed_out counts one contact)
+    # the usual case of a capsule LONGER than the face: legs stretched out level over cubes (0.25 m tops under 0.57 m feet, a degree off level): the first contact
+    # has just passed the top's edge on its way down (its normal leans by that degree), the second is over the far edge of the top, the exact face normal
+    cfg = orc.default_config(K.HRL_ANT_GATHER)
+    q = np.zeros(15); q[6] = 1.0
+    q[8::2] = np.array([1, -1, -1, 1.0]) * np.radians([1.0, -0.7, 0.4, 0.0])
+    q[2] = 0.225 + 0.08 + 0.004
+    pts = leg_points(cfg.model, q)
+    cen = pts[:, 1, :2] + 0.5 * (pts[:, 2, :2] - pts[:, 1, :2])
+    p = tb.params(cfg, items=cen); p.gravity = 0.0; p.lmargin = -10.0   # (no limit rows: the ankles are far outside their range)
+    _, _, o5 = tb.ant_substep(p, q, np.zeros(14), np.zeros(8))
+    surf = [o5.contact_surface[c] for c in range(o5.n_contacts)]
+    assert surf == [100, 101, 102, 103, 100, 101, 102, 103], surf   # first contacts of all cubes, then the second points, in their order
+    d = np.array([o5.contact_dist[c] for c in range(8)])
+    span = 0.25 / np.cos(np.pi / 4)   # the cube's top along a foot that crosses it diagonally... the legs run along the diagonals of the axis-aligned cubes
+    assert np.all(np.abs(d[:4]) < 0.008) and np.all(d[4:] >= d[:4] - 1e-12) and np.all(d[4:] - d[:4] < span * np.sin(np.radians(1.0)) + 1e-6), d
