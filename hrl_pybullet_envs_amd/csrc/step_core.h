@@ -167,6 +167,9 @@ struct alignas(16) WaveLds {
     int nC, nL, nS, on; /* contacts / limit rows / self contacts found by ant_contacts for this env's substep; on = the record holds an env */
     int ncnt;           /* ant_contacts_group: contacts a packed pass found for this env (added to nC by the next phase) */
     float planes[4][4];  /* lateral half-spaces (n, d), copied from the constants when the env is loaded: the collision passes index them per lane */
+    /* (at the END of the record: in the middle, behind csurf, the same two arrays made every launch 0.4 us longer -- they shift the solver's arrays against the LDS banks) */
+    float ct[MAXC];      /* contacts of a capsule with a box / cube: the parameter of the contact's point on the capsule's axis (read by second_support) */
+    int csph[MAXC];      /* the shape that touches: 0 the torso sphere, 1..12 the capsule that ends in sphere s; -1: a capsule pair */
 #ifdef HRL_WGTIME
     int dbg_rows; /* diagnostic build (tools/wg_times.py): solver rows | cube passes << 16 | self-contact substeps << 24, summed over the step */
 #endif
@@ -664,7 +667,7 @@ HRL_DEV int surf_item(int i) { return i + (i < 48 ? SURF_ITEM : SURF_SELF); }
 constexpr float ITEM_HALF = 0.125f, ITEM_Z = 0.1f; /* assets/food.xml:12,19 (box size 0.25), gather_scene.py:62 */
 
 /* r = contact point relative to O, n = normal towards the body `link`; link2 >= 0: against that ant body (self contact) */
-struct Hit { bool ok; float dist, n[3], r[3], mu; int link, link2, surf; };
+struct Hit { bool ok; float dist, n[3], r[3], mu, t; int link, link2, surf, sph; }; /* t, sph: the axis parameter and the shape of a capsule's contact with a box (WaveLds::ct, csph) */
 
 /* signed distance of a sphere (centre p, radius rad) to the axis-aligned box [lo, hi]; n = unit normal towards the sphere */
 HRL_DEV float sphere_vs_box(const float *p, float rad, const float *lo, const float *hi, float *n) {
@@ -763,7 +766,7 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
     float r_torso = c.r_torso, r_caps = c.r_caps, ctr[3] = {0.f, 0.f, 0.f};
     HRL_PIN_SCALAR(r_torso); /* two scalar loads and a select: left alone, the compiler selects the ADDRESS per lane and */
     HRL_PIN_SCALAR(r_caps);  /* fetches the radius with a vector memory load in the middle of the collision pass           */
-    h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu;
+    h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu; h.t = 0.f; h.sph = sph;
     h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.r[0] = h.r[1] = h.r[2] = 0.f;
     if (sph < 0 || sph >= 13) return h;
     int level = 0, leg = 0;
@@ -792,6 +795,7 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
 #pragma unroll
         for (int k = 0; k < 3; ++k) { c0[k] = level == 0 ? 0.f : s0[k]; pw[k] = q[k] + c0[k]; d[k] = ctr[k] - c0[k]; }
         const float t = seg_box_t(pw, d, lo, hi);
+        h.t = t;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { ctr[k] = fma_(d[k], t, c0[k]); p[k] = q[k] + ctr[k]; }
         h.dist = sphere_vs_box(p, rad, lo, hi, h.n);
@@ -806,13 +810,104 @@ HRL_DEV Hit sphere_vs_surface(const DevCfg &c, const WaveLds &L, const float *q,
     return h;
 }
 
+/* Is kept contact i of the record a capsule's (first) contact with a convex box -- the maze box or an item cube? */
+HRL_DEV bool contact_is_capsule_on_box(const WaveLds &L, int i) {
+    return (L.csurf[i] >= SURF_BOX) & (L.csph[i] > 0) & (L.clink2[i] < 0);
+}
+/* What is asked FIRST of every kept contact (a handful of loads and multiplies, in the ballot that decides whether second_support runs at all): is it a
+ * capsule's contact with a box whose normal is a face normal to within 5.7 degrees, and can a point a radius or more along the capsule's axis still be
+ * within the contact distance of that face -- it rises by at least |d_kf| rad / |d| against cdist - dist1 (+ 5 mm: just past the face's edge dist1 is the
+ * distance to the edge, a hair more than the height over the face)?  A foot that stands on a cube at 30 degrees and more says no.  Implied by
+ * second_support's own tests; the oracle rounds it alike (orc_impl.h: second_point). */
+HRL_DEV bool second_worth_a_look(const DevCfg &c, const WaveLds &L, int i, int *kf_out) {
+    const int sph = L.csph[i];
+    const bool on_box = contact_is_capsule_on_box(L, i) & (sph < 13);
+    const int s1 = on_box ? sph - 1 : 0, leg = s1 / 3, level = s1 % 3;
+    const float a0 = fabsf(L.cdir[0][i][0]), a1 = fabsf(L.cdir[0][i][1]), a2 = fabsf(L.cdir[0][i][2]);
+    const int kf = ((a0 >= a1) & (a0 >= a2)) ? 0 : (a1 >= a2 ? 1 : 2);
+    *kf_out = kf;
+    const bool face = (kf == 0 ? a0 : (kf == 1 ? a1 : a2)) >= 0.995f;
+    const float *src = level == 0 ? L.ph[leg] : (level == 1 ? L.pa[leg] : L.tip[leg]), *s0 = level == 1 ? L.ph[leg] : L.pa[leg];
+    float d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = src[k] - (level == 0 ? 0.f : s0[k]);
+    float r_caps = c.r_caps;
+    HRL_PIN_SCALAR(r_caps);
+    const float a = (kf == 0 ? d[0] : (kf == 1 ? d[1] : d[2])) * r_caps, b = (c.cdist - L.cdist_[i]) + 0.005f;
+    return on_box & face & (a * a <= (b * b) * dot3(d, d));
+}
+/* Second support point of a capsule that rests (nearly) FLAT on a face of a box -- Bullet keeps a manifold of up to four points per pair there, one point
+ * lets the capsule rock about it.  Kept contact i is the capsule's first contact: the axis point P(t1) closest to the box, normal n1.  When n1 is a FACE
+ * normal to within 5.7 degrees (largest component >= 0.995: the box's closest point lies in a face's interior, P(t1) is inside the box, or -- a capsule longer
+ * than the face -- P(t1) has just passed the face's edge and the normal leans by the capsule's own tilt), the part of the axis that projects into that face is [ta, tb] = [0, 1] clipped by the slabs of the two other axes; its end farther from t1 -- tb, towards the capsule's free end, unless ta
+ * is farther by more than a thousandth of the axis (a tie at the exact middle of a stretch is not decided by rounding) -- is the second point P(t2) if it
+ * is a radius or more away from P(t1) along the axis.  It keeps the first contact's normal and measures its distance to that face's plane (P(t2) sits on
+ * the border of the face's region by construction, where the box's closest feature is a matter of rounding).  The second points follow the first contacts
+ * of all boxes and cubes in the candidate list, in their order.  Branch-free; operations and order are the oracle's (orc_impl.h: second_point,
+ * shape_vs_box_second). */
+HRL_DEV Hit second_support(const DevCfg &c, const WaveLds &L, const float *q, int i) {
+    Hit h;
+    h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu; h.t = 0.f; h.sph = -1;
+    h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.r[0] = h.r[1] = h.r[2] = 0.f;
+    if (i < 0 || i >= MAXC) return h;
+    const int surf = L.csurf[i], sph = L.csph[i];
+    if (!contact_is_capsule_on_box(L, i) || sph >= 13) return h;
+    float r_caps = c.r_caps;
+    HRL_PIN_SCALAR(r_caps);
+    const float rad = r_caps;
+    const int leg = (sph - 1) / 3, level = (sph - 1) % 3;
+    float lo[3], hi[3];
+    const int item = surf >= SURF_SELF ? surf - SURF_SELF : (surf >= SURF_ITEM ? surf - SURF_ITEM : -1); /* the inverse of surf_item(); -1: the maze box */
+    if (item >= 0) {
+        const float ix = L.items[2 * item], iy = L.items[2 * item + 1];
+        lo[0] = ix - ITEM_HALF; lo[1] = iy - ITEM_HALF; lo[2] = ITEM_Z - ITEM_HALF; hi[0] = ix + ITEM_HALF; hi[1] = iy + ITEM_HALF; hi[2] = ITEM_Z + ITEM_HALF;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = c.box_lo[k]; hi[k] = c.box_hi[k]; }
+    }
+    const float *src = level == 0 ? L.ph[leg] : (level == 1 ? L.pa[leg] : L.tip[leg]), *s0 = level == 1 ? L.ph[leg] : L.pa[leg];
+    float c0[3], pw[3], d[3], n1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c0[k] = level == 0 ? 0.f : s0[k]; pw[k] = q[k] + c0[k]; d[k] = src[k] - c0[k]; n1[k] = L.cdir[0][i][k]; }
+    const float t1 = L.ct[i];
+    const float a0 = fabsf(n1[0]), a1 = fabsf(n1[1]), a2 = fabsf(n1[2]);
+    const int kf = ((a0 >= a1) & (a0 >= a2)) ? 0 : (a1 >= a2 ? 1 : 2);
+    const bool face = (kf == 0 ? a0 : (kf == 1 ? a1 : a2)) >= 0.995f;
+    float ta = 0.f, tb = 1.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool use = (k != kf) & (d[k] != 0.f);
+        const float inv = 1.f / d[k];
+        const float u = (lo[k] - pw[k]) * inv, v = (hi[k] - pw[k]) * inv;
+        const float tl_ = u < v ? u : v, th_ = u < v ? v : u;
+        ta = (use & (tl_ > ta)) ? tl_ : ta; tb = (use & (th_ < tb)) ? th_ : tb;
+    }
+    const float t2 = ((tb - t1) + 1e-3f >= t1 - ta) ? tb : ta, dt = t2 - t1;
+    const bool far_enough = (dt * dt) * dot3(d, d) >= rad * rad;
+    const float sa = (kf == 0 ? d[0] : (kf == 1 ? d[1] : d[2])) * rad, sb = (c.cdist - L.cdist_[i]) + 0.005f;
+    const bool slope_ok = sa * sa <= (sb * sb) * dot3(d, d); /* second_worth_a_look's question, on the same operands */
+    const float n1f = kf == 0 ? n1[0] : (kf == 1 ? n1[1] : n1[2]);
+    const float sg = n1f > 0.f ? 1.f : -1.f;
+    float ctr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ctr[k] = fma_(d[k], t2, c0[k]); h.n[k] = k == kf ? sg : 0.f; }
+    const float pf = kf == 0 ? q[0] + ctr[0] : (kf == 1 ? q[1] + ctr[1] : q[2] + ctr[2]);
+    const float lof = kf == 0 ? lo[0] : (kf == 1 ? lo[1] : lo[2]), hif = kf == 0 ? hi[0] : (kf == 1 ? hi[1] : hi[2]);
+    h.dist = sg * (pf - (sg > 0.f ? hif : lof)) - rad;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) h.r[k] = fma_(-rad, h.n[k], ctr[k]);
+    h.link = L.clink[i]; h.surf = surf; h.t = t2; h.sph = sph;
+    h.ok = face & slope_ok & far_enough & (h.dist < c.cdist);
+    return h;
+}
+
 /* Phase C helper, self-collision: capsule pair `id` = 8 * legpair + 3 * segA + segB - 1 (legpair (0,1),(0,2),(0,3),(1,2),
  * (1,3),(2,3); seg 0 = the jointless leg capsule O -> hip point (torso body), 1 = aux, 2 = foot; (0,0) skipped).
  * Closest points of the two capsule axes (Ericson, Real-Time Collision Detection 5.1.9) with the fixed squared segment
  * lengths 0.08 / 0.32 and their exact reciprocals 12.5 / 3.125; contact point = midway between the two surface points. */
 HRL_DEV Hit capsule_pair(const DevCfg &c, const WaveLds &L, int id) {
     Hit h;
-    h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu_self;
+    h.ok = false; h.dist = 0.f; h.link = 0; h.link2 = -1; h.surf = 0; h.mu = c.mu_self; h.t = 0.f; h.sph = -1;
     h.n[0] = h.n[1] = 0.f; h.n[2] = 1.f; h.r[0] = h.r[1] = h.r[2] = 0.f;
     if (id < 0 || id >= 48) return h;
     const int pp = id >> 3, k = (id & 7) + 1, a = k / 3, b = k - 3 * a;
@@ -1230,6 +1325,17 @@ HRL_DEV void ant_group_block(X &x, const DevCfg &c, int qi) {
     x.stamp(4);
 }
 
+/* One kept contact into the record (contact index i < MAXC). */
+HRL_DEV void store_contact(WaveLds &L, int i, const Hit &h, bool up, bool on_box = false) { /* on_box: a pass against the maze box / the cubes (its contacts' axis parameter and shape are read by second_support) */
+    if (i < MAXC) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) L.cr[i][k] = h.r[k];
+        store_contact_frame(L, i, h.n, up);
+        L.cdist_[i] = h.dist; L.clink[i] = h.link; L.clink2[i] = h.link2; L.csurf[i] = h.surf; L.cmu[i] = h.mu;
+        if (on_box) { L.ct[i] = h.t; L.csph[i] = h.sph; }
+    }
+}
+
 /* Contacts and limit rows of ONE env's pose q[qi] into its record L -- executed by whichever wave has the time: it needs the pose
  * only (the leg points come from a POS_ONLY kinematics pass of its own), so it runs WHILE the leader wave works through the group
  * block, on the waves that would otherwise wait at the barrier.  Results: the contact / limit lists and L.nC / nL / nS. */
@@ -1261,17 +1367,10 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
         for (int k = 0; k < 3; ++k) { const float cp = clampf(q[k], c.box_lo[k], c.box_hi[k]); d2 += (q[k] - cp) * (q[k] - cp); }
         near_box = d2 < reach * reach;
     }
-    auto keep = [&](int base, bool up = false) {
-        return [&L, base, up](int, int rank, const Hit &h) {
-            const int i = base + rank;
-            if (i < MAXC) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) L.cr[i][k] = h.r[k];
-                store_contact_frame(L, i, h.n, up);
-                L.cdist_[i] = h.dist; L.clink[i] = h.link; L.clink2[i] = h.link2; L.csurf[i] = h.surf; L.cmu[i] = h.mu;
-            }
-        };
+    auto keep = [&](int base, bool up = false, bool on_box = false) {
+        return [&L, base, up, on_box](int, int rank, const Hit &h) { store_contact(L, base + rank, h, up, on_box); };
     };
+    bool any_box = false; /* a pass against the box / a cube kept a contact: only then is there anything for second_support to look at */
     for (int pass = 0; pass < 3; ++pass) {
         const int nsurf = pass == 0 ? 1 : (pass == 1 ? c.n_planes : c.n_boxes);
         if (nsurf == 0) continue;
@@ -1282,10 +1381,11 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
                 const int fi = lane / 13, sph = lane - 13 * fi;
                 return sphere_vs_surface(c, L, q, fi < nsurf ? sph : -1, f0 + fi, -1);
             },
-            keep(nC, pass == 0),
+            keep(nC, pass == 0, pass == 2),
             [&](int lane, const Hit &h) { if (pass == 0 && lane < 16) L.gtouch[lane] = h.ok ? 1 : 0; });
         nC += cnt;
         if (nC > cap) nC = cap;
+        any_box = any_box | ((pass == 2) & (cnt > 0));
     }
     if (items_on) { /* food / poison cubes: lane = item decides whether its cube is within reach of any sphere (the cube's
                        half extent more than the planes' bound, per axis), then the near cubes are tested four at a time */
@@ -1315,11 +1415,20 @@ HRL_DEV void ant_contacts(X &x, const DevCfg &c, WaveLds &L, int qi, bool items_
                     const int item = slot == 0 ? it[0] : (slot == 1 ? it[1] : (slot == 2 ? it[2] : (slot == 3 ? it[3] : -1)));
                     return sphere_vs_surface(c, L, q, item >= 0 ? sph : -1, 0, item);
                 },
-                keep(nC), [&](int, const Hit &) {});
+                keep(nC, false, true), [&](int, const Hit &) {});
             nC += cnt;
             if (nC > cap) nC = cap;
+            any_box = any_box | (cnt > 0);
         }
     }
+#ifndef HRL_NO_SECOND /* (A/B builds of tools/variants.py define it) */
+    if (x.uniform(any_box) && x.each_ballot([&](int lane) { int kf; return (lane < nC) & second_worth_a_look(c, L, lane < MAXC ? lane : 0, &kf); })) {
+        /* second support points of the capsules that lie flat on a face of the box / a cube: one pass over the kept contacts, lane = contact */
+        int cnt = x.each_compact([&](int lane) { return second_support(c, L, q, lane < nC ? lane : -1); }, keep(nC, false, true), [&](int, const Hit &) {});
+        nC += cnt;
+        if (nC > cap) nC = cap;
+    }
+#endif
     if (c.self_collision) { /* Seen from above in the torso frame, leg l is the jointless capsule O -> hip point followed by the aux
         and foot capsules, which both lie in the vertical plane through the hip point at 45 + 90 l degrees + hip angle: with
         |ankle angle| <= 2 rad the foot folds back by at most 0.566 cos(2) = 0.24 m < the aux length, so everything past the
@@ -1378,16 +1487,6 @@ HRL_DEV void ant_limits(X &x, const DevCfg &c, WaveLds &L, int qi) {
     });
 }
 
-/* One kept contact into the record (contact index i < MAXC). */
-HRL_DEV void store_contact(WaveLds &L, int i, const Hit &h, bool up) {
-    if (i < MAXC) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) L.cr[i][k] = h.r[k];
-        store_contact_frame(L, i, h.n, up);
-        L.cdist_[i] = h.dist; L.clink[i] = h.link; L.clink2[i] = h.link2; L.csurf[i] = h.surf; L.cmu[i] = h.mu;
-    }
-}
-
 /* Contacts of ALL FOUR envs of a group by ONE wave, 16 lanes per env (lane >> 4 = env of the group, lane & 15 = sphere / item / joint):
  * the passes every substep runs -- leg points, the ground pass (13 spheres), the near-cube ballot and one cube per env and pass -- are
  * one instruction stream for the four envs instead of four streams (the group's vector-instruction count, which is what four workgroups per
@@ -1398,6 +1497,7 @@ template <class X>
 HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
     x.refresh();
     const int cap = c.max_contacts;
+    bool any_box = false; /* a pass against the maze box / a cube ran (rare): only then does second_support have anything to look at */
     x.each([&](int lane) { WaveLds &L = x.lds(lane >> 4); phase_kin_ankle<true>(c, L, x.reg(lane), L.q[qi], (lane & 15) << 2); });
     const float reach = 0.2f * 1.41421356f + c.L1 + c.L2 + c.r_caps + c.cdist + 0.02f;
     /* ground pass of the four envs; its count starts the env's list */
@@ -1436,10 +1536,11 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
                 const int f0 = pass == 1 ? 1 : 1 + c.n_planes;
                 int cnt = x.each_compact(
                     [&](int lane) { const int fi = lane / 13, sph = lane - 13 * fi; return sphere_vs_surface(c, L, q, fi < nsurf ? sph : -1, f0 + fi, -1); },
-                    [&L, nC](int, int rank, const Hit &h) { store_contact(L, nC + rank, h, false); },
+                    [&L, nC, pass](int, int rank, const Hit &h) { store_contact(L, nC + rank, h, false, pass == 2); },
                     [&](int, const Hit &) {});
                 nC += cnt;
                 if (nC > cap) nC = cap;
+                any_box = any_box | ((pass == 2) & (cnt > 0));
             }
             x.each([&](int lane) { if (lane == 0) L.nC = nC; });
         }
@@ -1472,11 +1573,12 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
                     const int s = lane & 15, item = sub ? ib + __builtin_ctz(sub) : -1;
                     return sphere_vs_surface(c, L, L.q[qi], (item >= 0 && s < 13) ? s : -1, 0, item);
                 },
-                [&](int lane, int rank, const Hit &h) { WaveLds &L = x.lds(lane >> 4); store_contact(L, L.nC + rank, h, false); },
+                [&](int lane, int rank, const Hit &h) { WaveLds &L = x.lds(lane >> 4); store_contact(L, L.nC + rank, h, false, true); },
                 [&](int lane, const Hit &, int count) { if ((lane & 15) == 0) x.lds(lane >> 4).ncnt = count; });
             x.each([&](int lane) {
                 if ((lane & 15) == 0) { WaveLds &L = x.lds(lane >> 4); const int n = L.nC + L.ncnt; L.nC = n > cap ? cap : n; }
             });
+            any_box = true;
             }
             unsigned long long low = 0; /* every env's lowest set bit is done */
 #pragma unroll
@@ -1485,6 +1587,25 @@ HRL_DEV void ant_contacts_group(X &x, const DevCfg &c, int qi, bool items_on) {
         }
         }
     }
+#ifndef HRL_NO_SECOND
+    if (x.uniform(any_box)) { /* second support points (see ant_contacts): lane = (env, kept contact), the four envs at once */
+        const unsigned long long any = x.each_ballot([&](int lane) {
+            const WaveLds &L = x.lds(lane >> 4);
+            const int i = lane & 15;
+            int kf;
+            return (i < L.nC) & second_worth_a_look(c, L, i < MAXC ? i : 0, &kf);
+        });
+        if (any) {
+            x.each_compact16(
+                [&](int lane) { const WaveLds &L = x.lds(lane >> 4); const int i = lane & 15; return second_support(c, L, L.q[qi], i < L.nC ? i : -1); },
+                [&](int lane, int rank, const Hit &h) { WaveLds &L = x.lds(lane >> 4); store_contact(L, L.nC + rank, h, false, true); },
+                [&](int lane, const Hit &, int count) { if ((lane & 15) == 0) x.lds(lane >> 4).ncnt = count; });
+            x.each([&](int lane) {
+                if ((lane & 15) == 0) { WaveLds &L = x.lds(lane >> 4); const int n = L.nC + L.ncnt; L.nC = n > cap ? cap : n; }
+            });
+        }
+    }
+#endif
     if (c.self_collision) { /* the envs with a joint outside the range in which no two legs can meet (see ant_contacts), one after the other */
         const bool thin = (c.r_caps + c.r_caps) + c.cdist < 0.2f;
         const unsigned long long unsafe = x.each_ballot([&](int lane) { /* lane = (env, joint) */

@@ -970,7 +970,7 @@ static void FN(orc_pgs)(int nr, REAL (*J)[16], REAL (*B)[16], const REAL *bias, 
 /* A contact: body A = (level, leg) of the ant against the static world (level2 < 0) or against another ant body
  * B = (level2, leg2) (self-collision).  r = contact point relative to O, n = normal towards A, surface = what it is with:
  * 0 ground, 1..n_planes lateral walls, 8 + b box b of the world, 16 + k item cube k, 64 + pair id self. */
-typedef struct FN(orc_contact) { int level, leg, level2, leg2, sphere, surface; REAL r[3], n[3], dist, mu; } FN(orc_contact);
+typedef struct FN(orc_contact) { int level, leg, level2, leg2, sphere, surface, second /* 1: a second support point */; REAL r[3], n[3], dist, mu; } FN(orc_contact);
 
 #define ORC_SURF_BOX 8
 #define ORC_SURF_ITEM 16
@@ -1052,13 +1052,59 @@ static REAL FN(seg_box_t)(const REAL *p, const REAL *d, const REAL *lo, const RE
 REAL FN(orc_seg_box_t)(const REAL *p, const REAL *d, const REAL *lo, const REAL *hi) { return FN(seg_box_t)(p, d, lo, hi); } /* tests */
 /* shape s of pose `pos` against the box: the point of its axis closest to the box stands in for the sphere centre of sphere_vs_box
  * (an axis point inside the box leaves through the nearest face, as a sphere centre does).  c = that point relative to O. */
-static REAL FN(shape_vs_box)(const FN(orc_dyn) * D, const REAL *pos, int s, const REAL *c_end, REAL rad, const REAL *lo, const REAL *hi, REAL *c, REAL *n) {
+static REAL FN(shape_vs_box)(const FN(orc_dyn) * D, const REAL *pos, int s, const REAL *c_end, REAL rad, const REAL *lo, const REAL *hi, REAL *c, REAL *n, REAL *t_out) {
     REAL c0[3], pw[3], d[3], p[3];
     FN(capsule_start)(D, s, c0);
     for (int k = 0; k < 3; ++k) { pw[k] = pos[k] + c0[k]; d[k] = c_end[k] - c0[k]; }
     const REAL t = FN(seg_box_t)(pw, d, lo, hi);
     for (int k = 0; k < 3; ++k) { c[k] = FMA_(d[k], t, c0[k]); p[k] = pos[k] + c[k]; }
+    if (t_out) *t_out = t;
     return FN(sphere_vs_box)(p, rad, lo, hi, n);
+}
+/* Second support point of a capsule that rests (nearly) flat on a face of a box (Bullet keeps a manifold of up to four points per pair there; one point
+ * lets the capsule rock about it).  The first contact is the axis point P(t1) closest to the box, normal n1.  When n1 is a FACE normal to within 5.7 degrees -- its largest
+ * component is 0.995 or more: the closest point of the box lies in a face's interior, P(t1) is inside the box, or (a capsule longer than the face) P(t1) has
+ * just passed the face's edge on its way down and the normal leans by the capsule's own tilt -- the part of the axis that projects into that face is [ta, tb] = [0, 1] clipped by the slabs of the two other axes; its end farther from t1 -- tb, towards the capsule's free end (its start is where
+ * the leg's neighbouring capsule ends), unless ta is farther by more than a thousandth of the axis -- is the candidate t2, if it is at least one radius away from P(t1) along the axis.  The caller tests
+ * the sphere at P(t2) against the box like any other.  Every operation pinned; a NaN anywhere ends in "none". */
+static int FN(second_point)(const REAL *p, const REAL *d, REAL t1, const REAL *n1, REAL dist1, REAL cdist, REAL rad, const REAL *lo, const REAL *hi, REAL *t2) {
+    const REAL a0 = RFABS(n1[0]), a1 = RFABS(n1[1]), a2 = RFABS(n1[2]);
+    const int kf = (a0 >= a1 && a0 >= a2) ? 0 : (a1 >= a2 ? 1 : 2);
+    if (!((kf == 0 ? a0 : (kf == 1 ? a1 : a2)) >= R_(0.995))) return 0;
+    { /* what the wave form asks FIRST, for every kept box contact: can a point a radius or more along this axis still be within the contact distance of the
+         face at all?  It rises by |d_kf| per unit of t, i.e. by at least |d_kf| rad / |d| -- against cdist - dist1 (+ 5 mm: just past the face's edge dist1 is
+         the distance to the edge, a hair more than the height over the face).  Implied by the tests below, so no part of the textbook form; stated here
+         because the wave form decides by it whether to run this function, and both must round alike. */
+        const REAL a = d[kf] * rad, b = (cdist - dist1) + R_(0.005);
+        if (!(a * a <= (b * b) * FN(v3dot)(d, d))) return 0;
+    }
+    REAL ta = 0, tb = 1;
+    for (int k = 0; k < 3; ++k) {
+        if (k == kf || d[k] == 0) continue;
+        const REAL inv = R_(1) / d[k];
+        const REAL u = (lo[k] - p[k]) * inv, v = (hi[k] - p[k]) * inv;
+        const REAL tl = u < v ? u : v, th = u < v ? v : u;
+        ta = tl > ta ? tl : ta; tb = th < tb ? th : tb;
+    }
+    const REAL tt = ((tb - t1) + R_(1e-3) >= t1 - ta) ? tb : ta, dt = tt - t1; /* the band: a tie at the exact middle of a stretch is not decided by rounding */
+    *t2 = tt;
+    return (dt * dt) * FN(v3dot)(d, d) >= rad * rad;
+}
+/* the second support point of shape s (first contact: parameter t1, normal n1): the sphere at P(t2) against the FACE of the first contact -- its normal, and the
+ * distance to that face's plane (P(t2) sits on the border of the face's region by construction, where the box's closest feature is a matter of rounding);
+ * returns 0 when the shape has none */
+static int FN(shape_vs_box_second)(const FN(orc_dyn) * D, const REAL *pos, int s, const REAL *c_end, REAL rad, const REAL *lo, const REAL *hi, REAL t1, const REAL *n1,
+                                   REAL dist1, REAL cdist, REAL *c, REAL *n, REAL *dist) {
+    REAL c0[3], pw[3], d[3], t2;
+    FN(capsule_start)(D, s, c0);
+    for (int k = 0; k < 3; ++k) { pw[k] = pos[k] + c0[k]; d[k] = c_end[k] - c0[k]; }
+    if (!FN(second_point)(pw, d, t1, n1, dist1, cdist, rad, lo, hi, &t2)) return 0;
+    const REAL a0 = RFABS(n1[0]), a1 = RFABS(n1[1]), a2 = RFABS(n1[2]);
+    const int kf = (a0 >= a1 && a0 >= a2) ? 0 : (a1 >= a2 ? 1 : 2);
+    const REAL sg = n1[kf] > 0 ? R_(1) : R_(-1);
+    for (int k = 0; k < 3; ++k) { c[k] = FMA_(d[k], t2, c0[k]); n[k] = k == kf ? sg : R_(0); }
+    *dist = sg * ((pos[kf] + c[kf]) - (sg > 0 ? hi[kf] : lo[kf])) - rad;
+    return 1;
 }
 static void FN(item_box)(const REAL *item_xy, REAL *lo, REAL *hi) {
     lo[0] = item_xy[0] - ORC_ITEM_HALF; lo[1] = item_xy[1] - ORC_ITEM_HALF; lo[2] = ORC_ITEM_Z - ORC_ITEM_HALF;
@@ -1091,7 +1137,10 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
     const int use_items = (K->item_collision && items_xy) ? n_items : 0;
     const int nsurf = 1 + W->n_planes + W->n_boxes + use_items;
     for (int s = 0; s < 13; ++s) ground_touch[s] = 0;
-    for (int f = 0; f < nsurf; ++f)
+    /* the first contacts with boxes and cubes, in candidate order, for the second support points after them */
+    struct { int s, surface; REAL t, dist, n[3], lo[3], hi[3]; } first[13 * (HRL_MAX_ITEMS + 4)];
+    int n_first = 0;
+    for (int f = 0; f < nsurf; ++f) {
         for (int s = 0; s < 13; ++s) {
             REAL c[3], rad, n[3], dist, p[3];
             int level, leg, surface;
@@ -1104,7 +1153,13 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                 dist = (FN(v3dot)(n, p) - W->plane_d[f - 1]) - rad; surface = f;
             } else if (f <= W->n_planes + W->n_boxes) {
                 const int b = f - 1 - W->n_planes;
-                dist = FN(shape_vs_box)(D, pos, s, c, rad, W->box_lo[b], W->box_hi[b], c, n); surface = ORC_SURF_BOX + b;
+                REAL t1;
+                dist = FN(shape_vs_box)(D, pos, s, c, rad, W->box_lo[b], W->box_hi[b], c, n, &t1); surface = ORC_SURF_BOX + b;
+                if (dist < K->cdist && s > 0) {
+                    first[n_first].s = s; first[n_first].surface = surface; first[n_first].t = t1; first[n_first].dist = dist;
+                    for (int a = 0; a < 3; ++a) { first[n_first].n[a] = n[a]; first[n_first].lo[a] = W->box_lo[b][a]; first[n_first].hi[a] = W->box_hi[b][a]; }
+                    ++n_first;
+                }
             } else {
                 const int k = f - 1 - W->n_planes - W->n_boxes;
                 REAL lo[3], hi[3];
@@ -1115,18 +1170,41 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                     if (!(RFABS(pos[0] - items_xy[2 * k]) < reach) || !(RFABS(pos[1] - items_xy[2 * k + 1]) < reach)) continue;
                 }
                 FN(item_box)(items_xy + 2 * k, lo, hi);
-                dist = FN(shape_vs_box)(D, pos, s, c, rad, lo, hi, c, n); surface = ORC_SURF_OF_ITEM(k);
+                REAL t1;
+                dist = FN(shape_vs_box)(D, pos, s, c, rad, lo, hi, c, n, &t1); surface = ORC_SURF_OF_ITEM(k);
+                if (dist < K->cdist && s > 0) {
+                    first[n_first].s = s; first[n_first].surface = surface; first[n_first].t = t1; first[n_first].dist = dist;
+                    for (int a = 0; a < 3; ++a) { first[n_first].n[a] = n[a]; first[n_first].lo[a] = lo[a]; first[n_first].hi[a] = hi[a]; }
+                    ++n_first;
+                }
             }
             if (dist < K->cdist) {
                 if (f == 0) ground_touch[s] = 1;
                 ++ncand;
                 if (nc < K->max_contacts) {
                     FN(orc_contact) *cc = &C[nc++];
-                    cc->level = level; cc->leg = leg; cc->level2 = -1; cc->leg2 = 0; cc->sphere = s; cc->dist = dist; cc->surface = surface; cc->mu = K->mu;
+                    cc->level = level; cc->leg = leg; cc->level2 = -1; cc->leg2 = 0; cc->sphere = s; cc->dist = dist; cc->surface = surface; cc->mu = K->mu; cc->second = 0;
                     for (int k = 0; k < 3; ++k) { cc->n[k] = n[k]; cc->r[k] = FMA_(-rad, n[k], c[k]); }
                 }
             }
         }
+    }
+    /* after the first contacts of every box and cube: the second support points of the capsules that lie flat on a face, in the order of their first contacts */
+    for (int i = 0; i < n_first; ++i) {
+        REAL c[3], rad, n[3], dist;
+        int level, leg;
+        const int s = first[i].s;
+        FN(sphere_info)(K, D, s, c, &rad, &level, &leg);
+        if (!FN(shape_vs_box_second)(D, pos, s, c, rad, first[i].lo, first[i].hi, first[i].t, first[i].n, first[i].dist, K->cdist, c, n, &dist)) continue;
+        if (dist < K->cdist) {
+            ++ncand;
+            if (nc < K->max_contacts) {
+                FN(orc_contact) *cc = &C[nc++];
+                cc->level = level; cc->leg = leg; cc->level2 = -1; cc->leg2 = 0; cc->sphere = s; cc->dist = dist; cc->surface = first[i].surface; cc->mu = K->mu; cc->second = 1;
+                for (int k = 0; k < 3; ++k) { cc->n[k] = n[k]; cc->r[k] = FMA_(-rad, n[k], c[k]); }
+            }
+        }
+    }
     if (K->self_collision) {
         const REAL zero[3] = {0, 0, 0};
         const REAL A0 = R_(0.08), A2 = R_(0.32), I0 = R_(12.5), I2 = R_(3.125); /* |(.2,.2)|^2, |(.4,.4)|^2 (ant.xml:16-22) and reciprocals */
@@ -1149,7 +1227,7 @@ static int FN(orc_detect)(const FN(orc_consts) * K, const FN(orc_world) * W, con
                         if (nc >= K->max_contacts) continue;
                         FN(orc_contact) *cc = &C[nc++];
                         const REAL len = RSQRT(d2n);
-                        cc->level = a; cc->leg = i; cc->level2 = b; cc->leg2 = j; cc->sphere = -1; cc->surface = ORC_SURF_SELF + id; cc->mu = K->mu_self;
+                        cc->level = a; cc->leg = i; cc->level2 = b; cc->leg2 = j; cc->sphere = -1; cc->surface = ORC_SURF_SELF + id; cc->mu = K->mu_self; cc->second = 0;
                         cc->dist = len - (K->r_caps + K->r_caps);
                         if (len > 0) { const REAL il = R_(1) / len; for (int k = 0; k < 3; ++k) cc->n[k] = dv[k] * il; } else FN(v3set)(cc->n, 0, 0, 1);
                         for (int k = 0; k < 3; ++k) cc->r[k] = R_(0.5) * (c1[k] + c2[k]); /* equal radii: midway between the two surface points */
@@ -1942,6 +2020,18 @@ void FN(orc_ant_leg_points)(const hrl_model *M, const REAL *q, REAL *out36) {
     FN(orc_dynamics)(&K, q, u0, 0, &D);
     for (int l = 0; l < 4; ++l)
         for (int k = 0; k < 3; ++k) { out36[9 * l + k] = q[k] + D.ph[l][k]; out36[9 * l + 3 + k] = q[k] + D.pa[l][k]; out36[9 * l + 6 + k] = q[k] + D.tip[l][k]; }
+}
+/* how many of the contacts the collision pass of pose q keeps are SECOND support points of capsules lying flat on a box face (tests: that a case exercises them) */
+int FN(orc_ant_second_points)(const hrl_config *cfg, const REAL *q, const REAL *items_xy, int n_items) {
+    FN(orc_consts) K; FN(orc_dyn) D; FN(orc_world) W; FN(orc_contact) C[MAXC];
+    REAL u0[14] = {0};
+    int gt[13], ncand = 0, n2 = 0;
+    FN(orc_consts_init)(&cfg->model, &K);
+    FN(orc_world_init)(cfg, &W);
+    FN(orc_dynamics)(&K, q, u0, 0, &D);
+    const int nc = FN(orc_detect)(&K, &W, &D, q, items_xy, n_items, C, gt, &ncand);
+    for (int c = 0; c < nc; ++c) n2 += C[c].second;
+    return n2;
 }
 /* the hard-wired ant model as numbers (tests/test_assets.py holds them against assets/ant.xml): radii, capsule lengths, masses and central
  * inertias (alpha, beta) of the three body types, joint ranges [rad] */

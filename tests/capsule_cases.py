@@ -95,3 +95,62 @@ def count_mid_section_contacts(o, rows, boxes_of):
             if s in boxes and np.all(end_sphere_clearance(o.cfg.model, q, *boxes[s]) >= o.cfg.model.contact_dist):
                 seen += 1
     return seen
+
+
+def count_second_points(o, rows):
+    """kept contacts of the first substep's collision pass (fp64 oracle kinematics of the fp32 state) that are SECOND support points"""
+    gather = o.cfg.n_food + o.cfg.n_poison if o.cfg.env_kind in (1, 3) else 0
+    n = 0
+    for i in rows:
+        q = o.state[i, :15].astype(np.float64)
+        it = o.items[i, :2 * gather].astype(np.float64) if gather else None
+        n += orc.lib().orc_ant_second_points_f64(C.byref(o.cfg), orc.ptr(q), orc.ptr(it) if gather else None, gather)
+    return n
+
+
+def feet_flat_against_the_maze_box(o, rng):
+    """Every env of the maze OracleEnv `o`: the ant beside one of the four vertical faces of the maze box [-5, 1] x [-2, 2] x [0, 2] (maze_scene.py:12-13,
+    assets/box.xml:12), the feet of the two legs that point towards the box hanging (nearly) straight down -- their axes run alongside the face, up to
+    1 cm inside its contact shell or 1.5 cm outside, a degree or two off parallel: capsules that lie FLAT on a face (second support points)."""
+    n = o.N
+    for i in range(n):
+        k = rng.randint(4)   # face: x = 1 (ant to the east), y = 2 (north), x = -5 (west), y = -2 (south): the configuration turned by k * 90 degrees
+        yaw = k * np.pi / 2 + rng.uniform(-0.02, 0.02)
+        q = np.zeros(15); q[5], q[6] = np.sin(yaw / 2), np.cos(yaw / 2)
+        off = rng.uniform(-1.5, 1.5, 4)
+        q[7:] = np.radians([0, 45, 0, -90 + off[0], 0, -90 + off[1], 0, 45]) + np.r_[rng.uniform(-0.02, 0.02), 0, rng.uniform(-0.02, 0.02), 0, rng.uniform(-0.02, 0.02), 0, rng.uniform(-0.02, 0.02), 0]
+        q[2] = rng.uniform(0.9, 1.6)
+        gap = rng.uniform(-0.01, 0.015)
+        d = 0.08 + gap + 0.4   # the two ankle points are 0.4 towards the box from the torso centre (level torso)
+        along = rng.uniform(-1.2, 1.2)
+        q[:2] = [(1 + d, along), (along * 1.5 - 2.0, 2 + d), (-5 - d, along), (along * 1.5 - 2.0, -2 - d)][k]
+        o.state[i, :15] = q.astype(np.float32)
+        o.state[i, 15:29] = rng.normal(size=14).astype(np.float32) * 0.05
+        o.state[i, 30] = 0.25
+    return n
+
+
+def feet_flat_on_cubes(o, rng):
+    """Every env of the gather OracleEnv `o`: legs stretched out level (ankles near 0 -- outside their range, a state like any other: the limit rows push
+    back), the torso so low that the foot capsules LIE on the tops of cubes put under them (assets/food.xml:12: tops at z = 0.225), within the contact
+    shell: flat capsule-on-face contacts with second support points at the far edge of the cube's top."""
+    n = o.N
+    ni = o.cfg.n_food + o.cfg.n_poison
+    for i in range(n):
+        yaw = rng.uniform(-np.pi, np.pi)
+        q = np.zeros(15); q[5], q[6] = np.sin(yaw / 2), np.cos(yaw / 2)
+        q[:2] = rng.uniform(-4, 4, 2)
+        sg = np.array([1, -1, -1, 1.0])   # the ankles' positive sense, leg by leg (assets/ant.xml:21,32,43,54)
+        q[7::2] = rng.uniform(-0.05, 0.05, 4)
+        q[8::2] = sg * rng.uniform(-0.015, 0.03, 4)
+        q[2] = 0.225 + 0.08 + rng.uniform(-0.008, 0.012)
+        pts = leg_points(o.cfg.model, q)
+        frac = rng.uniform(0.3, 0.7, 4)[:, None]
+        cen = pts[:, 1, :2] + frac * (pts[:, 2, :2] - pts[:, 1, :2])
+        items = rng.uniform(5.5, 7.0, (ni, 2)) * np.where(rng.rand(ni, 2) < 0.5, -1, 1)
+        items[:4] = cen
+        o.state[i, :15] = q.astype(np.float32)
+        o.state[i, 15:29] = rng.normal(size=14).astype(np.float32) * 0.05
+        o.state[i, 30] = 0.75
+        o.items[i, :2 * ni] = items.reshape(-1).astype(np.float32)
+    return n

@@ -922,3 +922,43 @@ def test_straggler_threshold_follows_the_model():
         rows.append(o.solver_rows / 4.0)
     rows = np.concatenate(rows)
     assert np.percentile(rows, 95) <= 20.0 and np.percentile(rows, 90) >= 19.0 and (rows > 20).mean() < 0.02, np.percentile(rows, [50, 90, 95, 99])
+
+
+@pytest.mark.parametrize('group', [0, 1])
+def test_second_support_points_of_capsules_lying_flat_on_a_box_face(group):
+    """A capsule that rests flat on a face of the maze box (assets/box.xml:12) or on the top of an item cube (assets/food.xml:12) gets a SECOND support
+    point (Bullet keeps a manifold there; with one point the capsule rocks): feet hanging alongside the box's vertical faces, legs stretched out level
+    over cubes -- states full of such contacts, counted; wave phases == oracle bit for bit in both launch shapes, the contact cap included."""
+    import capsule_cases as cc
+    n = 32
+    rng = np.random.RandomState(12)
+    for cap in (12, 5):
+        cfg = orc.default_config(K.HRL_ANT_MAZE, num_envs=n, seed=4, auto_reset=1, model_step_group=group, model_max_contacts=cap)
+        o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+        o.reset(); e.reset()
+        seconds = 0
+        for t in range(4):
+            cc.feet_flat_against_the_maze_box(o, rng)
+            seconds += cc.count_second_points(o, range(n))
+            e.state[...] = o.state; e.aux[...] = o.aux
+            for k in range(2):
+                a = (rng.uniform(-1, 1, (n, 8)) * 0.3).astype(np.float32)
+                o.step(a); e.step(a)
+                for name in ('state', 'aux', 'obs', 'rew', 'done', 'info', 'solver_rows'):
+                    assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (cap, t, k, name)
+        assert seconds >= (60 if cap == 12 else 10), (cap, seconds)
+    cfg = orc.default_config(K.HRL_ANT_GATHER, num_envs=n, seed=4, auto_reset=1, robot_coll_dist=0.0, model_step_group=group)
+    o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+    o.reset(); e.reset()
+    seconds = paid = 0
+    for t in range(4):
+        cc.feet_flat_on_cubes(o, rng)
+        seconds += cc.count_second_points(o, range(n))
+        e.state[...] = o.state; e.items[...] = o.items; e.aux[...] = o.aux
+        for k in range(2):
+            a = (rng.uniform(-1, 1, (n, 8)) * 0.2).astype(np.float32)
+            o.step(a); e.step(a)
+            for name in ('state', 'items', 'aux', 'obs', 'rew', 'done', 'info', 'solver_rows'):
+                assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, k, name)
+            paid += int((o.info[:, 0] != 0).sum())
+    assert seconds >= 100 and paid >= 60, (seconds, paid)

@@ -538,6 +538,47 @@ def test_capsule_mid_sections_against_cubes_and_the_maze_box_on_device():
     assert mid >= 30, mid
 
 
+def test_second_support_points_on_device():
+    """A capsule that rests flat on a face of the maze box or on the top of an item cube gets a SECOND support point (Bullet keeps a manifold there):
+    feet hanging alongside the box's vertical faces, legs stretched out level over cubes (tests/capsule_cases.py) -- states full of such contacts,
+    counted; device == oracle bit for bit, the default group launch and the one-wave-per-env shape, a tight contact cap included."""
+    import capsule_cases as cc
+    n = 256
+    rng = np.random.RandomState(12)
+    for group, cap in ((0, 12), (1, 12), (0, 5)):
+        g, o = make(K.HRL_ANT_MAZE, n, seed=4, model_step_group=group, model_max_contacts=cap)
+        g.reset(); o.reset()
+        g.count_solver_rows()
+        seconds = 0
+        for t in range(3):
+            cc.feet_flat_against_the_maze_box(o, rng)
+            seconds += cc.count_second_points(o, range(0, n, 4))
+            push(g, o)
+            for k in range(2):
+                a = (rng.uniform(-1, 1, (n, 8)) * 0.3).astype(np.float32)
+                go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+                assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True), (group, cap, t, k)
+                assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(gd.cpu().numpy(), o.done) and np.array_equal(g.solver_rows.cpu().numpy(), o.solver_rows), (group, cap, t, k)
+                assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0
+        assert seconds >= (100 if cap == 12 else 20), (group, cap, seconds)
+    for group in (0, 1):
+        g, o = make(K.HRL_ANT_GATHER, n, seed=4, robot_coll_dist=0.0, model_step_group=group)
+        g.reset(); o.reset()
+        seconds = paid = 0
+        for t in range(3):
+            cc.feet_flat_on_cubes(o, rng)
+            seconds += cc.count_second_points(o, range(0, n, 4))
+            push(g, o)
+            for k in range(2):
+                a = (rng.uniform(-1, 1, (n, 8)) * 0.2).astype(np.float32)
+                go, gr, gd, gi = g.step(torch.from_numpy(a).cuda()); o.step(a)
+                assert np.array_equal(g.state.cpu().numpy(), o.state, equal_nan=True) and np.array_equal(g.items.cpu().numpy(), o.items), (group, t, k)
+                assert np.array_equal(gr.cpu().numpy(), o.rew) and np.array_equal(g.info.cpu().numpy(), o.info) and np.array_equal(gd.cpu().numpy(), o.done), (group, t, k)
+                assert obs_bad_rows(go.cpu().numpy(), o.obs).sum() == 0
+                paid += int((o.info[:, 0] != 0).sum())
+        assert seconds >= 150 and paid >= 300, (group, seconds, paid)
+
+
 def test_self_collision_rows_on_device():
     """Hips forced beyond their range so that capsules of different legs meet: the two-body rows (second impulse response,
     10-term row products) on the device equal the oracle's bit for bit."""
