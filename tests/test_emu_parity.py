@@ -962,3 +962,26 @@ def test_second_support_points_of_capsules_lying_flat_on_a_box_face(group):
                 assert np.array_equal(getattr(o, name), getattr(e, name), equal_nan=True), (t, k, name)
             paid += int((o.info[:, 0] != 0).sum())
     assert seconds >= 100 and paid >= 60, (seconds, paid)
+
+
+def test_observe_shows_the_feet_flags_the_last_step_left():
+    """hrl_observe (include/hrl_envs.h): the feet-contact entries of an AntMaze / AntFlagrun observation are what robot.feet_contact holds in the reference at
+    that point -- the flags the LAST step left (bits 28..31 of aux[1]), zeros right after a reset; a replay that wants zeros clears the bits with the
+    state it writes.  Wave phases == oracle, and both == the bits."""
+    for kind, lo in ((K.HRL_ANT_MAZE, 22), (K.HRL_ANT_FLAGRUN, 24)):
+        cfg = orc.default_config(kind, num_envs=8, seed=3, auto_reset=0, max_episode_steps=0)
+        o, e = orc.OracleEnv(cfg, np.float32), emu_env.EmuEnv(cfg)
+        o.reset(); e.reset()
+        o.observe(); e.observe()
+        assert np.array_equal(o.obs, e.obs) and np.all(o.obs[:, lo:lo + 4] == 0)
+        for t in range(30):
+            o.step(np.zeros((8, 8), np.float32)); e.step(np.zeros((8, 8), np.float32))
+        bits = (o.aux[:, 1].view(np.uint32) >> 28) & 0xf
+        want = ((bits[:, None] >> np.arange(4)) & 1).astype(np.float32)
+        assert want.sum() >= 8   # standing ants: feet on the floor
+        o.obs[...] = -7; e.obs[...] = -7
+        o.observe(); e.observe()
+        assert np.array_equal(o.obs, e.obs) and np.array_equal(o.obs[:, lo:lo + 4], want)
+        o.aux[:, 1] &= 0x0fffffff; e.aux[...] = o.aux   # the replay's way to zeros
+        o.observe(); e.observe()
+        assert np.array_equal(o.obs, e.obs) and np.all(o.obs[:, lo:lo + 4] == 0)

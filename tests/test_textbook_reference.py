@@ -612,3 +612,30 @@ def test_capsule_flat_on_a_box_face_gets_a_second_support_point():
     d = np.array([o5.contact_dist[c] for c in range(8)])
     span = 0.25 / np.cos(np.pi / 4)   # the cube's top along a foot that crosses it diagonally... the legs run along the diagonals of the axis-aligned cubes
     assert np.all(np.abs(d[:4]) < 0.008) and np.all(d[4:] >= d[:4] - 1e-12) and np.all(d[4:] - d[:4] < span * np.sin(np.radians(1.0)) + 1e-4), d
+
+
+def test_second_support_points_optimised_equals_textbook_on_flat_capsules():
+    """States FULL of capsules lying flat on box faces (tests/capsule_cases.py: feet alongside the maze box's faces, legs level over cubes): the optimised
+    specification's second support points -- found by one pass over the kept contacts behind the slope question of second_point -- and the textbook's
+    (a second loop over all first contacts, no such question) are the same contacts: every count equal, the substep's result to 1e-5.  (Not the 1e-9 of the
+    random states: where a leg's aux capsule ends and its foot capsule begins both touch the face at the shared ankle point, two rows are EXACTLY
+    dependent -- as they were before second points existed -- and how Gauss-Seidel splits the load between them is a matter of rounding.)"""
+    import capsule_cases as cc
+    rng = np.random.RandomState(5)
+    seconds = checked = 0
+    worst = 0.0
+    for kind, gen in ((K.HRL_ANT_MAZE, cc.feet_flat_against_the_maze_box), (K.HRL_ANT_GATHER, cc.feet_flat_on_cubes)):
+        cfg = orc.default_config(kind, num_envs=48)
+        o = orc.OracleEnv(cfg, np.float64); o.reset()
+        for rep in range(3):
+            gen(o, rng)
+            seconds += cc.count_second_points(o, range(48))
+            for i in range(48):
+                q, u, tau = o.state[i, :15].copy(), o.state[i, 15:29].copy(), rng.uniform(-100, 100, 8)
+                items = o.items[i, :32].reshape(16, 2).copy() if kind == K.HRL_ANT_GATHER else None
+                p = tb.params(cfg, items=items) if items is not None else tb.params(cfg)
+                q1, u1, out = tb.ant_substep(p, q, u, tau)
+                q2, u2, info, dbg, _ = orc_substeps_items(cfg, q, u, tau, items if items is not None else np.zeros((0, 2)))
+                assert (info[0], info[1], info[2]) == (out.n_rows, out.n_limits, out.n_contacts) and dbg[0] == out.n_candidates, (kind, rep, i, info, out.n_rows, out.n_candidates)
+                worst = max(worst, np.abs(q1 - q2).max(), np.abs(u1 - u2).max()); checked += 1
+    assert worst < 1e-5 and seconds > 400 and checked == 288, (worst, seconds)
