@@ -7,6 +7,7 @@ deceleration, limit penetration, LCP residual).  No GPU needed.
 
 What this does NOT show: agreement with pybullet (absent: parity of the rigid-body step stays unpinned)."""
 import ctypes as C
+import zlib
 
 import numpy as np
 import pytest
@@ -56,7 +57,7 @@ def test_optimised_spec_equals_textbook_per_substep(name, kind, kw, gen):
     """1000 random contact states over the worlds: one substep, q and u to <= 1e-9, identical row/contact counts."""
     cfg = orc.default_config(kind, **kw)
     p = tb.params(cfg)
-    rng = np.random.RandomState(hash(name) % 2**31)
+    rng = np.random.RandomState(zlib.crc32(name.encode()))   # (not hash(): salted per process)
     n_states = 1000 if name == 'gather arena' else 250
     worst, rows, contacts, dropped = 0.0, [], [], 0
     for i in range(n_states):
