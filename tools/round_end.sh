@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: everything the committed evidence under profiles/ is made from, in one call (about five minutes):
 # the -m gpu tests, the rocprofv3 passes of all six kinds, and the bench lines of every BASELINE configuration.
-#   usage: tools/round_end.sh <tag> [round prefix, default r5]     outputs under gpurun_out/<tag>_*; then on the build machine:
+#   usage: tools/round_end.sh <tag> [round prefix, default r6]     outputs under gpurun_out/<tag>_*; then on the build machine:
 #          cp gpurun_out/<tag>_profiles/* profiles/ and the bench lines you want to keep
 set -e
 T=${1:?tag}; mkdir -p gpurun_out
@@ -13,7 +13,7 @@ for k in gather flat point maze maze_mj flagrun; do
   bash tools/profile_round.sh gpurun_out/prof_${T}_$k $k $n > gpurun_out/prof_${T}_$k.log 2>&1 && echo profiled $k
 done
 # condense them where the bench runs, so that its line carries the counters of exactly these kernels; the files travel back under gpurun_out/
-R=${2:-r5}
+R=${2:-r6}
 for k in gather flat point maze maze_mj flagrun; do
   n=4096; [ $k = maze ] && n=8192
   name=${R}_$k; [ $k = gather ] && name=${R}_final
