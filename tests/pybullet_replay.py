@@ -12,9 +12,9 @@ import orc
 from hrl_pybullet_envs_amd import _capi as K
 
 KIND = {'AntGatherBulletEnv': K.HRL_ANT_GATHER, 'AntMazeBulletEnv': K.HRL_ANT_MAZE, 'PointGatherBulletEnv': K.HRL_POINT_GATHER,
-        'AntFlagrunBulletEnv': K.HRL_ANT_FLAGRUN}
+        'AntFlagrunBulletEnv': K.HRL_ANT_FLAGRUN, 'AntMazeMjEnv': K.HRL_ANT_MAZE_MJ, 'AntMjEnv': K.HRL_ANT_FLAT}
 # SURVEY 8d "Parity tolerance to state": one env step from identical inputs, oracle-fp64 against the reference
-TOL = {'qpos': 1e-4, 'qvel': 1e-2, 'obs': 1e-4, 'rew': 1e-4}
+TOL = {'qpos': 1e-4, 'qvel': 1e-2, 'obs': 1e-4, 'rew': 1e-4, 'walk_target_dist': 1e-4}
 
 
 def ant_masses(rho):
@@ -34,7 +34,7 @@ def config_for(kind, r, model=None):
     """the oracle config one record is replayed under: the reference's constructor defaults (what gym.make builds), the record's own target, and for
     flagrun the MANUAL goal mode -- the recorded goals are data there (items record), not draws of the oracle's own stream"""
     kw = {'model_' + k: v for k, v in (model or {}).items()}
-    if kind == K.HRL_ANT_MAZE and r.get('target') is not None:
+    if kind in (K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ) and r.get('target') is not None:
         kw['targets'] = [tuple(r['target'][:2])]
     if kind == K.HRL_ANT_FLAGRUN:
         kw['flag_manual_goals'] = 1
@@ -95,8 +95,8 @@ def replay(files, model=None):
                                       'numSolverIterations': eng.get('numSolverIterations') == m0.solver_iters,
                                       'gravityAccelerationZ': _close(eng.get('gravityAccelerationZ'), -m0.gravity), 'contactERP': _close(eng.get('contactERP'), m0.contact_erp)}
         # ---- replay
-        dev = {k: [] for k in ('qpos', 'qvel', 'obs', 'rew')}
-        done_flips = steps = pickups = 0
+        dev = {k: [] for k in ('qpos', 'qvel', 'obs', 'rew', 'walk_target_dist')}
+        done_flips = steps = pickups = feet_flips = 0
         base = {K.HRL_ANT_GATHER: 26, K.HRL_POINT_GATHER: 8}.get(kind)
         for ep in g['episodes']:
             for t, r in enumerate(ep['steps']):
@@ -116,7 +116,16 @@ def replay(files, model=None):
                     dev['obs'].append(np.nanmax(np.abs(o.obs[0, :n] - ob[:n])))
                 dev['rew'].append(abs(float(o.rew[0]) - r['rew']))
                 done_flips += int(bool(o.done[0]) != r['done']); steps += 1
-        rep['steps'] = steps; rep['done_flips'] = done_flips; rep['pickup_steps'] = pickups
+                rob = r.get('robot') or {}
+                # upstream's own bookkeeping after the step, where the oracle keeps a counterpart: robot.feet_contact (bits 28..31 of aux[1]) and
+                # robot.walk_target_dist (from the PARTS CENTROID; the oracle's potential = -dist / dt) -- the locomotion kinds
+                if kind in (K.HRL_ANT_MAZE, K.HRL_ANT_FLAGRUN) and rob.get('feet_contact') is not None:
+                    bits = (int(o.aux[0, 1]) >> 28) & 0xf
+                    feet_flips += int([(bits >> l) & 1 for l in range(4)] != [int(bool(f)) for f in rob['feet_contact']])
+                if kind not in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) and rob.get('walk_target_dist') is not None and not r['done']:
+                    m = o.cfg.model
+                    dev['walk_target_dist'].append(abs(-float(o.state[0, K.HRL_POTENTIAL_OFF]) * m.timestep * m.frame_skip - rob['walk_target_dist']))
+        rep['steps'] = steps; rep['done_flips'] = done_flips; rep['pickup_steps'] = pickups; rep['feet_flips'] = feet_flips
         for k, v in dev.items():
             v = np.asarray(v)
             rep[k] = {'max': float(v.max()), 'median': float(np.median(v)), 'p99': float(np.percentile(v, 99))} if len(v) else None

@@ -39,7 +39,9 @@ FEET = ['front_left_foot', 'front_right_foot', 'left_back_foot', 'right_back_foo
 LO = np.radians([-40, 30, -40, -100, -40, -100, -40, 30])
 HI = np.radians([40, 100, 40, -30, 40, -30, 40, 100])
 KINDS = {'AntGatherBulletEnv': K.HRL_ANT_GATHER, 'AntMazeBulletEnv': K.HRL_ANT_MAZE, 'PointGatherBulletEnv': K.HRL_POINT_GATHER,
-         'AntFlagrunBulletEnv': K.HRL_ANT_FLAGRUN}
+         'AntFlagrunBulletEnv': K.HRL_ANT_FLAGRUN, 'AntMazeMjEnv': K.HRL_ANT_MAZE_MJ, 'AntMjEnv': K.HRL_ANT_FLAT}
+REGISTERED = ['AntGatherBulletEnv', 'AntMazeBulletEnv', 'PointGatherBulletEnv', 'AntFlagrunBulletEnv', 'AntMazeMjEnv']   # hrl_pybullet_envs/__init__.py:9 (AntMjEnv is not)
+MAZE_KINDS = (K.HRL_ANT_MAZE, K.HRL_ANT_MAZE_MJ)
 JOINT_REVOLUTE, JOINT_FIXED = 0, 4   # pybullet.JOINT_REVOLUTE / JOINT_FIXED
 GEOM_SPHERE, GEOM_BOX, GEOM_CAPSULE = 2, 3, 7
 
@@ -66,11 +68,11 @@ class Client:
         hx = hy = 0.0
         if env.kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) or (env.kind == K.HRL_ANT_FLAGRUN and (c.flag_enclosed or c.use_sensor)):
             hx, hy = c.world_size[0] / 2, c.world_size[1] / 2
-        if env.kind == K.HRL_ANT_MAZE:
+        if env.kind in MAZE_KINDS:
             hx, hy = 5.0, 9.0
         if hx:
             st += [('wall', [0, hy, 2.5], [25, 0.05, 2.5]), ('wall', [0, -hy, 2.5], [25, 0.05, 2.5]), ('wall', [hx, 0, 2.5], [0.05, 25, 2.5]), ('wall', [-hx, 0, 2.5], [0.05, 25, 2.5])]
-        if env.kind == K.HRL_ANT_MAZE:
+        if env.kind in MAZE_KINDS:
             st.append(('obstacle', [-2, 0, 1], [3, 2, 1]))
         self.statics = st
         self.n_items = c.n_food + c.n_poison if env.kind in (K.HRL_ANT_GATHER, K.HRL_POINT_GATHER) else 0
@@ -287,7 +289,7 @@ class StandinEnv:
 
     def goal_xy(self):
         c = self.o.cfg
-        if self.kind == K.HRL_ANT_MAZE:
+        if self.kind in MAZE_KINDS:
             return np.array(c.targets[int(self.o.aux[0, 3])][:], np.float64)
         if self.kind == K.HRL_ANT_FLAGRUN:
             g = np.zeros(2)
@@ -303,7 +305,7 @@ class StandinEnv:
         kind = self.__dict__.get('kind')
         if 'o' not in self.__dict__:
             raise AttributeError(k)
-        if kind == K.HRL_ANT_MAZE:
+        if kind in MAZE_KINDS:
             if k == 'target':
                 return self.goal_xy()
             if k == 't':
@@ -385,10 +387,12 @@ def install():
         JOINT_REVOLUTE=JOINT_REVOLUTE, JOINT_FIXED=JOINT_FIXED)
     mod('pybullet_envs')
     h = mod('hrl_pybullet_envs', standin=True)
-    for name in KINDS:   # hrl_pybullet_envs/__init__.py:9-16: `<ClassName>-v0`, max_episode_steps=2000
+    for name in REGISTERED:   # hrl_pybullet_envs/__init__.py:9-16: `<ClassName>-v0`, max_episode_steps=2000
         cls = (lambda n: (lambda **kw: StandinEnv(n)))(name)
         setattr(h, name, cls)
         register(id=name + '-v0', entry_point=cls, max_episode_steps=2000)
+    mod('hrl_pybullet_envs.envs')
+    mod('hrl_pybullet_envs.envs.MjAnt', AntMjEnv=lambda: StandinEnv('AntMjEnv'))   # envs/MjAnt.py:31-34: constructed directly, never registered
 
 
 def main():

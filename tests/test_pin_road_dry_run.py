@@ -7,7 +7,8 @@ This test makes sure that shot does not execute the recording code for the first
 which `gym`, `pybullet`, `pybullet_envs` and `hrl_pybullet_envs` are tests/pybullet_standin.py's duck-typed stand-ins -- pybullet getters and the
 reference classes' attributes answered by the fp64 CPU oracle under a PERTURBED hrl_model --, writing to a scratch directory; then
   (a) the replay of those records under the perturbed model deviates by ~0 in every quantity of every env (state order, quaternion convention, joint
-      order, item order, target, potential, initial_z, feet flags, flagrun goal bookkeeping all line up), and under the DEFAULT model the report is red;
+      order, item order, target, potential, initial_z, feet flags, flagrun goal bookkeeping all line up; all six kinds -- the pybulletgym flavour, which the
+      generator records where it imports and skips where it does not, included), and under the DEFAULT model the report is red;
   (b) the fit recovers the perturbation from the generator's own JSON;
   (c) tests/golden is untouched, stand-in records are marked and refused as fixtures.
 It says nothing about pybullet (the stand-in restates its getters' tuple layouts from memory) and pins nothing: the rigid-body step stays
@@ -30,7 +31,7 @@ import fit_model  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 PERTURBED = {'density': 850.0, 'contact_erp': 0.6, 'friction_ground': 0.55, 'solver_iters': 8}
-ANTS = ('AntGatherBulletEnv', 'AntMazeBulletEnv', 'AntFlagrunBulletEnv')
+ANTS = ('AntGatherBulletEnv', 'AntMazeBulletEnv', 'AntFlagrunBulletEnv', 'AntMazeMjEnv', 'AntMjEnv')
 
 
 def golden_digest():
@@ -56,7 +57,7 @@ def records(tmp_path_factory):
     assert p.returncode == 0, p.stderr[-2000:]
     files = sorted(str(out / f) for f in os.listdir(out))
     assert [os.path.basename(f) for f in files] == ['pybullet_AntFlagrunBulletEnv.json', 'pybullet_AntGatherBulletEnv.json', 'pybullet_AntMazeBulletEnv.json',
-                                                    'pybullet_PointGatherBulletEnv.json']
+                                                    'pybullet_AntMazeMjEnv.json', 'pybullet_AntMjEnv.json', 'pybullet_PointGatherBulletEnv.json']   # (the last two of the ant files: the optional pybulletgym flavour)
     assert golden_digest() == before, 'the dry run touched tests/golden'
     return files
 
@@ -73,7 +74,8 @@ def test_generator_records_what_the_replay_needs(records):
             assert [j['name'] for j in m['joints'] if j['type'] == 0] == ['hip_1', 'ankle_1', 'hip_2', 'ankle_2', 'hip_3', 'ankle_3', 'hip_4', 'ankle_4']
             assert abs(m['total_mass'] - pybullet_replay.ant_total(850.0)) < 1e-9
         assert m['engine']['numSubSteps'] == 4 and m['engine']['numSolverIterations'] == 8 and abs(m['engine']['fixedTimeStep'] - 0.0165) < 1e-9
-        assert len(g['episodes']) == 3 and g['obs_dim'] == {'AntGatherBulletEnv-v0': 46, 'AntMazeBulletEnv-v0': 38, 'PointGatherBulletEnv-v0': 18, 'AntFlagrunBulletEnv-v0': 28}[g['env_id']]
+        assert len(g['episodes']) == 3 and g['obs_dim'] == {'AntGatherBulletEnv-v0': 46, 'AntMazeBulletEnv-v0': 38, 'PointGatherBulletEnv-v0': 18, 'AntFlagrunBulletEnv-v0': 28,
+                                                            'AntMazeMjEnv-v0': 60, 'AntMjEnv': 29}[g['env_id']]
         n = 0
         for ep in g['episodes']:
             for r in ep['steps']:
@@ -98,6 +100,7 @@ def test_replay_agrees_with_the_engine_that_made_the_records_and_is_red_for_anot
         assert r['done_flips'] == 0 and r['steps'] >= 60, (name, r)
         for k in ('qpos', 'qvel', 'obs', 'rew'):
             assert r[k]['max'] < 1e-9, (name, k, r[k])   # same engine, same state: the replay reconstructs EVERYTHING a step reads
+        assert r['feet_flips'] == 0 and (r['walk_target_dist'] is None or r['walk_target_dist']['max'] < 1e-9)   # ... and upstream's own bookkeeping after the step
         if name in ANTS:
             assert abs(r['density_estimate'] - 850.0) < 1e-6 and r['density_hypothesis'] == 1000
             assert r['engine_equals_build'] == {'fixedTimeStep': True, 'numSubSteps': True, 'numSolverIterations': False, 'gravityAccelerationZ': True, 'contactERP': False}
@@ -123,7 +126,7 @@ def test_fit_recovers_the_engine_from_the_generators_own_json(records):
 
 def test_standin_records_never_become_fixtures(records, tmp_path):
     before = golden_digest()
-    p = run_generator(GOLDEN, '--steps', '2', '--seeds', '1')   # the generator's default --out, with the stand-ins installed
+    p = run_generator(GOLDEN, '--steps', '2', '--seeds', '1', '--no-optional')   # the generator's default --out, with the stand-ins installed
     assert p.returncode != 0 and 'scratch directory' in p.stderr, p.stderr[-500:]
     assert golden_digest() == before and not [f for f in os.listdir(GOLDEN) if f.startswith('pybullet_')]
     # a stand-in record that found its way there would be refused by the replay test (it checks `versions.standin` before anything else)

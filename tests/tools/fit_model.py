@@ -27,7 +27,7 @@ import orc  # noqa: E402
 from hrl_pybullet_envs_amd import _capi as K  # noqa: E402
 
 KIND = {'AntGatherBulletEnv': K.HRL_ANT_GATHER, 'AntMazeBulletEnv': K.HRL_ANT_MAZE, 'PointGatherBulletEnv': K.HRL_POINT_GATHER,
-        'AntFlagrunBulletEnv': K.HRL_ANT_FLAGRUN, 'AntMjEnv': K.HRL_ANT_FLAT}
+        'AntFlagrunBulletEnv': K.HRL_ANT_FLAGRUN, 'AntMjEnv': K.HRL_ANT_FLAT, 'AntMazeMjEnv': K.HRL_ANT_MAZE_MJ}
 # (lower, upper) of the search, in the parameter's own unit; positive ones are searched in log space
 CONTINUOUS = {'density': (1.0, 5000.0), 'contact_erp': (0.0, 1.0), 'limit_erp': (0.0, 1.0), 'friction_ground': (0.0, 3.0), 'friction_robot': (0.0, 4.0),
               'contact_dist': (0.0, 0.1), 'limit_margin': (0.0, 1.0), 'linear_damping': (0.0, 20.0), 'angular_damping': (0.0, 20.0),

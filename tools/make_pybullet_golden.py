@@ -31,6 +31,9 @@ import os
 import sys
 
 ENV_IDS = ['AntGatherBulletEnv-v0', 'AntMazeBulletEnv-v0', 'PointGatherBulletEnv-v0', 'AntFlagrunBulletEnv-v0']
+# the pybulletgym flavour (reference README.md:7: installed from GitHub, not in requirements.txt): recorded where it imports, skipped with the reason
+# where it does not.  AntMjEnv is never registered (hrl_pybullet_envs/__init__.py:9): it is constructed from its module (envs/MjAnt.py:31-34).
+OPTIONAL_ENV_IDS = ['AntMazeMjEnv-v0', 'hrl_pybullet_envs.envs.MjAnt:AntMjEnv']
 JOINT_ORDER = ['hip_1', 'ankle_1', 'hip_2', 'ankle_2', 'hip_3', 'ankle_3', 'hip_4', 'ankle_4']   # URDF link order (assets/ant.xml:18-54)
 
 
@@ -145,12 +148,21 @@ def task_state(u):
     return out
 
 
-def record(env_id, seeds, steps):
+def make_env(env_id):
+    """a registered id through gym.make (with its TimeLimit, hrl_pybullet_envs/__init__.py:15), or `module:Class` constructed directly"""
     import gym
+    if ':' not in env_id:
+        return gym.make(env_id)
+    import importlib
+    mod, cls = env_id.split(':')
+    return getattr(importlib.import_module(mod), cls)()
+
+
+def record(env_id, seeds, steps):
     import numpy as np
-    out = {'env_id': env_id, 'episodes': []}
+    out = {'env_id': env_id.split(':')[-1], 'episodes': []}
     for seed in range(seeds):
-        env = gym.make(env_id)
+        env = make_env(env_id)
         env.seed(seed)
         obs0 = env.reset()
         pr = Probe(env)
@@ -191,6 +203,7 @@ def main():
     ap.add_argument('--seeds', type=int, default=8)
     ap.add_argument('--out', default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
     ap.add_argument('--envs', nargs='*', default=ENV_IDS)
+    ap.add_argument('--no-optional', action='store_true', help='do not try the pybulletgym flavour (AntMazeMjEnv-v0, AntMjEnv)')
     a = ap.parse_args()
     missing = need(['numpy', 'pybullet', 'pybullet_envs', 'gym', 'hrl_pybullet_envs'])
     if missing:
@@ -207,10 +220,16 @@ def main():
         if os.path.realpath(a.out) == os.path.realpath(golden):
             sys.exit('make_pybullet_golden: stand-in packages are installed (a dry run): give --out a scratch directory, tests/golden is for records of the real pybullet')
     os.makedirs(a.out, exist_ok=True)
-    for env_id in a.envs:
-        data = record(env_id, a.seeds, a.steps)
+    for env_id in list(a.envs) + ([] if a.no_optional else OPTIONAL_ENV_IDS):
+        try:
+            data = record(env_id, a.seeds, a.steps)
+        except Exception as e:  # noqa: BLE001
+            if env_id not in OPTIONAL_ENV_IDS:
+                raise
+            print(f'{env_id}: skipped ({type(e).__name__}: {e}) -- the pybulletgym flavour is optional')
+            continue
         data['versions'] = versions
-        name = 'pybullet_' + env_id.split('-')[0] + '.json'
+        name = 'pybullet_' + data['env_id'].split('-')[0] + '.json'
         with open(os.path.join(a.out, name), 'w') as f:
             json.dump(data, f, allow_nan=True)
         print(name, sum(len(e['steps']) for e in data['episodes']), 'steps, total mass', data['model']['total_mass'])
