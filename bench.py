@@ -274,8 +274,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
-    if 'WORLD_SIZE' in os.environ:   # a rank of the driver's own torch.distributed.run: the same check, before the rendezvous (every rank leaves with 2 at once)
-        preflight(int(os.environ['WORLD_SIZE']), args.backend)
+    if 'WORLD_SIZE' in os.environ:   # a rank of the driver's own torch.distributed.run: the same check, before the rendezvous (every rank leaves with 2 at once);
+        #                              the ranks of THIS node are what its GPUs must cover (LOCAL_WORLD_SIZE, set by torch.distributed.run)
+        preflight(int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ['WORLD_SIZE']), args.backend)
 
     import torch
 
