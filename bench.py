@@ -132,6 +132,12 @@ def preflight(ranks, backend):
     have = count_gpus()
     if backend == 'gloo' or have is None or have >= ranks:
         return
+    try:   # a second opinion before refusing a run: torch's own count (does not initialise the GPU on this image); whoever sees enough devices wins
+        import torch
+        if torch.cuda.device_count() >= ranks:
+            return
+    except Exception:  # noqa: BLE001
+        pass
     print(f'bench.py: --gpus {ranks} asks for {ranks} ranks (one GPU each), this machine shows {have} GPU(s) '
           f'(KFD topology, ROCR_/HIP_VISIBLE_DEVICES): not started', file=sys.stderr, flush=True)
     sys.exit(2)
