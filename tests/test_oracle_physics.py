@@ -247,3 +247,46 @@ def test_pointbot_is_stopped_by_a_cube_under_the_middle_of_a_face():
     f[:] = [40.0 * nx, 40.0 * ny, 0.0]
     q, u, info = run(yaw, c)
     assert abs(q[0] * nx + q[1] * ny - gap) < 0.015 and abs(u[3] * nx + u[4] * ny) < 0.03 and info[1] >= 1
+
+
+def test_upright_player_cube_needs_no_edge_edge_test_against_item_cubes():
+    """the PointBot's contacts with an item cube are corner-in-box tests both ways (the player's 8 corners against the cube, the cube's 8 against
+    the player's oriented box); box-box EDGE-EDGE crossings are not generated.  While the player cube is upright the two footprints are squares of sides
+    0.7 (assets/player_cube.xml:8) and 0.25 (assets/food.xml:12): two squares whose sides differ by more than sqrt 2 cannot overlap without a corner of
+    one inside the other, so the corner tests are complete.  Checked, not just argued: random yaws and offsets around touching -- whenever the footprints
+    overlap by a millimetre or more the collision pass reports a contact with the cube, and whenever they are further apart than the contact distance
+    (+ rounding) it reports none."""
+    cfg = orc.default_config(K.HRL_POINT_GATHER, num_envs=1, seed=0)
+    rng = np.random.RandomState(4)
+
+    def square(c, half, yaw):
+        R = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        return c + (R @ (np.array([[1, 1], [-1, 1], [-1, -1], [1, -1]]).T * half)).T
+
+    def signed_gap(A, B):
+        """separating-axis distance of two convex polygons: > 0 apart (a lower bound of the distance, exact when a face separates), < 0: overlap depth"""
+        best = -1e9
+        for P, Q in ((A, B), (B, A)):
+            for i in range(len(P)):
+                e = P[(i + 1) % len(P)] - P[i]
+                n = np.array([e[1], -e[0]]) / np.linalg.norm(e)
+                best = max(best, (Q @ n).min() - (P @ n).max())
+        return best
+    overlaps = apart = 0
+    for trial in range(3000):
+        yaw = rng.uniform(-np.pi, np.pi)
+        ang = rng.uniform(-np.pi, np.pi)
+        d = rng.uniform(0.30, 0.72)   # centre distance: from deep overlap to clear of each other (0.35 sqrt 2 + 0.125 sqrt 2 = 0.67)
+        cube = np.array([d * np.cos(ang), d * np.sin(ang)])
+        gap = signed_gap(square(np.zeros(2), 0.35, yaw), square(cube, 0.125, 0.0))
+        q = np.array([0, 0, 0.355, 0, 0, np.sin(yaw / 2), np.cos(yaw / 2)])   # resting on the floor: z spans [0.005, 0.705], the cube's [-0.025, 0.225]
+        items = np.full((16, 2), 50.0); items[0] = cube
+        info = np.zeros(3, np.int32)
+        orc.lib().orc_point_substeps_items_f64(C.byref(cfg), orc.ptr(q.copy()), orc.ptr(np.zeros(6)), orc.ptr(np.zeros(3)), 1, orc.ptr(items.reshape(-1).copy()), 16, orc.ptr(info))
+        if gap <= -1e-3:
+            overlaps += 1
+            assert info[1] >= 1, (trial, yaw, cube, gap, info)
+        elif gap >= cfg.model.contact_dist + 1e-6:
+            apart += 1
+            assert info[1] == 0, (trial, yaw, cube, gap, info)
+    assert overlaps > 800 and apart > 300, (overlaps, apart)
