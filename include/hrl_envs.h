@@ -117,7 +117,8 @@ typedef struct hrl_model {
      * separating velocity of restitution * (approach speed) (Bullet combines the two bodies' restitutions by their product, SURVEY A.3:
      * ground / walls 0.5 (sizeable_enclosed_scene.py:60) x robot 0 = 0).  Default 0: every contact is plastic. */
     float restitution, restitution_threshold; /* 0, 0.2 m/s */
-    /* contacts kept per substep, 1..12 (candidates beyond it are dropped in candidate order: ground, walls, boxes, cubes, capsule pairs).
+    /* contacts kept per substep, 1..12 (candidates beyond it are dropped in candidate order: ground, walls, the maze box, cubes, then the second support
+     * points of capsules lying flat on a box face, then capsule pairs).
      * Default 12, the most the solver's 44 rows hold. */
     int32_t max_contacts;
     /* assets/ant.xml:8 gives every joint `armature="1" damping="1"` (MuJoCo's rotor inertia, kg m^2, and viscous damping, N m s / rad).  Whether
