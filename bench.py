@@ -133,9 +133,12 @@ def preflight(ranks, backend):
     if backend == 'gloo' or have is None or have >= ranks:
         return
     try:   # a second opinion before refusing a run: torch's own count (does not initialise the GPU on this image); whoever sees enough devices wins
+        import warnings
         import torch
-        if torch.cuda.device_count() >= ranks:
-            return
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')   # (a machine without a usable driver warns here; the count it returns is what is asked for)
+            if torch.cuda.device_count() >= ranks:
+                return
     except Exception:  # noqa: BLE001
         pass
     print(f'bench.py: --gpus {ranks} asks for {ranks} ranks (one GPU each), this machine shows {have} GPU(s) '
